@@ -1,0 +1,152 @@
+"""AIR component definitions for the hot-path operators (oracle; test infrastructure only).
+
+Row layouts, padding rows, constraint order and logup relations restate
+  Add    `crates/air/src/components/add/{table.rs:20-58,191-216, component.rs:38-116, witness.rs:33-167}`
+  Mul    `crates/air/src/components/mul/{table.rs:19-36, component.rs:40-126, witness.rs:18-165}`
+  Recip  `crates/air/src/components/recip/{table.rs:20-54, component.rs:38-107}`
+  Inputs `crates/air/src/components/inputs/{table.rs:20-44, components.rs:37-85}`
+`eval_fixed_{add,mul,recip}` live in numerair@11d1d26 (un-vendored).  KAT evidence (SURVEY.md §2.1,
+A.7) pins: eval_fixed_add = 1 constraint `out-(lhs+rhs)`; eval_fixed_mul = 2 constraint slots, the
+first `lhs*rhs-(out*scale+rem)`, the second contributing zero whenever rem == 0 — restated here as
+a zero slot (**unpinned for rem != 0**).  eval_fixed_recip is **unpinned**; `scale^2-(input*out+rem)`
+is used.
+
+Constraint functions are polymorphic: they run on `MV` (numpy M31 vectors, prover side) and on
+scalar `QM31` (OODS point, verifier side).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+from .field import P, U64, QM31, m_add, m_mul, m_sub
+
+FP_SCALE = 1 << 12  # DEFAULT_FP_SCALE = 12, crates/air/src/lib.rs:23-24
+
+
+class MV:
+    """numpy M31 vector with field operators (so constraint code reads like the Rust AIR)."""
+
+    __slots__ = ("a",)
+
+    def __init__(self, a):
+        self.a = np.asarray(a, dtype=U64)
+
+    @staticmethod
+    def _c(o):
+        return o.a if isinstance(o, MV) else U64(int(o) % P)
+
+    def __add__(self, o):
+        return MV(m_add(self.a, MV._c(o)))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return MV(m_sub(self.a, MV._c(o)))
+
+    def __rsub__(self, o):
+        return MV(m_sub(MV._c(o), self.a))
+
+    def __mul__(self, o):
+        return MV(m_mul(self.a, MV._c(o)))
+
+    __rmul__ = __mul__
+
+
+# kind ids = TraceTable variant order, crates/air/src/pie.rs:31-66
+KIND_ADD, KIND_MUL, KIND_RECIP, KIND_SIN, KIND_SIN_LOOKUP, KIND_SUM_REDUCE, KIND_MAX_REDUCE, KIND_SQRT, \
+    KIND_REM, KIND_EXP2, KIND_EXP2_LOOKUP, KIND_LOG2, KIND_LOG2_LOOKUP, KIND_LESS_THAN, \
+    KIND_RANGE_CHECK_LOOKUP, KIND_INPUTS, KIND_CONTIGUOUS = range(17)
+N_KINDS = 17
+# KAT-era claim struct had 8 options: add, mul, recip, sin, sin_lookup, sum_reduce, max_reduce, sqrt? —
+# only the count (8) and the first two slots are pinned by the KAT bytes.
+N_KINDS_KAT = 8
+
+
+@dataclass
+class Component:
+    name: str
+    kind: int
+    n_cols: int
+    padding: Tuple[int, ...]
+    local: Callable[[Sequence], List]            # cols -> list of constraint values
+    relations: Tuple[Tuple[int, Tuple[int, int]], ...]  # (mult_col, (value_col, id_col))
+
+    @property
+    def n_local(self):
+        one = [QM31(1)] * self.n_cols
+        return len(self.local(one))
+
+    @property
+    def n_constraints(self):
+        return self.n_local + len(self.relations)
+
+
+def _transition(not_last, pairs, nxt_idx, idx):
+    out = [not_last * (n - c) for n, c in pairs]
+    out.append(not_last * (nxt_idx - idx - 1))
+    return out
+
+
+def _add_local(c):
+    (node, lhs_id, rhs_id, idx, is_last, n_node, n_lhs, n_rhs, n_idx, lhs, rhs, out, _lm, _rm, _om) = c
+    cons = [is_last * (is_last - 1), out - (lhs + rhs)]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_lhs, lhs_id), (n_rhs, rhs_id)], n_idx, idx)
+    return cons
+
+
+def _mul_local(c):
+    (node, lhs_id, rhs_id, idx, is_last, n_node, n_lhs, n_rhs, n_idx, lhs, rhs, out, rem, _lm, _rm, _om) = c
+    cons = [is_last * (is_last - 1), lhs * rhs - (out * FP_SCALE + rem), rem * 0]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_lhs, lhs_id), (n_rhs, rhs_id)], n_idx, idx)
+    return cons
+
+
+def _recip_local(c):
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, inp, out, rem, scale, _im, _om) = c
+    cons = [is_last * (is_last - 1), scale * scale - (inp * out + rem)]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+    return cons
+
+
+def _inputs_local(c):
+    (node, idx, is_last, n_node, n_idx, _val, _mult) = c
+    not_last = 1 - is_last
+    return [is_last * (is_last - 1), not_last * (n_node - node), not_last * (n_idx - idx - 1)]
+
+
+def _pad(n, is_last_col):
+    p = [0] * n
+    p[is_last_col] = 1
+    return tuple(p)
+
+
+ADD = Component("add", KIND_ADD, 15, _pad(15, 4), _add_local,
+                ((12, (9, 1)), (13, (10, 2)), (14, (11, 0))))
+MUL = Component("mul", KIND_MUL, 16, _pad(16, 4), _mul_local,
+                ((13, (9, 1)), (14, (10, 2)), (15, (11, 0))))
+RECIP = Component("recip", KIND_RECIP, 13, _pad(13, 3), _recip_local,
+                  ((11, (7, 1)), (12, (8, 0))))
+INPUTS = Component("inputs", KIND_INPUTS, 7, _pad(7, 2), _inputs_local,
+                   ((6, (5, 0)),))
+
+COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS)}
+
+
+def pad_table(comp: Component, rows: np.ndarray) -> np.ndarray:
+    """AoS rows (n, n_cols) -> SoA columns (n_cols, 2^log_size), padded as `write_trace` does
+    (`add/witness.rs:43-46`: size = max(next_pow2(n_rows), N_LANES=16))."""
+    rows = np.asarray(rows, dtype=U64).reshape(-1, comp.n_cols)
+    n = rows.shape[0]
+    if n == 0:
+        raise ValueError("EmptyTrace")  # TraceError::EmptyTrace, add/witness.rs:39-41
+    size = max(1 << (n - 1).bit_length(), 16)
+    out = np.empty((size, comp.n_cols), dtype=U64)
+    out[:n] = rows
+    out[n:] = np.array(comp.padding, dtype=U64)
+    return np.ascontiguousarray(out.T)
