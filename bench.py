@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — proofs/sec of the MI355X prove hot path on BASELINE.json config 2
+(single Add-op AIR, 2^20 trace rows per proof), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one whole proof (AoS trace rows resident in HBM -> bincode proof bytes on the host).
+Proofs are independent, so ranks shard proofs with no data-path collective ("weak" scaling);
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks timing.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-rows", type=int, default=20, help="log2 rows of the Add trace (default 20 = BASELINE config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log", type=int, default=16)
+    return ap.parse_args(argv)
+
+
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def timed_region(step_fn, steps, warmup, barrier, device_sync):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides."""
+    for _ in range(warmup):
+        step_fn()
+    device_sync()
+    barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    device_sync()
+    barrier()
+    device_sync()
+    return time.perf_counter() - t0
+
+
+def aggregate(elapsed, world, steps_per_rank, reduce_max):
+    """value = units all ranks processed / max-over-ranks time."""
+    tmax = reduce_max(elapsed)
+    return {"seconds": tmax, "value": world * steps_per_rank / tmax, "ms_per_step": 1e3 * tmax / steps_per_rank}
+
+
+def cpu_baseline(sample_log, full_log):
+    """The oracle (numpy restatement of the reference algorithm) timed on this box's host cores on
+    a bounded sample of the same workload, scaled linearly in rows to the full size."""
+    import numpy as np
+    from luminair_amd import synthetic as syn
+    from oracle.prover import prove as oracle_prove
+    tabs = syn.config2_add_only(1 << sample_log, 42)
+    t0 = time.perf_counter()
+    oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs])
+    dt = time.perf_counter() - t0
+    scale = float(1 << (full_log - sample_log))
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "numpy oracle proof of a 2^%d-row Add trace took %.2f s; scaled x%d (linear in rows) to 2^%d rows"
+                      % (sample_log, dt, int(scale), full_log)}
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, local_rank, world = dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    import numpy as np
+    import torch
+    import luminair_amd
+    from luminair_amd import synthetic as syn
+
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = local_rank if torch.cuda.is_available() else 0
+
+    prover = luminair_amd.Prover(dev)
+    tabs = syn.config2_add_only(1 << args.log_rows, 42 + rank)   # each rank proves its own trace
+    ctx = prover.ctx
+    bufs = [(k, ctx.upload(r), len(r)) for k, r in tabs]          # trace rows resident in HBM
+    out = {}
+
+    def step():
+        out["proof"] = ctx.prove_tables(bufs)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def device_sync():
+        torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = timed_region(step, args.steps, args.warmup, barrier, device_sync)
+    agg = aggregate(elapsed, world, args.steps, reduce_max)
+
+    # roofline of the dominant kernel family, from HIP events recorded on the prover's own stream
+    # during the last timed step (lmn_timings)
+    tm = prover.timings()
+    fams = {
+        "k_fft_pass": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"]),
+        "k_merkle_layer": (tm["merkle_ms"], tm["merkle_bytes"], tm["merkle_launches"]),
+    }
+    dom = max(fams, key=lambda k: fams[k][0])
+    ms, nbytes, launches = fams[dom]
+    achieved = (nbytes / max(launches, 1)) / (1e-3 * ms / max(launches, 1)) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches_per_proof": launches, "avg_launch_ms": ms / max(launches, 1),
+                "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+
+    line = {
+        "metric": "proofs/sec, 2^%d-row Add trace" % args.log_rows, "value": agg["value"], "unit": "proofs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": agg["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31/QM31 field arithmetic)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 2a: single Add-op AIR, 2^%d trace rows per proof, PcsConfig default "
+                               "(pow 5, blowup 2x, 3 queries), KAT protocol variant" % args.log_rows,
+                   "rows": 1 << args.log_rows, "proofs_per_rank": args.steps, "parallelism": "proof-sharded x%d" % world,
+                   "proof_bytes": len(out["proof"])},
+        "prove_latency_ms": agg["ms_per_step"],
+        "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows)
+    if rank == 0:
+        print(json.dumps(line))
+    for _, b, _ in bufs:
+        b.free()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+"""ctypes binding of the C ABI in include/luminair_hip.h.
+
+The product library is `luminair_amd/csrc/libluminair_hip.so` (hipcc, gfx950).  There is no CPU
+fallback: loading fails loudly if the library was not built, and `Context()` fails with
+LMN_ERR_NO_DEVICE when no HIP device is present.  (`Library(path)` accepts an explicit path so
+the test-suite can load the test-only emulation build; the package itself never does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libluminair_hip.so")
+
+LMN_OK = 0
+ERR_EMPTY_TRACE, ERR_MAIN_TRACE, ERR_INTERACTION_TRACE, ERR_CONSTRAINTS = -1, -2, -3, -4
+ERR_SERIALIZATION, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_INTERNAL = -5, -6, -7, -8, -100
+VARIANT_KAT, VARIANT_PINNED = 0, 1
+TABLE_ROWS_ON_DEVICE = 1
+
+
+class LmnConfig(C.Structure):
+    _fields_ = [("pow_bits", C.c_uint32), ("log_blowup", C.c_uint32), ("log_last_layer", C.c_uint32),
+                ("n_queries", C.c_uint32), ("fp_scale", C.c_uint32), ("protocol_variant", C.c_uint32)]
+
+
+class LmnTable(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("n_rows", C.c_uint64), ("rows", C.c_void_p)]
+
+
+class LmnSettings(C.Structure):
+    _fields_ = [("has_lookups", C.c_uint32)]
+
+
+class LmnTimings(C.Structure):
+    _fields_ = [("total_ms", C.c_float)] + [(n, C.c_float) for n in (
+        "transpose_ms", "main_commit_ms", "logup_ms", "interaction_commit_ms", "composition_ms",
+        "composition_commit_ms", "oods_ms", "quotients_ms", "fri_ms", "decommit_ms", "fft_ms", "merkle_ms")] + [
+        ("fft_bytes", C.c_uint64), ("merkle_bytes", C.c_uint64), ("fft_launches", C.c_uint32),
+        ("merkle_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
+           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_upload", "lmn_device_free",
+           "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
+           "lmn_op_fft_selftest"]
+
+
+class LuminairBackendError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("%s (code %d)" % (message, code))
+        self.code = code
+
+
+class Library:
+    def __init__(self, path: Optional[str] = None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise LuminairBackendError(ERR_NO_DEVICE, "HIP backend library not built: %s (run __graft_entry__.build())"
+                                       % path)
+        self.path = path
+        lib = C.CDLL(path)
+        self.lib = lib
+        lib.lmn_strerror.restype = C.c_char_p
+        lib.lmn_strerror.argtypes = [C.c_int]
+        lib.lmn_last_error.restype = C.c_char_p
+        lib.lmn_last_error.argtypes = [C.c_void_p]
+        lib.lmn_default_config.argtypes = [C.POINTER(LmnConfig)]
+        lib.lmn_kind_columns.restype = C.c_uint32
+        lib.lmn_kind_columns.argtypes = [C.c_uint32]
+        lib.lmn_ctx_create.argtypes = [C.c_int, C.POINTER(LmnConfig), C.POINTER(C.c_void_p)]
+        lib.lmn_ctx_destroy.argtypes = [C.c_void_p]
+        lib.lmn_prove.argtypes = [C.c_void_p, C.POINTER(LmnTable), C.c_size_t, C.POINTER(LmnSettings),
+                                  C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        lib.lmn_free.argtypes = [C.c_void_p]
+        lib.lmn_get_timings.argtypes = [C.c_void_p, C.POINTER(LmnTimings)]
+        lib.lmn_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.lmn_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lmn_op_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.lmn_op_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.lmn_op_merkle_root.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32,
+                                           C.c_void_p]
+        lib.lmn_op_eval_at_point.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lmn_op_fft_selftest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+
+    def default_config(self) -> LmnConfig:
+        cfg = LmnConfig()
+        self.lib.lmn_default_config(C.byref(cfg))
+        return cfg
+
+    def kind_columns(self, kind: int) -> int:
+        return int(self.lib.lmn_kind_columns(kind))
+
+
+_default_library: Optional[Library] = None
+
+
+def default_library() -> Library:
+    global _default_library
+    if _default_library is None:
+        _default_library = Library()
+    return _default_library
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: "Context", ptr: int, nbytes: int):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.lib.lmn_device_free(self.ctx.handle, self.ptr)
+            self.ptr = 0
+
+
+class Context:
+    """One prover context per GPU (`lmn_ctx`)."""
+
+    def __init__(self, device: int = 0, config: Optional[LmnConfig] = None, library: Optional[Library] = None):
+        self.lib = library or default_library()
+        self.config = config or self.lib.default_config()
+        h = C.c_void_p()
+        rc = self.lib.lib.lmn_ctx_create(device, C.byref(self.config), C.byref(h))
+        if rc != LMN_OK:
+            msg = self.lib.lib.lmn_last_error(None).decode() or self.lib.lib.lmn_strerror(rc).decode()
+            raise LuminairBackendError(rc, msg)
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lib.lmn_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != LMN_OK:
+            msg = self.lib.lib.lmn_last_error(self.handle).decode() or self.lib.lib.lmn_strerror(rc).decode()
+            raise LuminairBackendError(rc, msg)
+
+    def upload(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_upload(self.handle, arr.ctypes.data, arr.nbytes, C.byref(out)))
+        return DeviceBuffer(self, out.value, arr.nbytes)
+
+    def prove_tables(self, tables: Sequence[Tuple[int, object, int]]) -> bytes:
+        """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer."""
+        n = len(tables)
+        arr = (LmnTable * max(n, 1))()
+        keep = []
+        for i, (kind, rows, n_rows) in enumerate(tables):
+            arr[i].kind = kind
+            arr[i].n_rows = n_rows
+            if isinstance(rows, DeviceBuffer):
+                arr[i].flags = TABLE_ROWS_ON_DEVICE
+                arr[i].rows = rows.ptr
+            else:
+                a = np.ascontiguousarray(rows, dtype=np.uint32)
+                keep.append(a)
+                arr[i].flags = 0
+                arr[i].rows = a.ctypes.data
+        settings = LmnSettings(0)
+        out = C.POINTER(C.c_uint8)()
+        out_len = C.c_size_t()
+        self._check(self.lib.lib.lmn_prove(self.handle, arr, n, C.byref(settings), C.byref(out), C.byref(out_len)))
+        data = C.string_at(out, out_len.value)
+        self.lib.lib.lmn_free(out)
+        return data
+
+    def timings(self) -> dict:
+        t = LmnTimings()
+        self._check(self.lib.lib.lmn_get_timings(self.handle, C.byref(t)))
+        return t.as_dict()
+
+    # ---- level-2 ops (host buffers)
+    def interpolate(self, cols: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(cols, dtype=np.uint32).copy()
+        ncols, n = a.shape
+        self._check(self.lib.lib.lmn_op_interpolate(self.handle, a.ctypes.data, ncols, n.bit_length() - 1))
+        return a
+
+    def evaluate(self, coeffs: np.ndarray, log_domain: int) -> np.ndarray:
+        a = np.ascontiguousarray(coeffs, dtype=np.uint32)
+        ncols, n = a.shape
+        out = np.empty((ncols, 1 << log_domain), dtype=np.uint32)
+        self._check(self.lib.lib.lmn_op_evaluate(self.handle, a.ctypes.data, ncols, n.bit_length() - 1, log_domain,
+                                                 out.ctypes.data))
+        return out
+
+    def merkle_root(self, cols: List[np.ndarray]) -> bytes:
+        arrs = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        logs = (C.c_uint32 * max(len(arrs), 1))(*[len(a).bit_length() - 1 for a in arrs])
+        root = (C.c_uint8 * 32)()
+        self._check(self.lib.lib.lmn_op_merkle_root(self.handle, ptrs, logs, len(arrs), root))
+        return bytes(root)
+
+    def eval_at_point(self, coeffs: np.ndarray, point_xy: Sequence[int]) -> Tuple[int, int, int, int]:
+        a = np.ascontiguousarray(coeffs, dtype=np.uint32)
+        pt = (C.c_uint32 * 8)(*[int(v) for v in point_xy])
+        out = (C.c_uint32 * 4)()
+        self._check(self.lib.lib.lmn_op_eval_at_point(self.handle, a.ctypes.data, len(a).bit_length() - 1, pt, out))
+        return tuple(int(v) for v in out)
+
+    def fft_selftest(self, log_size: int, ncols: int = 2):
+        self._check(self.lib.lib.lmn_op_fft_selftest(self.handle, log_size, ncols))

@@ -1,0 +1,91 @@
+// Blake2s-256 (RFC 7693, unkeyed) compression shared by host transcript code and gfx950 kernels.
+// Replaces the `blake2` 0.10.6 crate + stwo `core/vcs/blake2_hash.rs` used behind
+// /root/reference/crates/prover/src/prover.rs:44-46 (Blake2sChannel, Blake2sMerkleChannel).
+#pragma once
+#include "platform.h"
+
+namespace lmn {
+
+struct Hash32 {
+  uint32_t w[8];
+};
+
+LMN_HD uint32_t b2_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+#define LMN_B2_G(a, b, c, d, x, y) \
+  a = a + b + (x);                 \
+  d = b2_rotr(d ^ a, 16);          \
+  c = c + d;                       \
+  b = b2_rotr(b ^ c, 12);          \
+  a = a + b + (y);                 \
+  d = b2_rotr(d ^ a, 8);           \
+  c = c + d;                       \
+  b = b2_rotr(b ^ c, 7);
+
+#define LMN_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+  LMN_B2_G(v0, v4, v8, v12, m[s0], m[s1])                                                  \
+  LMN_B2_G(v1, v5, v9, v13, m[s2], m[s3])                                                  \
+  LMN_B2_G(v2, v6, v10, v14, m[s4], m[s5])                                                 \
+  LMN_B2_G(v3, v7, v11, v15, m[s6], m[s7])                                                 \
+  LMN_B2_G(v0, v5, v10, v15, m[s8], m[s9])                                                 \
+  LMN_B2_G(v1, v6, v11, v12, m[s10], m[s11])                                               \
+  LMN_B2_G(v2, v7, v8, v13, m[s12], m[s13])                                                \
+  LMN_B2_G(v3, v4, v9, v14, m[s14], m[s15])
+
+// h <- F(h, m, t, f0).  The sigma schedule is unrolled so message words stay in registers.
+LMN_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32_t f0) {
+  uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+  uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+  uint32_t v12 = 0x510E527Fu ^ t0, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu ^ f0, v15 = 0x5BE0CD19u;
+  LMN_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  LMN_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  h[0] ^= v0 ^ v8;
+  h[1] ^= v1 ^ v9;
+  h[2] ^= v2 ^ v10;
+  h[3] ^= v3 ^ v11;
+  h[4] ^= v4 ^ v12;
+  h[5] ^= v5 ^ v13;
+  h[6] ^= v6 ^ v14;
+  h[7] ^= v7 ^ v15;
+}
+
+LMN_HD void b2_init(uint32_t h[8]) {
+  h[0] = 0x6A09E667u ^ 0x01010020u;
+  h[1] = 0xBB67AE85u;
+  h[2] = 0x3C6EF372u;
+  h[3] = 0xA54FF53Au;
+  h[4] = 0x510E527Fu;
+  h[5] = 0x9B05688Cu;
+  h[6] = 0x1F83D9ABu;
+  h[7] = 0x5BE0CD19u;
+}
+
+// Hash a message given as `nwords` little-endian 32-bit words (host helper).
+inline Hash32 b2_hash_words(const uint32_t* words, size_t nwords) {
+  uint32_t h[8];
+  b2_init(h);
+  size_t nblocks = nwords == 0 ? 1 : (nwords + 15) / 16;
+  for (size_t b = 0; b < nblocks; ++b) {
+    uint32_t m[16];
+    for (int i = 0; i < 16; ++i) {
+      size_t k = 16 * b + i;
+      m[i] = k < nwords ? words[k] : 0u;
+    }
+    bool last = b + 1 == nblocks;
+    uint32_t t = last ? (uint32_t)(4 * nwords) : (uint32_t)(64 * (b + 1));
+    b2_compress(h, m, t, last ? 0xffffffffu : 0u);
+  }
+  Hash32 r;
+  for (int i = 0; i < 8; ++i) r.w[i] = h[i];
+  return r;
+}
+
+}  // namespace lmn

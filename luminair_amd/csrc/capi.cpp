@@ -1,0 +1,153 @@
+// extern "C" boundary (include/luminair_hip.h): the entry points a Rust `extern "C"` block would
+// bind in place of /root/reference/crates/prover/src/prover.rs:28-31.
+#include "../../include/luminair_hip.h"
+
+#include "prover.h"
+
+using lmn::Context;
+
+
+struct lmn_ctx {
+  Context* impl;
+  std::string last_error;
+};
+
+namespace {
+template <typename F>
+int guard(lmn_ctx* ctx, F&& f) {
+  try {
+    f();
+    return LMN_OK;
+  } catch (const LmnError& e) {
+    if (ctx) ctx->last_error = e.what();
+    int c = e.code;
+    return (c == -100 || (c <= -1 && c >= -8)) ? c : LMN_ERR_INTERNAL;
+  } catch (const std::bad_alloc&) {
+    if (ctx) ctx->last_error = "host allocation failed";
+    return LMN_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->last_error = e.what();
+    return LMN_ERR_INTERNAL;
+  }
+}
+thread_local std::string g_create_error;
+}  // namespace
+
+extern "C" {
+
+const char* lmn_strerror(int code) {
+  switch (code) {
+    case LMN_OK: return "ok";
+    case LMN_ERR_EMPTY_TRACE: return "TraceError(EmptyTrace)";
+    case LMN_ERR_MAIN_TRACE: return "MainTraceEvalGenError";
+    case LMN_ERR_INTERACTION_TRACE: return "InteractionTraceEvalGenError";
+    case LMN_ERR_CONSTRAINTS: return "ProverError(ConstraintsNotSatisfied)";
+    case LMN_ERR_SERIALIZATION: return "SerializationError";
+    case LMN_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case LMN_ERR_OUT_OF_MEMORY: return "out of memory";
+    case LMN_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+    default: return "internal error";
+  }
+}
+
+const char* lmn_last_error(const lmn_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+void lmn_default_config(lmn_config* cfg) {
+  if (!cfg) return;
+  cfg->pow_bits = 5;
+  cfg->log_blowup = 1;
+  cfg->log_last_layer = 0;
+  cfg->n_queries = 3;
+  cfg->fp_scale = 12;
+  cfg->protocol_variant = LMN_VARIANT_KAT;
+}
+
+uint32_t lmn_kind_columns(uint32_t kind) {
+  const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
+  return s ? (uint32_t)s->n_cols : 0u;
+}
+
+int lmn_ctx_create(int device, const lmn_config* cfg, lmn_ctx** out) {
+  if (!out) return LMN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  lmn_config c;
+  lmn_default_config(&c);
+  if (cfg) c = *cfg;
+  lmn_ctx* ctx = new lmn_ctx{nullptr, {}};
+  int rc = guard(ctx, [&] { ctx->impl = new Context(device, c); });
+  if (rc != LMN_OK) {
+    g_create_error = ctx->last_error;
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return LMN_OK;
+}
+
+void lmn_ctx_destroy(lmn_ctx* ctx) {
+  if (!ctx) return;
+  delete ctx->impl;
+  delete ctx;
+}
+
+int lmn_prove(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_settings* settings,
+              uint8_t** proof_bincode, size_t* proof_len) {
+  if (!ctx || !proof_bincode || !proof_len) return LMN_ERR_INVALID_ARGUMENT;
+  *proof_bincode = nullptr;
+  *proof_len = 0;
+  return guard(ctx, [&] {
+    std::vector<uint8_t> bytes = ctx->impl->prove(tables, n_tables, settings);
+    uint8_t* p = (uint8_t*)malloc(bytes.size());
+    if (!p) throw std::bad_alloc();
+    memcpy(p, bytes.data(), bytes.size());
+    *proof_bincode = p;
+    *proof_len = bytes.size();
+  });
+}
+
+void lmn_free(void* p) { free(p); }
+
+int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out) {
+  if (!ctx || !out) return LMN_ERR_INVALID_ARGUMENT;
+  *out = ctx->impl->timings;
+  return LMN_OK;
+}
+
+int lmn_upload(lmn_ctx* ctx, const void* host, size_t bytes, void** device_out) {
+  if (!ctx || !host || !device_out) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { *device_out = ctx->impl->upload(host, bytes); });
+}
+
+void lmn_device_free(lmn_ctx* ctx, void* p) {
+  if (ctx && p) ctx->impl->device_free(p);
+}
+
+int lmn_op_interpolate(lmn_ctx* ctx, uint32_t* cols, uint32_t ncols, uint32_t log_size) {
+  if (!ctx || !cols || ncols == 0 || log_size < 1) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_interpolate(cols, ncols, log_size); });
+}
+
+int lmn_op_evaluate(lmn_ctx* ctx, const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
+                    uint32_t* evals_out) {
+  if (!ctx || !coeffs || !evals_out || ncols == 0 || log_domain < 1) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_evaluate(coeffs, ncols, log_coeffs, log_domain, evals_out); });
+}
+
+int lmn_op_merkle_root(lmn_ctx* ctx, const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols,
+                       uint8_t root_out[32]) {
+  if (!ctx || !root_out || (ncols && (!cols || !log_sizes))) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_merkle_root(cols, log_sizes, ncols, root_out); });
+}
+
+int lmn_op_eval_at_point(lmn_ctx* ctx, const uint32_t* coeffs, uint32_t log_size, const uint32_t point_xy[8],
+                         uint32_t value_out[4]) {
+  if (!ctx || !coeffs || !point_xy || !value_out) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_eval_at_point(coeffs, log_size, point_xy, value_out); });
+}
+
+int lmn_op_fft_selftest(lmn_ctx* ctx, uint32_t log_size, uint32_t ncols) {
+  if (!ctx || log_size < 1 || ncols == 0) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_fft_selftest(log_size, ncols); });
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Launch wrappers for the gfx950 kernels of the prove hot path.
+// All pointers are device pointers; all launches are asynchronous on `s`.
+#pragma once
+#include "blake2s.h"
+#include "field.h"
+
+namespace lmn {
+
+constexpr int MAX_LOG = 30;
+
+// Per-layer twiddle pointers of one canonic circle domain (layer 0 = circle/y layer).
+struct TwPtrs {
+  const uint32_t* l[MAX_LOG];
+};
+
+// ---- a3: AoS rows -> padded SoA columns (write_trace / pack_values)
+void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
+                          int is_last_col, lmn_stream_t s);
+
+// ---- a4: circle FFT passes.  data = ncols columns of 2^log_n words at stride col_stride.
+// dst may equal src (in place).  launch_fft zero-extends src (2^log_src words) to 2^log_n (LDE).
+// Both return the number of pass kernels launched.
+int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int ncols, int log_n,
+                const TwPtrs& itw, lmn_stream_t s);
+int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
+               int log_n, const TwPtrs& tw, lmn_stream_t s);
+// single-layer reference kernels (debug / self-test only)
+void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
+                       lmn_stream_t s);
+// dst (2^log_dst per column) <- src coefficients (2^log_src per column) zero-extended
+void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32_t* dst, uint64_t dst_stride,
+                   int log_dst, int ncols, lmn_stream_t s);
+
+// ---- a4: Blake2s Merkle layer.  out[i] = H(prev[2i] || prev[2i+1] || cols[0][i] .. cols[ncols-1][i])
+void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
+                         lmn_stream_t s);
+
+// ---- gather: out[dst_off[e] + k] = arena[src_off[e] + k], k < len[e]
+struct GatherEntry {
+  uint64_t src_off;  // word offset into arena
+  uint32_t len;      // words
+  uint32_t dst_off;  // word offset into out
+};
+void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, uint32_t* out,
+                   lmn_stream_t s);
+
+// ---- a6: logup
+struct LogupArgs {
+  int k;                       // number of relations (1..3)
+  const uint32_t* val[3];      // value column
+  const uint32_t* id[3];       // tensor-id column
+  const uint32_t* mult[3];     // multiplicity column
+  QM31 z, alpha;
+  uint32_t* inter;             // interaction eval columns (4k columns, stride n)
+  QM31* last_tmp;              // S_{k-1} per row (AoS), n entries
+  uint32_t* partials;          // per-block partial sums, 4 words each
+  uint32_t n;                  // rows
+};
+int logup_num_blocks(uint32_t n);
+void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s);
+// claimed_out[0] = sum of partials; claimed_out[1] = shift = claimed * n_inv
+void launch_logup_reduce(const uint32_t* partials, int nblocks, uint32_t n_inv, QM31* claimed_out, lmn_stream_t s);
+// prefix sum of (last_tmp - shift) in coset order, written to the last 4 interaction columns
+void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_size, uint32_t* out_cols /*4 x n*/,
+                       QM31* blocksums, lmn_stream_t s);
+int logup_scan_num_blocks(int log_size);
+
+// ---- a7: constraint quotients on the eval domain (log_size + 1)
+struct CompositionArgs {
+  int kind;                    // TraceTable kind (0 add, 1 mul, 2 recip, 15 inputs)
+  int log_size;                // trace log size
+  int eval_log;                // eval domain log size
+  const uint32_t* main;        // main columns on the eval domain, stride 2^eval_log
+  const uint32_t* inter;       // interaction columns on the eval domain
+  uint32_t* out;               // 4 coordinate columns, stride 2^eval_log
+  int accumulate;              // out += instead of out =
+  int zero_slot;               // 1: Mul's second eval_fixed_mul slot contributes zero (KAT form)
+  QM31 z, alpha;
+  const QM31* claimed_shift;   // device: [claimed, shift]
+  QM31 coeff[16];              // alpha^(N-1-k) for this component's constraints, in order
+  uint32_t zinv[2];            // 1/Z for rows with (s >> log_size) == 0 / 1
+};
+void launch_composition(const CompositionArgs& a, lmn_stream_t s);
+// out (4 x n) += in (4 x n)
+void launch_secure_add(uint32_t* out, const uint32_t* in, uint64_t n_words, lmn_stream_t s);
+
+// ---- a9: OODS evaluation of coefficient columns
+struct EvalJob {
+  const uint32_t* coeffs;
+  int log_n;
+  int point;                   // which point table (0 = oods, 1.. = shifted points)
+};
+constexpr int EVAL_LB = 10;
+// tables: for point p: lo table at lo_tab + p*2^EVAL_LB, hi table at hi_tab + p*hi_stride
+void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, const QM31* hi_tab, uint32_t hi_stride,
+                          int max_log, QM31* partial_out /* njobs x max_chunks */, int max_chunks, lmn_stream_t s);
+int eval_num_chunks(int log_n);
+
+// ---- a9: FRI quotients
+constexpr int QUOT_MAX_BATCH = 4;
+struct QuotientArgs {
+  int log_size;
+  const uint32_t* const* cols; // device array of column pointers (all of size 2^log_size)
+  int nbatch;
+  int batch_start[QUOT_MAX_BATCH + 1];  // range into col_idx / coeff_c
+  const int* col_idx;          // device
+  const QM31* coeff_c;         // device: alpha^k * c per (batch, column)
+  QM31 A[QUOT_MAX_BATCH], B[QUOT_MAX_BATCH], batch_coeff[QUOT_MAX_BATCH];
+  CM31 prx[QUOT_MAX_BATCH], pry[QUOT_MAX_BATCH], pix[QUOT_MAX_BATCH], piy[QUOT_MAX_BATCH];
+  const uint32_t* tw_y;        // layer-0 twiddles of the domain (y at storage 2h)
+  const uint32_t* tw_x;        // layer-1 twiddles (x at storage 4h)
+  uint32_t* out;               // 4 coordinate columns
+};
+void launch_quotients(const QuotientArgs& a, lmn_stream_t s);
+
+// ---- a9: FRI folds.  Secure columns are 4 coordinate arrays at stride = length.
+void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
+                                  QM31 alpha, int accumulate, lmn_stream_t s);
+void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, QM31 alpha,
+                      lmn_stream_t s);
+
+}  // namespace lmn

@@ -1,0 +1,727 @@
+// gfx950 kernels for the LuminAIR prove hot path.  One wavefront = 64 lanes; all global accesses
+// are laid out so consecutive lanes touch consecutive 4-byte words of a column (column-major
+// trace data).  See DESIGN.md for the per-kernel roofline notes.
+#include "kernels.h"
+
+namespace lmn {
+
+constexpr int TPB = 256;
+
+static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// =============================================================================================
+// a3  AoS -> SoA transpose with padding rows (is_last_idx = 1, everything else 0)
+// =============================================================================================
+constexpr int TR_ROWS = 64;
+LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
+                           uint32_t* __restrict__ cols, int is_last_col) {
+  LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
+  const int stride = ncols + 1;
+  const uint64_t row0 = (uint64_t)blockIdx.x * TR_ROWS;
+  const int total = TR_ROWS * ncols;
+  for (int k = threadIdx.x; k < total; k += blockDim.x) {
+    int r = k / ncols, c = k - r * ncols;
+    uint64_t gr = row0 + r;
+    uint32_t v;
+    if (gr < n_rows)
+      v = rows[gr * (uint64_t)ncols + c];
+    else
+      v = (c == is_last_col) ? 1u : 0u;
+    tile[r * stride + c] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < total; k += blockDim.x) {
+    int c = k / TR_ROWS, r = k - c * TR_ROWS;
+    if (row0 + r < size) cols[(uint64_t)c * size + row0 + r] = tile[r * stride + c];
+  }
+}
+
+void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
+                          int is_last_col, lmn_stream_t s) {
+  uint64_t size = 1ull << log_size;
+  unsigned grid = cdiv(size, TR_ROWS);
+  size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
+  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, is_last_col);
+}
+
+// =============================================================================================
+// a4  Circle FFT.  Layer i pairs indices differing in bit i; twiddle index = idx >> (i+1).
+//     A pass runs layers [lo, hi) on LDS tiles of 2^(hi-lo) rows x 2^cb contiguous words.
+// =============================================================================================
+// src may differ from data (out-of-place first pass); words at index >= src_len read as zero
+// (zero-extension of a coefficient vector onto a larger domain, i.e. the LDE).
+template <bool INV>
+LMN_KERNEL k_fft_pass(uint32_t* data, uint64_t col_stride, const uint32_t* src,
+                      uint64_t src_stride, uint64_t src_len, int lo, int hi, int cb, TwPtrs tw, uint32_t scale) {
+  LMN_DYN_SMEM(uint32_t, sm);
+  const int rbits = hi - lo;
+  const int C = 1 << cb;
+  const int tile_elems = 1 << (rbits + cb);
+  uint32_t* col = data + (uint64_t)blockIdx.y * col_stride;
+  const uint32_t* scol = src + (uint64_t)blockIdx.y * src_stride;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t q = tile & ((1u << (lo - cb)) - 1u);
+  const uint32_t H = tile >> (lo - cb);
+  const uint64_t base = ((uint64_t)H << hi) + ((uint64_t)q << cb);
+  for (int e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+    int m = e >> cb, c = e & (C - 1);
+    uint64_t gi = base + ((uint64_t)m << lo) + c;
+    sm[e] = gi < src_len ? scol[gi] : 0u;
+  }
+  __syncthreads();
+  for (int step = 0; step < rbits; ++step) {
+    const int i = INV ? lo + step : hi - 1 - step;
+    const int bit = i - lo;
+    const uint32_t* __restrict__ t = tw.l[i];
+    const uint32_t hbase = H << (hi - i - 1);
+    for (int b = threadIdx.x; b < tile_elems / 2; b += blockDim.x) {
+      int c = b & (C - 1);
+      int p = b >> cb;
+      int m0 = ((p >> bit) << (bit + 1)) | (p & ((1 << bit) - 1));
+      int m1 = m0 | (1 << bit);
+      uint32_t w = t[hbase + (uint32_t)(m0 >> (bit + 1))];
+      int i0 = (m0 << cb) | c, i1 = (m1 << cb) | c;
+      uint32_t v0 = sm[i0], v1 = sm[i1];
+      if (INV) {
+        sm[i0] = m_add(v0, v1);
+        sm[i1] = m_mul(m_sub(v0, v1), w);
+      } else {
+        uint32_t x = m_mul(v1, w);
+        sm[i0] = m_add(v0, x);
+        sm[i1] = m_sub(v0, x);
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+    int m = e >> cb, c = e & (C - 1);
+    uint32_t v = sm[e];
+    if (INV && scale != 1u) v = m_mul(v, scale);
+    col[base + ((uint64_t)m << lo) + c] = v;
+  }
+}
+
+struct FftPass {
+  int lo, hi, cb;
+};
+constexpr int FFT_LOW_BITS = 12;    // contiguous low pass: 2^12 words = 16 KiB LDS
+constexpr int FFT_HIGH_BITS = 10;   // strided high passes: 2^10 rows x 16 words = 64 KiB LDS
+constexpr int FFT_HIGH_CB = 4;
+
+static int plan_passes(int log_n, FftPass* out) {
+  int n = 0;
+  int lo = 0;
+  int hi = log_n < FFT_LOW_BITS ? log_n : FFT_LOW_BITS;
+  out[n++] = {0, hi, 0};
+  lo = hi;
+  while (lo < log_n) {
+    int rem = log_n - lo;
+    int npass = (rem + FFT_HIGH_BITS - 1) / FFT_HIGH_BITS;
+    int take = (rem + npass - 1) / npass;
+    out[n++] = {lo, lo + take, FFT_HIGH_CB};
+    lo += take;
+  }
+  return n;
+}
+
+static uint32_t inv_pow2(int log_n) {
+  // 2^-log_n mod P = 2^(31 - log_n mod 31)
+  int e = (31 - (log_n % 31)) % 31;
+  return 1u << e;
+}
+
+template <bool INV>
+static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int log_src,
+                    int ncols, int log_n, const TwPtrs& tw, lmn_stream_t s) {
+  if (log_n < 1) throw LmnError(-100, "fft: log_n < 1");
+  FftPass passes[8];
+  int np = plan_passes(log_n, passes);
+  for (int k = 0; k < np; ++k) {
+    const FftPass& p = INV ? passes[k] : passes[np - 1 - k];
+    int rbits = p.hi - p.lo;
+    unsigned tiles = 1u << (log_n - rbits - p.cb);
+    size_t smem = (size_t)4 << (rbits + p.cb);
+    bool last = INV && k == np - 1;
+    uint32_t scale = last ? inv_pow2(log_n) : 1u;
+    const uint32_t* psrc = k == 0 ? src : data;
+    uint64_t pstride = k == 0 ? src_stride : col_stride;
+    uint64_t plen = k == 0 ? (1ull << log_src) : (1ull << log_n);
+    LMN_LAUNCH(k_fft_pass<INV>, dim3(tiles, ncols), dim3(TPB), smem, s, data, col_stride, psrc, pstride, plen, p.lo,
+               p.hi, p.cb, tw, scale);
+  }
+  return np;
+}
+
+int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int ncols, int log_n,
+                const TwPtrs& itw, lmn_stream_t s) {
+  return run_fft<true>(dst, dst_stride, src, src_stride, log_n, ncols, log_n, itw, s);
+}
+int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
+               int log_n, const TwPtrs& tw, lmn_stream_t s) {
+  return run_fft<false>(dst, dst_stride, src, src_stride, log_src, ncols, log_n, tw, s);
+}
+
+// one global-memory layer per launch: the obviously-correct reference used by the self-test
+LMN_KERNEL k_fft_layer_simple(uint32_t* __restrict__ data, uint64_t col_stride, int log_n, int i,
+                              const uint32_t* __restrict__ t, int inverse, uint32_t scale) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t half = 1ull << (log_n - 1);
+  if (b >= half) return;
+  uint32_t* col = data + (uint64_t)blockIdx.y * col_stride;
+  uint64_t h = b >> i, l = b & ((1ull << i) - 1);
+  uint64_t i0 = (h << (i + 1)) + l, i1 = i0 + (1ull << i);
+  uint32_t w = t[h];
+  uint32_t v0 = col[i0], v1 = col[i1];
+  if (inverse) {
+    uint32_t a = m_add(v0, v1), d = m_mul(m_sub(v0, v1), w);
+    if (scale != 1u) {
+      a = m_mul(a, scale);
+      d = m_mul(d, scale);
+    }
+    col[i0] = a;
+    col[i1] = d;
+  } else {
+    uint32_t x = m_mul(v1, w);
+    col[i0] = m_add(v0, x);
+    col[i1] = m_sub(v0, x);
+  }
+}
+
+void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
+                       lmn_stream_t s) {
+  uint64_t half = 1ull << (log_n - 1);
+  for (int k = 0; k < log_n; ++k) {
+    int i = inverse ? k : log_n - 1 - k;
+    uint32_t scale = (inverse && k == log_n - 1) ? inv_pow2(log_n) : 1u;
+    LMN_LAUNCH(k_fft_layer_simple, dim3(cdiv(half, TPB), ncols), dim3(TPB), 0, s, data, col_stride, log_n, i,
+               tw.l[i], inverse ? 1 : 0, scale);
+  }
+}
+
+LMN_KERNEL k_extend(const uint32_t* __restrict__ src, uint64_t src_stride, uint64_t src_len,
+                    uint32_t* __restrict__ dst, uint64_t dst_stride, uint64_t dst_len) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dst_len) return;
+  uint32_t v = i < src_len ? src[(uint64_t)blockIdx.y * src_stride + i] : 0u;
+  dst[(uint64_t)blockIdx.y * dst_stride + i] = v;
+}
+
+void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32_t* dst, uint64_t dst_stride,
+                   int log_dst, int ncols, lmn_stream_t s) {
+  uint64_t dl = 1ull << log_dst;
+  LMN_LAUNCH(k_extend, dim3(cdiv(dl, TPB), ncols), dim3(TPB), 0, s, src, src_stride, 1ull << log_src, dst,
+             dst_stride, dl);
+}
+
+// =============================================================================================
+// a4  Blake2s Merkle layer: one lane per node; a wave reads 64 consecutive rows of each column.
+// =============================================================================================
+LMN_KERNEL k_merkle_layer(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int ncols,
+                          uint32_t size, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size) return;
+  const int npre = prev ? 16 : 0;
+  const int nwords = npre + ncols;
+  const int nblocks = (nwords + 15) / 16;
+  uint32_t h[8];
+  b2_init(h);
+  for (int b = 0; b < nblocks; ++b) {
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int w = b * 16 + k;
+      uint32_t v = 0u;
+      if (w < npre)
+        v = prev[(uint64_t)i * 16 + w];
+      else if (w < nwords)
+        v = cols[w - npre][i];
+      m[k] = v;
+    }
+    bool last = b + 1 == nblocks;
+    b2_compress(h, m, last ? (uint32_t)(4 * nwords) : (uint32_t)(64 * (b + 1)), last ? 0xffffffffu : 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[(uint64_t)i * 8 + k] = h[k];
+}
+
+void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
+                         lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle layer with no input");
+  LMN_LAUNCH(k_merkle_layer, dim3(cdiv(size, TPB)), dim3(TPB), 0, s, prev, cols, ncols, size, out);
+}
+
+// =============================================================================================
+// gather
+// =============================================================================================
+LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,
+                    uint32_t* __restrict__ out) {
+  uint32_t e = blockIdx.x;
+  if (e >= n) return;
+  GatherEntry g = entries[e];
+  for (uint32_t k = threadIdx.x; k < g.len; k += blockDim.x) out[g.dst_off + k] = arena[g.src_off + k];
+}
+
+void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, uint32_t* out,
+                   lmn_stream_t s) {
+  if (n_entries == 0) return;
+  LMN_LAUNCH(k_gather, dim3(n_entries), dim3(64), 0, s, arena, entries, n_entries, out);
+}
+
+// =============================================================================================
+// a6  LogUp: S_j[r] = S_{j-1}[r] + mult_j[r] / (val_j[r] + alpha*id_j[r] - z)
+// =============================================================================================
+int logup_num_blocks(uint32_t n) { return (int)cdiv(n, TPB); }
+
+LMN_KERNEL k_logup_fracs(LogupArgs a) {
+  LMN_SHARED uint64_t red[TPB * 4];
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  QM31 S = q_zero();
+  if (r < a.n) {
+    QM31 den[3], pre[3];
+    for (int j = 0; j < a.k; ++j) {
+      QM31 d = q_sub(q_add_m(q_mul_m(a.alpha, a.id[j][r]), a.val[j][r]), a.z);
+      den[j] = d;
+      pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
+    }
+    QM31 inv = q_inv(pre[a.k - 1]);
+    QM31 invs[3];
+    for (int j = a.k - 1; j >= 0; --j) {
+      invs[j] = j == 0 ? inv : q_mul(inv, pre[j - 1]);
+      inv = q_mul(inv, den[j]);
+    }
+    for (int j = 0; j < a.k; ++j) {
+      S = q_add(S, q_mul_m(invs[j], a.mult[j][r]));
+      if (j < a.k - 1) {
+        uint32_t* o = a.inter + (uint64_t)(4 * j) * a.n + r;
+        o[0] = S.a;
+        o[(uint64_t)a.n] = S.b;
+        o[(uint64_t)2 * a.n] = S.c;
+        o[(uint64_t)3 * a.n] = S.d;
+      }
+    }
+    a.last_tmp[r] = S;
+  }
+  red[threadIdx.x * 4 + 0] = S.a;
+  red[threadIdx.x * 4 + 1] = S.b;
+  red[threadIdx.x * 4 + 2] = S.c;
+  red[threadIdx.x * 4 + 3] = S.d;
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] += red[(threadIdx.x + st) * 4 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) a.partials[blockIdx.x * 4 + threadIdx.x] = m_red64(red[threadIdx.x]);
+}
+
+void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s) {
+  LMN_LAUNCH(k_logup_fracs, dim3(logup_num_blocks(a.n)), dim3(TPB), 0, s, a);
+}
+
+LMN_KERNEL k_logup_reduce(const uint32_t* __restrict__ partials, int nblocks, uint32_t n_inv, QM31* out) {
+  LMN_SHARED uint64_t red[TPB * 4];
+  uint64_t acc[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+    for (int k = 0; k < 4; ++k) acc[k] += partials[b * 4 + k];
+  for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = m_red64(acc[k]);
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] += red[(threadIdx.x + st) * 4 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    QM31 c{m_red64(red[0]), m_red64(red[1]), m_red64(red[2]), m_red64(red[3])};
+    out[0] = c;
+    out[1] = q_mul_m(c, n_inv);
+  }
+}
+
+void launch_logup_reduce(const uint32_t* partials, int nblocks, uint32_t n_inv, QM31* claimed_out, lmn_stream_t s) {
+  LMN_LAUNCH(k_logup_reduce, dim3(1), dim3(TPB), 0, s, partials, nblocks, n_inv, claimed_out);
+}
+
+// coset-order position -> storage index (bit-reversed circle-domain order), SURVEY Appendix A.2
+LMN_D uint32_t coset_pos_to_storage(uint32_t i, int log_size) {
+  uint32_t n = 1u << log_size;
+  uint32_t cd = (i & 1u) ? n - ((i + 1u) >> 1) : (i >> 1);
+  return log_size == 0 ? 0u : (__brev(cd) >> (32 - log_size));
+}
+
+constexpr int SCAN_PER_THREAD = 4;
+constexpr int SCAN_PER_BLOCK = TPB * SCAN_PER_THREAD;
+int logup_scan_num_blocks(int log_size) { return (int)cdiv(1ull << log_size, SCAN_PER_BLOCK); }
+
+// block-local inclusive scan of thread sums in LDS (Hillis-Steele over TPB QM31 values)
+LMN_D QM31 block_scan_inclusive(QM31 v, QM31* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < TPB; off <<= 1) {
+    QM31 add = q_zero();
+    if ((int)threadIdx.x >= off) add = sh[threadIdx.x - off];
+    __syncthreads();
+    sh[threadIdx.x] = q_add(sh[threadIdx.x], add);
+    __syncthreads();
+  }
+  return sh[threadIdx.x];
+}
+
+// mode 0: write block totals; mode 1: write scanned values (+ exclusive block offsets)
+LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restrict__ claimed_shift, int log_size,
+                        uint32_t* __restrict__ out_cols, QM31* blocksums, int mode) {
+  LMN_SHARED QM31 sh[TPB];
+  const uint32_t n = 1u << log_size;
+  const QM31 shift = claimed_shift[1];
+  uint32_t i0 = (blockIdx.x * TPB + threadIdx.x) * SCAN_PER_THREAD;
+  QM31 v[SCAN_PER_THREAD];
+  uint32_t st[SCAN_PER_THREAD];
+  QM31 run = q_zero();
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    uint32_t i = i0 + k;
+    if (i < n) {
+      st[k] = coset_pos_to_storage(i, log_size);
+      run = q_add(run, q_sub(last_tmp[st[k]], shift));
+    } else {
+      st[k] = 0xffffffffu;
+    }
+    v[k] = run;
+  }
+  QM31 incl = block_scan_inclusive(run, sh);
+  if (mode == 0) {
+    if (threadIdx.x == TPB - 1) blocksums[blockIdx.x] = incl;
+    return;
+  }
+  QM31 offset = q_sub(incl, run);  // exclusive prefix of this thread within the block
+  if (blockIdx.x > 0) offset = q_add(offset, blocksums[blockIdx.x - 1]);
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (st[k] == 0xffffffffu) continue;
+    QM31 t = q_add(v[k], offset);
+    uint32_t* o = out_cols + st[k];
+    o[0] = t.a;
+    o[(uint64_t)n] = t.b;
+    o[(uint64_t)2 * n] = t.c;
+    o[(uint64_t)3 * n] = t.d;
+  }
+}
+
+// inclusive scan of the block totals in place (single block)
+LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
+  LMN_SHARED QM31 sh[TPB];
+  int per = (nblocks + TPB - 1) / TPB;
+  int b0 = threadIdx.x * per;
+  QM31 run = q_zero();
+  for (int k = 0; k < per; ++k) {
+    int b = b0 + k;
+    if (b < nblocks) {
+      run = q_add(run, blocksums[b]);
+      blocksums[b] = run;
+    }
+  }
+  QM31 incl = block_scan_inclusive(run, sh);
+  QM31 offset = q_sub(incl, run);
+  for (int k = 0; k < per; ++k) {
+    int b = b0 + k;
+    if (b < nblocks) blocksums[b] = q_add(blocksums[b], offset);
+  }
+}
+
+void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_size, uint32_t* out_cols,
+                       QM31* blocksums, lmn_stream_t s) {
+  int nb = logup_scan_num_blocks(log_size);
+  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 0);
+  LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(TPB), 0, s, blocksums, nb);
+  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 1);
+}
+
+// =============================================================================================
+// a7  Constraint quotients (composition polynomial) on the eval domain
+// =============================================================================================
+// storage index of the point p_s - 2^(eval_log - log_size) coset steps (mask offset -1)
+LMN_D uint32_t prev_row_storage(uint32_t s, int eval_log, int log_size) {
+  const int hb = eval_log - 1;
+  const uint32_t low = s & 1u;
+  uint32_t t = s >> 1;
+  if (hb == 0) return s;
+  const uint32_t mask = (1u << hb) - 1u;
+  const uint32_t d = 1u << (eval_log - log_size - 1);
+  uint32_t j = __brev(t) >> (32 - hb);
+  j = (low ? j + d : j - d) & mask;
+  t = __brev(j) >> (32 - hb);
+  return (t << 1) | low;
+}
+
+struct ConsAcc {
+  QM31 acc;
+  const QM31* coeff;
+  int k;
+  LMN_HD void add_m(uint32_t c) {
+    acc = q_add(acc, q_mul_m(coeff[k], c));
+    ++k;
+  }
+  LMN_HD void add_q(QM31 c) {
+    acc = q_add(acc, q_mul(coeff[k], c));
+    ++k;
+  }
+};
+
+template <int NCOLS>
+LMN_D void load_row(const uint32_t* __restrict__ base, uint64_t stride, uint32_t s, uint32_t* c) {
+#pragma unroll
+  for (int k = 0; k < NCOLS; ++k) c[k] = base[(uint64_t)k * stride + s];
+}
+
+LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint32_t s) {
+  return QM31{base[s], base[stride + s], base[2 * stride + s], base[3 * stride + s]};
+}
+
+// logup constraints for NREL relations; rel_mult/rel_val/rel_id index into the row array
+template <int NREL>
+LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t* c, const int* rel_mult,
+                             const int* rel_val, const int* rel_id, uint32_t s, uint64_t E) {
+  QM31 prev = q_zero();
+#pragma unroll
+  for (int j = 0; j < NREL; ++j) {
+    QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * E, E, s);
+    QM31 den = q_sub(q_add_m(q_mul_m(a.alpha, c[rel_id[j]]), c[rel_val[j]]), a.z);
+    QM31 diff;
+    if (j < NREL - 1) {
+      diff = q_sub(cur, prev);
+    } else {
+      uint32_t ps = prev_row_storage(s, a.eval_log, a.log_size);
+      QM31 pr = load_secure(a.inter + (uint64_t)(4 * j) * E, E, ps);
+      diff = q_add(q_sub(q_sub(cur, pr), prev), a.claimed_shift[1]);
+    }
+    ca.add_q(q_sub_m(q_mul(diff, den), c[rel_mult[j]]));
+    prev = cur;
+  }
+}
+
+LMN_KERNEL k_composition(CompositionArgs a) {
+  const uint64_t E = 1ull << a.eval_log;
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= E) return;
+  ConsAcc ca{q_zero(), a.coeff, 0};
+  if (a.kind == 0 || a.kind == 1) {
+    // Add (15 cols) / Mul (16 cols: rem inserted at 12)
+    const bool mul = a.kind == 1;
+    uint32_t c[16];
+    if (mul)
+      load_row<16>(a.main, E, s, c);
+    else
+      load_row<15>(a.main, E, s, c);
+    const uint32_t node = c[0], lhs_id = c[1], rhs_id = c[2], idx = c[3], is_last = c[4];
+    const uint32_t lhs = c[9], rhs = c[10], out = c[11];
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    if (mul) {
+      const uint32_t rem = c[12];
+      ca.add_m(m_sub(m_mul(lhs, rhs), m_add(m_mul(out, 4096u), rem)));
+      ca.add_m(0u);  // second eval_fixed_mul slot: zero on rem == 0 (KAT-pinned form)
+    } else {
+      ca.add_m(m_sub(out, m_add(lhs, rhs)));
+    }
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(c[5], node)));
+    ca.add_m(m_mul(not_last, m_sub(c[6], lhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(c[7], rhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(c[8], idx), 1u)));
+    const int mo = mul ? 13 : 12;
+    const int rel_mult[3] = {mo, mo + 1, mo + 2};
+    const int rel_val[3] = {9, 10, 11};
+    const int rel_id[3] = {1, 2, 0};
+    logup_constraints<3>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
+  } else if (a.kind == 2) {
+    uint32_t c[13];
+    load_row<13>(a.main, E, s, c);
+    const uint32_t is_last = c[3];
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    ca.add_m(m_sub(m_sqr(c[10]), m_add(m_mul(c[7], c[8]), c[9])));
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(c[4], c[0])));
+    ca.add_m(m_mul(not_last, m_sub(c[5], c[1])));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(c[6], c[2]), 1u)));
+    const int rel_mult[2] = {11, 12};
+    const int rel_val[2] = {7, 8};
+    const int rel_id[2] = {1, 0};
+    logup_constraints<2>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
+  } else {
+    uint32_t c[7];
+    load_row<7>(a.main, E, s, c);
+    const uint32_t is_last = c[2];
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(c[3], c[0])));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(c[4], c[1]), 1u)));
+    const int rel_mult[1] = {6};
+    const int rel_val[1] = {5};
+    const int rel_id[1] = {0};
+    logup_constraints<1>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
+  }
+  QM31 r = q_mul_m(ca.acc, a.zinv[(s >> a.log_size) & 1u]);
+  uint32_t* o = a.out + s;
+  if (a.accumulate) {
+    r.a = m_add(r.a, o[0]);
+    r.b = m_add(r.b, o[E]);
+    r.c = m_add(r.c, o[2 * E]);
+    r.d = m_add(r.d, o[3 * E]);
+  }
+  o[0] = r.a;
+  o[E] = r.b;
+  o[2 * E] = r.c;
+  o[3 * E] = r.d;
+}
+
+void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
+  if (a.eval_log != a.log_size + 1) throw LmnError(-100, "composition: eval domain must be log_size+1");
+  LMN_LAUNCH(k_composition, dim3(cdiv(1ull << a.eval_log, TPB)), dim3(TPB), 0, s, a);
+}
+
+LMN_KERNEL k_secure_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = m_add(out[i], in[i]);
+}
+void launch_secure_add(uint32_t* out, const uint32_t* in, uint64_t n_words, lmn_stream_t s) {
+  LMN_LAUNCH(k_secure_add, dim3(cdiv(n_words, TPB)), dim3(TPB), 0, s, out, in, n_words);
+}
+
+// =============================================================================================
+// a9  eval_at_point: sum_j coeff_j * basis_j(point), basis factored as lo-table x hi-table
+// =============================================================================================
+constexpr int EVAL_HI_PER_CHUNK = 8;
+LMN_HD int eval_num_chunks_hd(int log_n) {
+  if (log_n <= EVAL_LB) return 1;
+  int total_hi = 1 << (log_n - EVAL_LB);
+  int hpc = total_hi < EVAL_HI_PER_CHUNK ? total_hi : EVAL_HI_PER_CHUNK;
+  return total_hi / hpc;
+}
+int eval_num_chunks(int log_n) { return eval_num_chunks_hd(log_n); }
+
+LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restrict__ lo_tab,
+                           const QM31* __restrict__ hi_tab, uint32_t hi_stride, QM31* __restrict__ partial_out,
+                           int max_chunks) {
+  LMN_SHARED QM31 red[TPB];
+  const EvalJob job = jobs[blockIdx.y];
+  const int chunk = blockIdx.x;
+  const int nchunks = eval_num_chunks_hd(job.log_n);
+  if (chunk >= nchunks) return;
+  const int lb = job.log_n < EVAL_LB ? job.log_n : EVAL_LB;
+  const uint32_t lo_n = 1u << lb;
+  const uint32_t total_hi = 1u << (job.log_n - lb);
+  const uint32_t hpc = total_hi / (uint32_t)nchunks;
+  const QM31* L = lo_tab + ((uint64_t)job.point << EVAL_LB);
+  const QM31* Hh = hi_tab + (uint64_t)job.point * hi_stride;
+  QM31 acc = q_zero();
+  for (uint32_t hh = 0; hh < hpc; ++hh) {
+    uint32_t hi = chunk * hpc + hh;
+    QM31 inner = q_zero();
+    for (uint32_t lo = threadIdx.x; lo < lo_n; lo += blockDim.x)
+      inner = q_add(inner, q_mul_m(L[lo], job.coeffs[((uint64_t)hi << lb) + lo]));
+    acc = q_add(acc, q_mul(Hh[hi], inner));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = q_add(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial_out[(uint64_t)blockIdx.y * max_chunks + chunk] = red[0];
+}
+
+void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, const QM31* hi_tab, uint32_t hi_stride,
+                          int max_log, QM31* partial_out, int max_chunks, lmn_stream_t s) {
+  (void)max_log;
+  LMN_LAUNCH(k_eval_at_point, dim3(max_chunks, njobs), dim3(TPB), 0, s, jobs, lo_tab, hi_tab, hi_stride, partial_out,
+             max_chunks);
+}
+
+// =============================================================================================
+// a9  FRI quotients: row = sum_batches [ row*alpha^|batch| + (sum_cols c*f(q) - (A*q.y + B)) / den ]
+// =============================================================================================
+LMN_HD uint32_t domain_x(const uint32_t* tw_x, uint32_t s) {
+  uint32_t x = tw_x[s >> 2];
+  return (s & 2u) ? m_neg(x) : x;
+}
+LMN_HD uint32_t domain_y(const uint32_t* tw_y, uint32_t s) {
+  uint32_t y = tw_y[s >> 1];
+  return (s & 1u) ? m_neg(y) : y;
+}
+
+LMN_KERNEL k_quotients(QuotientArgs a) {
+  const uint64_t L = 1ull << a.log_size;
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= L) return;
+  const uint32_t x = a.log_size >= 2 ? domain_x(a.tw_x, s) : 0u;
+  const uint32_t y = domain_y(a.tw_y, s);
+  // denominators (CM31) and their batched inverses
+  CM31 den[QUOT_MAX_BATCH];
+  uint32_t nrm[QUOT_MAX_BATCH], pre[QUOT_MAX_BATCH];
+  for (int b = 0; b < a.nbatch; ++b) {
+    CM31 dx{m_sub(a.prx[b].a, x), a.prx[b].b};
+    CM31 dy{m_sub(a.pry[b].a, y), a.pry[b].b};
+    den[b] = c_sub(c_mul(dx, a.piy[b]), c_mul(dy, a.pix[b]));
+    nrm[b] = c_norm(den[b]);
+    pre[b] = b == 0 ? nrm[b] : m_mul(pre[b - 1], nrm[b]);
+  }
+  uint32_t inv = m_inv(pre[a.nbatch - 1]);
+  CM31 dinv[QUOT_MAX_BATCH];
+  for (int b = a.nbatch - 1; b >= 0; --b) {
+    uint32_t ni = b == 0 ? inv : m_mul(inv, pre[b - 1]);
+    inv = m_mul(inv, nrm[b]);
+    dinv[b] = CM31{m_mul(den[b].a, ni), m_mul(m_neg(den[b].b), ni)};
+  }
+  QM31 row = q_zero();
+  for (int b = 0; b < a.nbatch; ++b) {
+    QM31 num = q_zero();
+    for (int k = a.batch_start[b]; k < a.batch_start[b + 1]; ++k) {
+      uint32_t f = a.cols[a.col_idx[k]][s];
+      num = q_add(num, q_mul_m(a.coeff_c[k], f));
+    }
+    num = q_sub(num, q_add(q_mul_m(a.A[b], y), a.B[b]));
+    row = q_add(q_mul(row, a.batch_coeff[b]), q_mul_c(num, dinv[b]));
+  }
+  uint32_t* o = a.out + s;
+  o[0] = row.a;
+  o[L] = row.b;
+  o[2 * L] = row.c;
+  o[3 * L] = row.d;
+}
+
+void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
+  if (a.nbatch < 1 || a.nbatch > QUOT_MAX_BATCH) throw LmnError(-100, "quotients: bad batch count");
+  LMN_LAUNCH(k_quotients, dim3(cdiv(1ull << a.log_size, TPB)), dim3(TPB), 0, s, a);
+}
+
+// =============================================================================================
+// a9  FRI folds
+// =============================================================================================
+LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t src_len,
+                  const uint32_t* __restrict__ itw, QM31 alpha, QM31 alpha_sq, int accumulate) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = src_len >> 1;
+  if (i >= n) return;
+  const uint64_t L = src_len;
+  QM31 a{src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
+  QM31 b{src[2 * i + 1], src[L + 2 * i + 1], src[2 * L + 2 * i + 1], src[3 * L + 2 * i + 1]};
+  QM31 f0 = q_add(a, b);
+  QM31 f1 = q_mul_m(q_sub(a, b), itw[i]);
+  QM31 r = q_add(f0, q_mul(alpha, f1));
+  if (accumulate) {
+    QM31 d{dst[i], dst[(uint64_t)n + i], dst[2ull * n + i], dst[3ull * n + i]};
+    r = q_add(q_mul(d, alpha_sq), r);
+  }
+  dst[i] = r.a;
+  dst[(uint64_t)n + i] = r.b;
+  dst[2ull * n + i] = r.c;
+  dst[3ull * n + i] = r.d;
+}
+
+void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
+                                  QM31 alpha, int accumulate, lmn_stream_t s) {
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_y, alpha,
+             q_mul(alpha, alpha), accumulate);
+}
+void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, QM31 alpha,
+                      lmn_stream_t s) {
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_x, alpha, q_one(), 0);
+}
+
+}  // namespace lmn

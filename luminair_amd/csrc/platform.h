@@ -1,0 +1,132 @@
+// Platform layer: the product build is HIP for gfx950 (hipcc).  Defining LMN_EMU instead builds the
+// same kernel sources for a *test-only* host emulation (one OS thread per GPU thread, real
+// barriers) used by tests/emu to debug host orchestration and kernel indexing on a machine without
+// a GPU.  The emulation library is never loaded by the luminair_amd package; the shipped
+// libluminair_hip.so is built without LMN_EMU and fails loudly when no HIP device is present.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#ifndef LMN_EMU
+#include <hip/hip_runtime.h>
+#define LMN_HD __host__ __device__ __forceinline__
+#define LMN_D __device__ __forceinline__
+#define LMN_KERNEL __global__ void
+#define LMN_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; T* name = reinterpret_cast<T*>(name##_raw)
+#define LMN_SHARED __shared__
+typedef hipStream_t lmn_stream_t;
+
+struct LmnError : std::runtime_error {
+  int code;
+  LmnError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define LMN_HIP_CHECK(expr)                                                                        \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      throw LmnError(-100, std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                               std::to_string(__LINE__));                                          \
+  } while (0)
+
+#define LMN_LAUNCH(kernel, grid, block, smem, stream, ...)                          \
+  do {                                                                              \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);             \
+    LMN_HIP_CHECK(hipGetLastError());                                               \
+  } while (0)
+
+inline void* lmn_dev_malloc(size_t bytes) {
+  void* p = nullptr;
+  LMN_HIP_CHECK(hipMalloc(&p, bytes));
+  return p;
+}
+inline void lmn_dev_free(void* p) { (void)hipFree(p); }
+inline void lmn_h2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
+}
+inline void lmn_d2h(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
+}
+inline void lmn_d2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+}
+inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) { LMN_HIP_CHECK(hipMemsetAsync(dst, v, n, s)); }
+inline void lmn_sync(lmn_stream_t s) { LMN_HIP_CHECK(hipStreamSynchronize(s)); }
+typedef hipEvent_t lmn_event_t;
+inline lmn_event_t lmn_event_create() {
+  hipEvent_t e;
+  LMN_HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+inline void lmn_event_destroy(lmn_event_t e) { (void)hipEventDestroy(e); }
+inline void lmn_event_record(lmn_event_t e, lmn_stream_t s) { LMN_HIP_CHECK(hipEventRecord(e, s)); }
+inline float lmn_event_elapsed_ms(lmn_event_t a, lmn_event_t b) {
+  float ms = 0.f;
+  LMN_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms;
+}
+
+#else  // ------------------------------------------------------------------ LMN_EMU (tests only)
+#include <barrier>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define LMN_HD inline
+#define LMN_D inline
+#define LMN_KERNEL static void
+#define LMN_SHARED static
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3e {
+  unsigned x, y, z;
+};
+extern thread_local uint3e threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+extern thread_local unsigned char* lmn_emu_dyn_smem;
+void lmn_emu_syncthreads();
+#define __syncthreads() lmn_emu_syncthreads()
+#define LMN_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(lmn_emu_dyn_smem)
+typedef int lmn_stream_t;
+inline unsigned __brev(unsigned x) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+  return r;
+}
+
+struct LmnError : std::runtime_error {
+  int code;
+  LmnError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem);
+#define LMN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  lmn_emu_run([&]() { kernel(__VA_ARGS__); }, grid, block, smem)
+
+inline void* lmn_dev_malloc(size_t bytes) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p) throw LmnError(-100, "emu malloc failed");
+  return p;
+}
+inline void lmn_dev_free(void* p) { free(p); }
+inline void lmn_h2d(void* d, const void* s, size_t n, lmn_stream_t) { memcpy(d, s, n); }
+inline void lmn_d2h(void* d, const void* s, size_t n, lmn_stream_t) { memcpy(d, s, n); }
+inline void lmn_d2d(void* d, const void* s, size_t n, lmn_stream_t) { memmove(d, s, n); }
+inline void lmn_memset(void* d, int v, size_t n, lmn_stream_t) { memset(d, v, n); }
+inline void lmn_sync(lmn_stream_t) {}
+#include <chrono>
+typedef double* lmn_event_t;
+inline lmn_event_t lmn_event_create() { return new double(0.0); }
+inline void lmn_event_destroy(lmn_event_t e) { delete e; }
+inline void lmn_event_record(lmn_event_t e, lmn_stream_t) {
+  *e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline float lmn_event_elapsed_ms(lmn_event_t a, lmn_event_t b) { return (float)(*b - *a); }
+#endif

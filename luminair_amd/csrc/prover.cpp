@@ -1,0 +1,1250 @@
+// prove(): MI355X replacement for /root/reference/crates/prover/src/prover.rs:28-319.
+// The Fiat-Shamir channel, proof assembly and (tiny) decommitment bookkeeping run on the host;
+// every per-row / per-coefficient pass runs in the gfx950 kernels of kernels.hip on trace data
+// that stays resident in HBM from the first transpose to the last query gather.
+#include "prover.h"
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <set>
+
+namespace lmn {
+
+// ------------------------------------------------------------------------------------ components
+// Column layouts / relation wiring: crates/air/src/components/{add,mul,recip,inputs}/{table,component}.rs
+static const ComponentSpec kSpecs[] = {
+    {LMN_KIND_ADD, 15, 4, 3, {12, 13, 14}, {9, 10, 11}, {1, 2, 0}, 6},
+    {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7},
+    {LMN_KIND_RECIP, 13, 3, 2, {11, 12, 0}, {7, 8, 0}, {1, 0, 0}, 5},
+    {LMN_KIND_INPUTS, 7, 2, 1, {6, 0, 0}, {5, 0, 0}, {0, 0, 0}, 3},
+};
+const ComponentSpec* component_spec(int kind) {
+  for (auto& s : kSpecs)
+    if (s.kind == kind) return &s;
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------ arena
+Arena::~Arena() {
+  if (base_) lmn_dev_free(base_);
+}
+void Arena::reserve(size_t bytes) {
+  if (bytes <= cap_) return;
+  if (base_) lmn_dev_free(base_);
+  base_ = nullptr;
+  cap_ = 0;
+  try {
+    base_ = (char*)lmn_dev_malloc(bytes);
+  } catch (const LmnError& e) {
+    throw LmnError(LMN_ERR_OUT_OF_MEMORY, std::string("device arena allocation failed: ") + e.what());
+  }
+  cap_ = bytes;
+  off_ = 0;
+}
+void* Arena::alloc_bytes(size_t bytes) {
+  size_t a = (off_ + 255) & ~(size_t)255;
+  if (a + bytes > cap_) throw LmnError(LMN_ERR_OUT_OF_MEMORY, "device arena exhausted");
+  off_ = a + bytes;
+  return base_ + a;
+}
+
+// ------------------------------------------------------------------------------------ timing helper
+struct TimedSpan {
+  lmn_event_t a, b;
+  int cat;  // index into accumulators
+};
+struct EventLog {
+  std::vector<lmn_event_t> pool;
+  size_t used = 0;
+  std::vector<TimedSpan> spans;
+  lmn_event_t get() {
+    if (used == pool.size()) pool.push_back(lmn_event_create());
+    return pool[used++];
+  }
+  void reset() {
+    used = 0;
+    spans.clear();
+  }
+  ~EventLog() {
+    for (auto e : pool) lmn_event_destroy(e);
+  }
+};
+static EventLog* g_log(Context* c);
+
+enum Cat {
+  C_TOTAL = 0, C_TRANSPOSE, C_MAIN_COMMIT, C_LOGUP, C_INTER_COMMIT, C_COMPOSITION, C_COMP_COMMIT, C_OODS, C_QUOT,
+  C_FRI, C_DECOMMIT, C_FFT, C_MERKLE, C_N
+};
+
+struct StageTimer {
+  Context* ctx;
+  EventLog* log;
+  lmn_stream_t s;
+  int cat;
+  lmn_event_t a;
+  StageTimer(Context* c, EventLog* l, lmn_stream_t st, int cat_) : ctx(c), log(l), s(st), cat(cat_) {
+    a = log->get();
+    lmn_event_record(a, s);
+  }
+  ~StageTimer() {
+    lmn_event_t b = log->get();
+    lmn_event_record(b, s);
+    log->spans.push_back({a, b, cat});
+  }
+};
+
+// one EventLog per context, stored out-of-line to keep prover.h free of event types
+static std::map<Context*, EventLog*>& logs() {
+  static std::map<Context*, EventLog*> m;
+  return m;
+}
+static EventLog* g_log(Context* c) {
+  auto& m = logs();
+  auto it = m.find(c);
+  if (it == m.end()) it = m.emplace(c, new EventLog()).first;
+  return it->second;
+}
+
+// ------------------------------------------------------------------------------------ context
+Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
+#ifndef LMN_EMU
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw LmnError(LMN_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "device index out of range");
+  LMN_HIP_CHECK(hipSetDevice(device));
+  LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+#else
+  stream_ = 0;
+#endif
+  if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
+  if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
+  if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
+  if (cfg.pow_bits > 40) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad pow_bits");
+  if (cfg.protocol_variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  if (cfg.fp_scale != 12) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only fp_scale = 12 is supported");
+}
+
+Context::~Context() {
+#ifndef LMN_EMU
+  (void)hipSetDevice(device_);
+  (void)hipStreamSynchronize(stream_);
+#endif
+  auto& m = logs();
+  auto it = m.find(this);
+  if (it != m.end()) {
+    delete it->second;
+    m.erase(it);
+  }
+  for (void* p : tw_allocs_) lmn_dev_free(p);
+#ifndef LMN_EMU
+  (void)hipStreamDestroy(stream_);
+#endif
+}
+
+void* Context::upload(const void* host, size_t bytes) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  void* d = lmn_dev_malloc(bytes);
+  lmn_h2d(d, host, bytes, stream_);
+  lmn_sync(stream_);
+  return d;
+}
+void Context::device_free(void* p) { lmn_dev_free(p); }
+
+// Twiddle tables for every canonic domain up to 2^max_domain_log (computed
+// once per context and cached across proofs, instead of once per proof as prover.rs:38-42 does).
+//   Y[m][h] = y(half_coset_m.at(bitrev(h, m-1))), h < 2^(m-1)      (layer 0 of domain m)
+//   X[k][h] = x(half_coset_k.at(bitrev(h, k-2))), h < 2^(k-2)      (layer 1 of domain k)
+// Layer i >= 1 of domain m is X[m-i+1] (doubling a canonic half coset gives the next smaller one).
+void Context::ensure_twiddles(int M) {
+  if (M <= tw_max_log_) return;
+  if (M > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
+  for (void* p : tw_allocs_) lmn_dev_free(p);
+  tw_allocs_.clear();
+  twY_.assign(M + 1, nullptr);
+  twX_.assign(M + 1, nullptr);
+  itwY_.assign(M + 1, nullptr);
+  itwX_.assign(M + 1, nullptr);
+  auto batch_inverse = [](const std::vector<uint32_t>& v) {
+    std::vector<uint32_t> pre(v.size()), out(v.size());
+    uint32_t acc = 1;
+    for (size_t i = 0; i < v.size(); ++i) {
+      pre[i] = acc;
+      acc = m_mul(acc, v[i]);
+    }
+    uint32_t inv = m_inv(acc);
+    for (size_t i = v.size(); i-- > 0;) {
+      out[i] = m_mul(inv, pre[i]);
+      inv = m_mul(inv, v[i]);
+    }
+    return out;
+  };
+  auto up = [&](const std::vector<uint32_t>& v) {
+    uint32_t* d = (uint32_t*)lmn_dev_malloc(v.size() * 4);
+    tw_allocs_.push_back(d);
+    lmn_h2d(d, v.data(), v.size() * 4, stream_);
+    lmn_sync(stream_);
+    return d;
+  };
+  for (int m = 1; m <= M; ++m) {
+    // half coset of CanonicCoset(m): initial index 2^(30-m), step 2^(32-m), 2^(m-1) points
+    uint32_t half = 1u << (m - 1);
+    Pt cur = pt_of_index(1u << (30 - m));
+    Pt step = pt_of_index(m >= 2 ? (1u << (32 - m)) : 0u);
+    std::vector<Pt> pts(half);
+    for (uint32_t j = 0; j < half; ++j) {
+      pts[j] = cur;
+      cur = pt_add(cur, step);
+    }
+    std::vector<uint32_t> Y(half);
+    for (uint32_t h = 0; h < half; ++h) Y[h] = pts[bit_reverse(h, m - 1)].y;
+    twY_[m] = up(Y);
+    itwY_[m] = up(batch_inverse(Y));
+    if (m >= 2) {
+      uint32_t quarter = 1u << (m - 2);
+      std::vector<uint32_t> X(quarter);
+      for (uint32_t h = 0; h < quarter; ++h) X[h] = pts[bit_reverse(h, m - 2)].x;
+      twX_[m] = up(X);
+      itwX_[m] = up(batch_inverse(X));
+    }
+  }
+  tw_max_log_ = M;
+}
+
+TwPtrs Context::tw(int m) const {
+  TwPtrs t{};
+  t.l[0] = twY_[m];
+  for (int i = 1; i < m; ++i) t.l[i] = twX_[m - i + 1];
+  return t;
+}
+TwPtrs Context::itw(int m) const {
+  TwPtrs t{};
+  t.l[0] = itwY_[m];
+  for (int i = 1; i < m; ++i) t.l[i] = itwX_[m - i + 1];
+  return t;
+}
+
+// point of CanonicCoset(log).circle_domain() stored at index s (bit-reversed order)
+static Pt domain_point(int log, uint32_t s) {
+  uint32_t idx = bit_reverse(s, log);
+  uint32_t half = 1u << (log - 1);
+  uint32_t init = 1u << (30 - log);
+  uint32_t step = log >= 2 ? (1u << (32 - log)) : 0u;
+  if (idx < half) return pt_of_index(init + idx * step);
+  Pt p = pt_of_index(init + (idx - half) * step);
+  return {p.x, m_neg(p.y)};
+}
+
+// ------------------------------------------------------------------------------------ timed launches
+void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size,
+                                 uint32_t* out) {
+  launch_merkle_layer(prev, cols, ncols, size, out, stream_);
+  timings.merkle_launches++;
+  timings.merkle_bytes += (uint64_t)size * (4ull * ncols + 32ull + (prev ? 64ull : 0ull));
+}
+
+// Merkle tree over columns sorted by size (descending, stable): SURVEY.md Appendix A.4
+void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted) {
+  m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].second;
+  m.layers.assign(m.max_log + 1, nullptr);
+  if (cols_sorted.empty()) {
+    m.root = b2_hash_words(nullptr, 0);
+    return;
+  }
+  // one device pointer table for all columns
+  std::vector<const uint32_t*> ptrs(cols_sorted.size());
+  for (size_t i = 0; i < cols_sorted.size(); ++i) ptrs[i] = cols_sorted[i].first;
+  const uint32_t** dptrs = (const uint32_t**)arena_.alloc_bytes(ptrs.size() * sizeof(void*));
+  lmn_h2d((void*)dptrs, ptrs.data(), ptrs.size() * sizeof(void*), stream_);
+  lmn_sync(stream_);  // ptrs is a stack vector
+  size_t pos = 0;
+  const uint32_t* prev = nullptr;
+  StageTimer t(this, g_log(this), stream_, C_MERKLE);
+  for (int log = m.max_log; log >= 0; --log) {
+    size_t start = pos;
+    while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
+    uint32_t size = 1u << log;
+    uint32_t* out = arena_.alloc_words((size_t)size * 8);
+    merkle_layer_timed(prev, dptrs + start, (int)(pos - start), size, out);
+    m.layers[log] = out;
+    prev = out;
+  }
+  lmn_d2h(m.root.w, m.layers[0], 32, stream_);
+  lmn_sync(stream_);
+}
+
+// columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches)
+void Context::lde_and_merkle(DevTree& tree) {
+  const int lb = (int)cfg.log_blowup;
+  size_t i = 0;
+  while (i < tree.cols.size()) {
+    size_t j = i;
+    int log = tree.cols[i].log_size;
+    uint64_t n = 1ull << log;
+    while (j < tree.cols.size() && tree.cols[j].log_size == log && tree.cols[j].coeffs == tree.cols[i].coeffs + (j - i) * n)
+      ++j;
+    int ncols = (int)(j - i);
+    uint64_t L = n << lb;
+    uint32_t* lde = arena_.alloc_words((size_t)ncols * L);
+    {
+      StageTimer t(this, g_log(this), stream_, C_FFT);
+      timings.fft_launches += launch_fft(lde, L, tree.cols[i].coeffs, n, log, ncols, log + lb, tw(log + lb), stream_);
+      timings.fft_bytes += (uint64_t)ncols * (4ull * n + 4ull * L);
+    }
+    for (int c = 0; c < ncols; ++c) tree.cols[i + c].lde = lde + (uint64_t)c * L;
+    i = j;
+  }
+  std::vector<std::pair<const uint32_t*, int>> sorted;
+  for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb});
+  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
+  build_merkle(tree.merkle, sorted);
+}
+
+// ------------------------------------------------------------------------------------ host-side AIR at a point
+struct Instance {
+  const ComponentSpec* spec;
+  int log_size;
+  int main_start, inter_start;  // column offsets inside trees 1 / 2
+  QM31 claimed;
+  const QM31* d_claimed_shift;  // device [claimed, shift]
+  uint32_t* trace_evals;        // device, n_cols x 2^log_size
+};
+
+static QM31 qsub1(QM31 a) { return q_sub_m(a, 1u); }
+static QM31 one_minus(QM31 a) { return q_sub(q_one(), a); }
+
+// local constraints at a point, in `evaluate` order (crates/air/src/components/*/component.rs)
+static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c) {
+  std::vector<QM31> out;
+  if (kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) {
+    QM31 is_last = c[4], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    if (kind == LMN_KIND_ADD) {
+      out.push_back(q_sub(c[11], q_add(c[9], c[10])));
+    } else {
+      out.push_back(q_sub(q_mul(c[9], c[10]), q_add(q_mul_m(c[11], 4096u), c[12])));
+      out.push_back(q_zero());
+    }
+    out.push_back(q_mul(not_last, q_sub(c[5], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[6], c[1])));
+    out.push_back(q_mul(not_last, q_sub(c[7], c[2])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[8], c[3]))));
+  } else if (kind == LMN_KIND_RECIP) {
+    QM31 is_last = c[3], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    out.push_back(q_sub(q_sqr(c[10]), q_add(q_mul(c[7], c[8]), c[9])));
+    out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
+  } else {
+    QM31 is_last = c[2], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    out.push_back(q_mul(not_last, q_sub(c[3], c[0])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[4], c[1]))));
+  }
+  return out;
+}
+
+static QM31 eval_composition_at_point(const std::vector<Instance>& inst,
+                                      const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, QM31 z,
+                                      QM31 alpha_rel, QM31 comp_alpha) {
+  QM31 acc = q_zero();
+  for (auto& ci : inst) {
+    const ComponentSpec* sp = ci.spec;
+    std::vector<QM31> main(sp->n_cols);
+    for (int c = 0; c < sp->n_cols; ++c) main[c] = sv[1][ci.main_start + c][0];
+    std::vector<QM31> cons = local_constraints(sp->kind, main);
+    QM31 prev = q_zero();
+    QM31 shift = q_mul_m(ci.claimed, m_inv((uint32_t)((1ull << ci.log_size) % P31)));
+    for (int j = 0; j < sp->n_rel; ++j) {
+      const auto* cols = &sv[2][ci.inter_start + 4 * j];
+      QM31 den = q_sub(q_add(main[sp->rel_val[j]], q_mul(alpha_rel, main[sp->rel_id[j]])), z);
+      QM31 num = main[sp->rel_mult[j]];
+      QM31 cur, diff;
+      if (j < sp->n_rel - 1) {
+        cur = q_from_partial_evals(cols[0][0], cols[1][0], cols[2][0], cols[3][0]);
+        diff = q_sub(cur, prev);
+      } else {
+        QM31 prev_row = q_from_partial_evals(cols[0][0], cols[1][0], cols[2][0], cols[3][0]);
+        cur = q_from_partial_evals(cols[0][1], cols[1][1], cols[2][1], cols[3][1]);
+        diff = q_add(q_sub(q_sub(cur, prev_row), prev), shift);
+      }
+      cons.push_back(q_sub(q_mul(diff, den), num));
+      prev = cur;
+    }
+    QM31 x = oods.x;
+    for (int k = 0; k < ci.log_size - 1; ++k) x = q_sub_m(q_add(q_sqr(x), q_sqr(x)), 1u);
+    QM31 zinv = q_inv(x);
+    for (auto& c : cons) acc = q_add(q_mul(acc, comp_alpha), q_mul(c, zinv));
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------ OODS evaluation
+std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points,
+                                          int max_log) {
+  const int np = (int)points.size();
+  const uint32_t lo_n = 1u << EVAL_LB;
+  const int hi_bits = max_log > EVAL_LB ? max_log - EVAL_LB : 0;
+  const uint32_t hi_n = 1u << hi_bits;
+  std::vector<QM31> lo_tab((size_t)np * lo_n), hi_tab((size_t)np * hi_n);
+  for (int p = 0; p < np; ++p) {
+    // mappings: y, x, pi(x), pi^2(x), ...
+    std::vector<QM31> maps;
+    maps.push_back(points[p].y);
+    maps.push_back(points[p].x);
+    QM31 cur = points[p].x;
+    for (int k = 2; k < std::max(max_log, EVAL_LB); ++k) {
+      cur = q_sub_m(q_add(q_sqr(cur), q_sqr(cur)), 1u);
+      maps.push_back(cur);
+    }
+    QM31* L = &lo_tab[(size_t)p * lo_n];
+    L[0] = q_one();
+    for (int k = 0; k < EVAL_LB; ++k)
+      for (uint32_t j = 0; j < (1u << k); ++j) L[j + (1u << k)] = q_mul(L[j], maps[k]);
+    QM31* H = &hi_tab[(size_t)p * hi_n];
+    H[0] = q_one();
+    for (int k = 0; k < hi_bits; ++k)
+      for (uint32_t j = 0; j < (1u << k); ++j) H[j + (1u << k)] = q_mul(H[j], maps[EVAL_LB + k]);
+  }
+  int max_chunks = eval_num_chunks(max_log);
+  EvalJob* d_jobs = (EvalJob*)arena_.alloc_bytes(jobs.size() * sizeof(EvalJob));
+  QM31* d_lo = (QM31*)arena_.alloc_bytes(lo_tab.size() * sizeof(QM31));
+  QM31* d_hi = (QM31*)arena_.alloc_bytes(hi_tab.size() * sizeof(QM31));
+  QM31* d_out = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));
+  lmn_h2d(d_jobs, jobs.data(), jobs.size() * sizeof(EvalJob), stream_);
+  lmn_h2d(d_lo, lo_tab.data(), lo_tab.size() * sizeof(QM31), stream_);
+  lmn_h2d(d_hi, hi_tab.data(), hi_tab.size() * sizeof(QM31), stream_);
+  launch_eval_at_point(d_jobs, (int)jobs.size(), d_lo, d_hi, hi_n, max_log, d_out, max_chunks, stream_);
+  std::vector<QM31> partial(jobs.size() * (size_t)max_chunks);
+  lmn_d2h(partial.data(), d_out, partial.size() * sizeof(QM31), stream_);
+  lmn_sync(stream_);
+  std::vector<QM31> res(jobs.size());
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    QM31 acc = q_zero();
+    int nc = eval_num_chunks(jobs[j].log_n);
+    for (int c = 0; c < nc; ++c) acc = q_add(acc, partial[j * max_chunks + c]);
+    res[j] = acc;
+  }
+  return res;
+}
+
+// ------------------------------------------------------------------------------------ decommit planning
+struct Ref {
+  const uint32_t* ptr;
+  uint32_t len;
+};
+
+// MerkleProver::decommit: emits device references in output order
+static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
+                                 const std::map<int, std::vector<uint32_t>>& queries, std::vector<Ref>& queried,
+                                 std::vector<Ref>& hash_wit, std::vector<Ref>& col_wit) {
+  size_t pos = 0;
+  std::vector<uint32_t> last;
+  for (int log = m.max_log; log >= 0; --log) {
+    size_t start = pos;
+    while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
+    bool have_prev = log < m.max_log;
+    std::vector<uint32_t> colq;
+    auto it = queries.find(log);
+    if (it != queries.end()) colq = it->second;
+    size_t pi = 0, ci = 0;
+    std::vector<uint32_t> total;
+    while (pi < last.size() || ci < colq.size()) {
+      uint32_t node;
+      if (pi < last.size() && ci < colq.size())
+        node = std::min(last[pi] / 2, colq[ci]);
+      else if (pi < last.size())
+        node = last[pi] / 2;
+      else
+        node = colq[ci];
+      if (have_prev) {
+        if (pi < last.size() && last[pi] == 2 * node)
+          ++pi;
+        else
+          hash_wit.push_back({m.layers[log + 1] + (uint64_t)(2 * node) * 8, 8});
+        if (pi < last.size() && last[pi] == 2 * node + 1)
+          ++pi;
+        else
+          hash_wit.push_back({m.layers[log + 1] + (uint64_t)(2 * node + 1) * 8, 8});
+      }
+      bool is_q = ci < colq.size() && colq[ci] == node;
+      if (is_q) ++ci;
+      for (size_t c = start; c < pos; ++c) (is_q ? queried : col_wit).push_back({cols_sorted[c].first + node, 1});
+      total.push_back(node);
+    }
+    last.swap(total);
+  }
+}
+
+static std::vector<uint32_t> fold_positions(const std::vector<uint32_t>& p, int n) {
+  std::vector<uint32_t> out;
+  for (auto v : p) {
+    uint32_t q = v >> n;
+    if (out.empty() || out.back() != q) out.push_back(q);
+  }
+  return out;
+}
+
+// compute_decommitment_positions_and_witness_evals with fold_step = 1; `col` = 4 coordinate arrays
+static void plan_fri_witness(const uint32_t* col, uint64_t len, const std::vector<uint32_t>& qpos,
+                             std::vector<uint32_t>& dec_pos, std::vector<Ref>& wit) {
+  size_t i = 0;
+  while (i < qpos.size()) {
+    uint32_t start = (qpos[i] >> 1) << 1;
+    std::vector<uint32_t> subset;
+    while (i < qpos.size() && ((qpos[i] >> 1) << 1) == start) subset.push_back(qpos[i++]);
+    for (uint32_t pos = start; pos < start + 2; ++pos) {
+      dec_pos.push_back(pos);
+      if (std::find(subset.begin(), subset.end(), pos) != subset.end()) continue;
+      for (int k = 0; k < 4; ++k) wit.push_back({col + (uint64_t)k * len + pos, 1});
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ prove
+std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  if (!tables || n_tables == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "no trace tables");
+  if (settings && settings->has_lookups) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "lookup tables are out of scope");
+  const int lb = (int)cfg.log_blowup;
+  const int n_slots = cfg.protocol_variant == LMN_VARIANT_KAT ? 8 : 17;
+  EventLog* log = g_log(this);
+  log->reset();
+  memset(&timings, 0, sizeof timings);
+
+  // ---- validate + size
+  struct TableInfo {
+    const ComponentSpec* spec;
+    uint64_t n_rows;
+    int log_size;
+    const uint32_t* rows;
+    bool on_device;
+  };
+  std::vector<TableInfo> infos;
+  int max_log = 0;
+  int prev_kind = -1;
+  size_t words = 0;
+  for (size_t t = 0; t < n_tables; ++t) {
+    const lmn_table& tb = tables[t];
+    const ComponentSpec* sp = component_spec((int)tb.kind);
+    if (!sp) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "unsupported component kind " + std::to_string(tb.kind));
+    if ((int)tb.kind >= n_slots)
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "component kind has no claim slot in this protocol variant");
+    if ((int)tb.kind <= prev_kind)
+      throw LmnError(LMN_ERR_CONSTRAINTS, "tables must be in gen_trace order (ascending kind, no duplicates)");
+    prev_kind = (int)tb.kind;
+    if (tb.n_rows == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
+    if (!tb.rows) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null rows pointer");
+    uint64_t size = 16;
+    while (size < tb.n_rows) size <<= 1;
+    int ls = 0;
+    while ((1ull << ls) < size) ++ls;
+    if (ls + lb + 2 > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
+    infos.push_back({sp, tb.n_rows, ls, tb.rows, (tb.flags & LMN_TABLE_ROWS_ON_DEVICE) != 0});
+    max_log = std::max(max_log, ls);
+    uint64_t cells = (uint64_t)(sp->n_cols + 4 * sp->n_rel) << ls;
+    words += cells * (2 + (1ull << lb));                       // evals + coeffs + lde
+    if (!infos.back().on_device) words += tb.n_rows * sp->n_cols;  // staging
+    words += (4ull << ls) * 2;                                 // logup temps
+    words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
+  }
+  const int comp_log = max_log + 1;
+  const int max_lde = comp_log + lb;
+  words += (4ull << comp_log) * 2 + (4ull << max_lde);         // composition values/coeffs + lde
+  words += (4ull << max_lde) * 3;                              // quotient columns (all sizes) + fri layers
+  words += 7 * (16ull << max_lde);                             // merkle trees (4 trace + fri first + inner)
+  words += (16u << 20);                                        // slack: tables, partials, gather buffers
+  ensure_twiddles(max_lde);
+  arena_.reserve(words * 4);
+  arena_.reset();
+
+  Channel channel(cfg.protocol_variant);
+  Proof proof;
+  proof.claim.assign(n_slots, -1);
+  proof.interaction_claim.assign(n_slots, {false, q_zero()});
+  proof.pow_bits = cfg.pow_bits;
+  proof.log_blowup = cfg.log_blowup;
+  proof.log_last_layer = cfg.log_last_layer;
+  proof.n_queries = cfg.n_queries;
+
+  StageTimer* total_timer = new StageTimer(this, log, stream_, C_TOTAL);
+  std::unique_ptr<StageTimer> total_guard(total_timer);
+
+  // ---- PHASE 0: preprocessed trace — empty tree, root = blake2s("") (prover.rs:54-59)
+  DevTree tree0;
+  build_merkle(tree0.merkle, {});
+  channel.mix_root(tree0.merkle.root);
+
+  // ---- PHASE 1: main trace (prover.rs:70-179)
+  DevTree tree1;
+  std::vector<Instance> inst;
+  {
+    StageTimer st(this, log, stream_, C_TRANSPOSE);
+    for (auto& ti : infos) {
+      const uint32_t* d_rows = ti.rows;
+      if (!ti.on_device) {
+        uint32_t* stg = arena_.alloc_words(ti.n_rows * ti.spec->n_cols);
+        lmn_h2d(stg, ti.rows, ti.n_rows * ti.spec->n_cols * 4, stream_);
+        d_rows = stg;
+      }
+      uint64_t n = 1ull << ti.log_size;
+      uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * n);
+      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, ti.spec->is_last_col, stream_);
+      Instance ci{};
+      ci.spec = ti.spec;
+      ci.log_size = ti.log_size;
+      ci.trace_evals = evals;
+      inst.push_back(ci);
+      proof.claim[ti.spec->kind] = ti.log_size;
+    }
+  }
+  {
+    StageTimer st(this, log, stream_, C_MAIN_COMMIT);
+    int off = 0;
+    for (auto& ci : inst) {
+      uint64_t n = 1ull << ci.log_size;
+      int nc = ci.spec->n_cols;
+      uint32_t* coeffs = arena_.alloc_words((size_t)nc * n);
+      {
+        StageTimer t(this, log, stream_, C_FFT);
+        timings.fft_launches += launch_ifft(coeffs, n, ci.trace_evals, n, nc, ci.log_size, itw(ci.log_size), stream_);
+        timings.fft_bytes += (uint64_t)nc * 8ull * n;
+      }
+      ci.main_start = off;
+      off += nc;
+      for (int c = 0; c < nc; ++c) tree1.cols.push_back({ci.log_size, coeffs + (uint64_t)c * n, nullptr});
+    }
+    for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
+      if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
+    lde_and_merkle(tree1);
+    channel.mix_root(tree1.merkle.root);
+  }
+
+  // ---- PHASE 2: interaction trace (prover.rs:186-298)
+  std::vector<QM31> rel = channel.draw_felts(2);  // NodeElements: z, alpha
+  const QM31 z = rel[0], alpha_rel = rel[1];
+  for (int k = 0; k < (cfg.protocol_variant == LMN_VARIANT_KAT ? 1 : 4); ++k) channel.draw_felts(2);  // LookupElements
+  DevTree tree2;
+  {
+    StageTimer st(this, log, stream_, C_LOGUP);
+    int off = 0;
+    for (auto& ci : inst) {
+      const ComponentSpec* sp = ci.spec;
+      uint64_t n = 1ull << ci.log_size;
+      int nic = 4 * sp->n_rel;
+      uint32_t* ievals = arena_.alloc_words((size_t)nic * n);
+      LogupArgs a{};
+      a.k = sp->n_rel;
+      for (int j = 0; j < sp->n_rel; ++j) {
+        a.val[j] = ci.trace_evals + (uint64_t)sp->rel_val[j] * n;
+        a.id[j] = ci.trace_evals + (uint64_t)sp->rel_id[j] * n;
+        a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * n;
+      }
+      a.z = z;
+      a.alpha = alpha_rel;
+      a.inter = ievals;
+      a.last_tmp = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
+      int nb = logup_num_blocks((uint32_t)n);
+      a.partials = arena_.alloc_words((size_t)nb * 4);
+      a.n = (uint32_t)n;
+      launch_logup_fracs(a, stream_);
+      QM31* d_cs = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
+      uint32_t n_inv = m_inv((uint32_t)(n % P31));
+      launch_logup_reduce(a.partials, nb, n_inv, d_cs, stream_);
+      QM31* bsums = (QM31*)arena_.alloc_bytes((size_t)logup_scan_num_blocks(ci.log_size) * sizeof(QM31));
+      launch_logup_scan(a.last_tmp, d_cs, ci.log_size, ievals + (uint64_t)(nic - 4) * n, bsums, stream_);
+      ci.d_claimed_shift = d_cs;
+      ci.inter_start = off;
+      off += nic;
+      // interaction evals -> coefficients in place, registered as tree-2 columns
+      {
+        StageTimer t(this, log, stream_, C_FFT);
+        timings.fft_launches += launch_ifft(ievals, n, ievals, n, nic, ci.log_size, itw(ci.log_size), stream_);
+        timings.fft_bytes += (uint64_t)nic * 8ull * n;
+      }
+      for (int c = 0; c < nic; ++c) tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, nullptr});
+    }
+    // claimed sums back to the host for the transcript
+    std::vector<QM31> cs(2 * inst.size());
+    for (size_t i = 0; i < inst.size(); ++i) lmn_d2h(&cs[2 * i], inst[i].d_claimed_shift, 2 * sizeof(QM31), stream_);
+    lmn_sync(stream_);
+    for (size_t i = 0; i < inst.size(); ++i) {
+      inst[i].claimed = cs[2 * i];
+      proof.interaction_claim[inst[i].spec->kind] = {true, cs[2 * i]};
+    }
+  }
+  for (int k = 0; k < n_slots; ++k)
+    if (proof.interaction_claim[k].first) channel.mix_felts({proof.interaction_claim[k].second});
+  {
+    StageTimer st(this, log, stream_, C_INTER_COMMIT);
+    lde_and_merkle(tree2);
+    channel.mix_root(tree2.merkle.root);
+  }
+
+  // ---- stwo::prover::prove (prover.rs:312): composition polynomial
+  const QM31 comp_alpha = channel.draw_felt();
+  int n_total = 0;
+  for (auto& ci : inst) n_total += ci.spec->n_local + ci.spec->n_rel;
+  std::vector<QM31> powers(n_total);
+  powers[0] = q_one();
+  for (int k = 1; k < n_total; ++k) powers[k] = q_mul(powers[k - 1], comp_alpha);
+  DevTree tree3;
+  {
+    StageTimer st(this, log, stream_, C_COMPOSITION);
+    std::map<int, uint32_t*> sub;  // eval log -> 4 x 2^e accumulation buffer
+    int k0 = 0;
+    for (auto& ci : inst) {
+      int e = ci.log_size + 1;
+      uint64_t E = 1ull << e;
+      bool first = sub.find(e) == sub.end();
+      if (first) sub[e] = arena_.alloc_words(4 * E);
+      CompositionArgs a{};
+      a.kind = ci.spec->kind;
+      a.log_size = ci.log_size;
+      a.eval_log = e;
+      a.main = tree1.cols[ci.main_start].lde;
+      a.inter = tree2.cols[ci.inter_start].lde;
+      a.out = sub[e];
+      a.accumulate = first ? 0 : 1;
+      a.z = z;
+      a.alpha = alpha_rel;
+      a.claimed_shift = ci.d_claimed_shift;
+      int nc = ci.spec->n_local + ci.spec->n_rel;
+      for (int k = 0; k < nc; ++k) a.coeff[k] = powers[n_total - 1 - (k0 + k)];
+      k0 += nc;
+      for (int b = 0; b < 2; ++b) {
+        Pt p = domain_point(e, (uint32_t)b << ci.log_size);
+        uint32_t x = p.x;
+        for (int k = 0; k < ci.log_size - 1; ++k) x = m_sub(m_dbl(m_sqr(x)), 1u);
+        a.zinv[b] = m_inv(x);
+      }
+      launch_composition(a, stream_);
+    }
+    // DomainEvaluationAccumulator::finalize: fold smaller sizes into larger ones
+    uint32_t* cur = nullptr;  // coefficients, 4 x 2^cur_log
+    int cur_log = 0;
+    for (auto& kv : sub) {
+      int e = kv.first;
+      uint64_t E = 1ull << e;
+      uint32_t* vals = kv.second;
+      if (cur) {
+        uint32_t* ext = arena_.alloc_words(4 * E);
+        StageTimer t(this, log, stream_, C_FFT);
+        timings.fft_launches += launch_fft(ext, E, cur, 1ull << cur_log, cur_log, 4, e, tw(e), stream_);
+        timings.fft_bytes += 4ull * (4ull << cur_log) + 4ull * 4ull * E;
+        launch_secure_add(vals, ext, 4 * E, stream_);
+      }
+      {
+        StageTimer t(this, log, stream_, C_FFT);
+        timings.fft_launches += launch_ifft(vals, E, vals, E, 4, e, itw(e), stream_);
+        timings.fft_bytes += 4ull * 8ull * E;
+      }
+      cur = vals;
+      cur_log = e;
+    }
+    if (cur_log != comp_log) throw LmnError(LMN_ERR_INTERNAL, "composition size mismatch");
+    for (int k = 0; k < 4; ++k) tree3.cols.push_back({comp_log, cur + ((uint64_t)k << comp_log), nullptr});
+  }
+  {
+    StageTimer st(this, log, stream_, C_COMP_COMMIT);
+    lde_and_merkle(tree3);
+    channel.mix_root(tree3.merkle.root);
+  }
+  DevTree* trees[4] = {&tree0, &tree1, &tree2, &tree3};
+  for (auto* t : trees) proof.commitments.push_back(t->merkle.root);
+
+  // ---- OODS point + mask points
+  QM31 tt = channel.draw_felt();
+  QM31 t2 = q_sqr(tt);
+  QM31 tinv = q_inv(q_add_m(t2, 1u));
+  QPt oods{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
+  std::vector<QPt> points{oods};
+  std::map<int, int> prev_point_of_log;
+  for (auto& ci : inst) {
+    if (prev_point_of_log.count(ci.log_size)) continue;
+    Pt stp = pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu);  // -step
+    prev_point_of_log[ci.log_size] = (int)points.size();
+    points.push_back(qpt_add_m(oods, stp));
+  }
+  // sample point indices per tree/column, in sampled_values order
+  std::vector<std::vector<std::vector<int>>> spoints(4);
+  spoints[1].assign(tree1.cols.size(), {0});
+  spoints[2].assign(tree2.cols.size(), {0});
+  spoints[3].assign(4, {0});
+  for (auto& ci : inst) {
+    int nic = 4 * ci.spec->n_rel;
+    for (int c = nic - 4; c < nic; ++c) spoints[2][ci.inter_start + c] = {prev_point_of_log[ci.log_size], 0};
+  }
+  std::vector<std::vector<std::vector<QM31>>> sampled(4);
+  {
+    StageTimer st(this, log, stream_, C_OODS);
+    std::vector<EvalJob> jobs;
+    for (int t = 1; t < 4; ++t)
+      for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+        for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p});
+    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log);
+    size_t k = 0;
+    for (int t = 1; t < 4; ++t) {
+      sampled[t].resize(trees[t]->cols.size());
+      for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+        for (size_t p = 0; p < spoints[t][c].size(); ++p) sampled[t][c].push_back(vals[k++]);
+    }
+  }
+  proof.sampled_values = sampled;
+  {
+    std::vector<QM31> flat;
+    for (auto& t : sampled)
+      for (auto& c : t)
+        for (auto& v : c) flat.push_back(v);
+    channel.mix_felts(flat);
+  }
+  // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
+  {
+    QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
+    QM31 rhs = eval_composition_at_point(inst, sampled, oods, z, alpha_rel, comp_alpha);
+    if (!q_eq(lhs, rhs)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
+  }
+
+  // ---- FRI quotients, one secure column per LDE size (descending)
+  const QM31 quot_alpha = channel.draw_felt();
+  struct FlatCol {
+    const uint32_t* lde;
+    int lde_log;
+    std::vector<std::pair<int, QM31>> samples;  // (point index, value)
+  };
+  std::vector<FlatCol> flat;
+  for (int t = 1; t < 4; ++t)
+    for (size_t c = 0; c < trees[t]->cols.size(); ++c) {
+      FlatCol f{trees[t]->cols[c].lde, trees[t]->cols[c].log_size + lb, {}};
+      for (size_t p = 0; p < spoints[t][c].size(); ++p) f.samples.push_back({spoints[t][c][p], sampled[t][c][p]});
+      flat.push_back(f);
+    }
+  std::set<int, std::greater<int>> size_set;
+  for (auto& f : flat) size_set.insert(f.lde_log);
+  std::vector<int> sizes(size_set.begin(), size_set.end());
+  struct Quot {
+    int log;
+    uint32_t* vals;  // 4 x 2^log
+  };
+  std::vector<Quot> quots;
+  {
+    StageTimer st(this, log, stream_, C_QUOT);
+    for (int ls : sizes) {
+      std::vector<const FlatCol*> cols;
+      for (auto& f : flat)
+        if (f.lde_log == ls) cols.push_back(&f);
+      // ColumnSampleBatch::new_vec: group by point in first-appearance order
+      std::vector<int> batch_point;
+      std::vector<std::vector<std::pair<int, QM31>>> batch_cols;
+      for (size_t c = 0; c < cols.size(); ++c)
+        for (auto& sm : cols[c]->samples) {
+          size_t b = 0;
+          while (b < batch_point.size() && batch_point[b] != sm.first) ++b;
+          if (b == batch_point.size()) {
+            batch_point.push_back(sm.first);
+            batch_cols.emplace_back();
+          }
+          batch_cols[b].push_back({(int)c, sm.second});
+        }
+      if (batch_point.size() > (size_t)QUOT_MAX_BATCH) throw LmnError(LMN_ERR_INTERNAL, "too many sample batches");
+      QuotientArgs a{};
+      a.log_size = ls;
+      a.nbatch = (int)batch_point.size();
+      std::vector<int> col_idx;
+      std::vector<QM31> coeff_c;
+      for (size_t b = 0; b < batch_point.size(); ++b) {
+        QPt pt = points[batch_point[b]];
+        a.batch_start[b] = (int)col_idx.size();
+        QM31 alpha = q_one(), A = q_zero(), B = q_zero();
+        for (auto& cv : batch_cols[b]) {
+          alpha = q_mul(alpha, quot_alpha);
+          QM31 val = cv.second;
+          QM31 la = q_sub(q_conj(val), val);
+          QM31 lc = q_sub(q_conj(pt.y), pt.y);
+          QM31 lbb = q_sub(q_mul(val, lc), q_mul(la, pt.y));
+          A = q_add(A, q_mul(alpha, la));
+          B = q_add(B, q_mul(alpha, lbb));
+          col_idx.push_back(cv.first);
+          coeff_c.push_back(q_mul(alpha, lc));
+        }
+        a.A[b] = A;
+        a.B[b] = B;
+        a.batch_coeff[b] = q_pow(quot_alpha, batch_cols[b].size());
+        a.prx[b] = {pt.x.a, pt.x.b};
+        a.pix[b] = {pt.x.c, pt.x.d};
+        a.pry[b] = {pt.y.a, pt.y.b};
+        a.piy[b] = {pt.y.c, pt.y.d};
+      }
+      a.batch_start[batch_point.size()] = (int)col_idx.size();
+      std::vector<const uint32_t*> ptrs;
+      for (auto* f : cols) ptrs.push_back(f->lde);
+      const uint32_t** d_ptrs = (const uint32_t**)arena_.alloc_bytes(ptrs.size() * sizeof(void*));
+      int* d_idx = (int*)arena_.alloc_bytes(col_idx.size() * sizeof(int));
+      QM31* d_c = (QM31*)arena_.alloc_bytes(coeff_c.size() * sizeof(QM31));
+      lmn_h2d((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), stream_);
+      lmn_h2d(d_idx, col_idx.data(), col_idx.size() * sizeof(int), stream_);
+      lmn_h2d(d_c, coeff_c.data(), coeff_c.size() * sizeof(QM31), stream_);
+      lmn_sync(stream_);
+      a.cols = d_ptrs;
+      a.col_idx = d_idx;
+      a.coeff_c = d_c;
+      a.tw_y = twY_[ls];
+      a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
+      a.out = arena_.alloc_words(4ull << ls);
+      launch_quotients(a, stream_);
+      quots.push_back({ls, a.out});
+    }
+  }
+
+  // ---- FRI commit
+  struct FriLayer {
+    int log;
+    uint32_t* vals;  // 4 x 2^log (line evaluation)
+    DevMerkle merkle;
+  };
+  DevMerkle first_merkle;
+  std::vector<std::pair<const uint32_t*, int>> first_cols;
+  std::vector<FriLayer> inner;
+  std::vector<QM31> last_vals;
+  int last_log = 0;
+  {
+    StageTimer st(this, log, stream_, C_FRI);
+    for (auto& q : quots)
+      for (int k = 0; k < 4; ++k) first_cols.push_back({q.vals + ((uint64_t)k << q.log), q.log});
+    build_merkle(first_merkle, first_cols);
+    channel.mix_root(first_merkle.root);
+    QM31 alpha = channel.draw_felt();
+    int ls0 = quots[0].log;
+    int layer_log = ls0 - 1;
+    uint32_t* layer = arena_.alloc_words(4ull << layer_log);
+    launch_fold_circle_into_line(layer, quots[0].vals, 1u << ls0, itwY_[ls0], alpha, 0, stream_);
+    size_t qi = 1;
+    const int last_size_log = (int)cfg.log_last_layer + lb;
+    while (layer_log > last_size_log) {
+      FriLayer fl;
+      fl.log = layer_log;
+      fl.vals = layer;
+      std::vector<std::pair<const uint32_t*, int>> lc;
+      for (int k = 0; k < 4; ++k) lc.push_back({layer + ((uint64_t)k << layer_log), layer_log});
+      build_merkle(fl.merkle, lc);
+      channel.mix_root(fl.merkle.root);
+      alpha = channel.draw_felt();
+      uint32_t* next = arena_.alloc_words(4ull << (layer_log - 1));
+      // line domain of log L has the x-coordinates of CanonicCoset(L+1)'s half coset
+      launch_fold_line(next, layer, 1u << layer_log, itwX_[layer_log + 1], alpha, stream_);
+      inner.push_back(fl);
+      layer = next;
+      layer_log -= 1;
+      while (qi < quots.size() && quots[qi].log - 1 == layer_log) {
+        launch_fold_circle_into_line(layer, quots[qi].vals, 1u << quots[qi].log, itwY_[quots[qi].log], alpha, 1,
+                                     stream_);
+        ++qi;
+      }
+    }
+    if (qi != quots.size()) throw LmnError(LMN_ERR_INTERNAL, "FRI: unconsumed columns");
+    last_log = layer_log;
+    std::vector<uint32_t> raw(4ull << last_log);
+    lmn_d2h(raw.data(), layer, raw.size() * 4, stream_);
+    lmn_sync(stream_);
+    uint32_t n = 1u << last_log;
+    for (uint32_t i = 0; i < n; ++i) last_vals.push_back({raw[i], raw[n + i], raw[2 * n + i], raw[3 * n + i]});
+  }
+  // last layer: interpolate the line evaluation (bit-reversed over LineDomain(half_odds(last_log)))
+  {
+    std::vector<std::vector<QM31>> chunks{last_vals};
+    int dlog = last_log;
+    // x-coordinates of the current line domain in bit-reversed order
+    auto line_xs = [&](int lg) {
+      std::vector<uint32_t> xs(1u << lg);
+      uint32_t init = 1u << (31 - (lg + 2)), step = lg >= 1 ? (1u << (31 - lg)) : 0u;
+      for (uint32_t i = 0; i < (1u << lg); ++i) xs[i] = pt_of_index(init + bit_reverse(i, lg) * step).x;
+      return xs;
+    };
+    while (dlog > 0) {
+      std::vector<uint32_t> xs = line_xs(dlog);
+      std::vector<std::vector<QM31>> nc;
+      for (auto& ch : chunks) {
+        std::vector<QM31> f0, f1;
+        for (size_t i = 0; i < ch.size() / 2; ++i) {
+          QM31 a = ch[2 * i], b = ch[2 * i + 1];
+          f0.push_back(q_add(a, b));
+          f1.push_back(q_mul_m(q_sub(a, b), m_inv(xs[2 * i])));
+        }
+        nc.push_back(f0);
+        nc.push_back(f1);
+      }
+      chunks.swap(nc);
+      // after halving, the remaining domain is the doubled line domain
+      dlog -= 1;
+    }
+    uint32_t n = 1u << last_log;
+    uint32_t ninv = m_inv(n % P31);
+    std::vector<QM31> coeffs(n);
+    for (uint32_t idx = 0; idx < n; ++idx) {
+      uint32_t j = 0;
+      for (int k = 0; k < last_log; ++k) j |= ((idx >> (last_log - 1 - k)) & 1u) << k;
+      coeffs[j] = q_mul_m(chunks[idx][0], ninv);
+    }
+    uint32_t bound = 1u << cfg.log_last_layer;
+    for (uint32_t j = bound; j < n; ++j)
+      if (!q_is_zero(coeffs[j])) throw LmnError(LMN_ERR_INTERNAL, "FRI: invalid last-layer degree");
+    coeffs.resize(bound);
+    proof.last_layer_coeffs = coeffs;
+    proof.last_layer_log_size = cfg.log_last_layer;
+    channel.mix_felts(coeffs);
+  }
+
+  // ---- proof of work + queries
+  proof.proof_of_work = channel.grind(cfg.pow_bits);
+  channel.mix_u64(proof.proof_of_work);
+  const int ls0 = quots[0].log;
+  std::vector<uint32_t> queries;
+  {
+    std::set<uint32_t> qs;
+    uint64_t cnt = 0;
+    const uint32_t mask = (1u << ls0) - 1u;
+    while (cnt < cfg.n_queries) {
+      Hash32 r = channel.draw_random_words();
+      for (int i = 0; i < 8 && cnt < cfg.n_queries; ++i, ++cnt) qs.insert(r.w[i] & mask);
+    }
+    queries.assign(qs.begin(), qs.end());
+  }
+  std::map<int, std::vector<uint32_t>> pos_by_log;
+  for (int ls : sizes) pos_by_log[ls] = fold_positions(queries, ls0 - ls);
+
+  // ---- decommitment: plan device references, gather once, distribute
+  {
+    StageTimer st(this, log, stream_, C_DECOMMIT);
+    struct Plan {
+      std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
+    };
+    std::vector<Plan> plans;  // [first, inner..., tree0..3]
+    {
+      Plan p;
+      std::map<int, std::vector<uint32_t>> dec;
+      for (auto& q : quots) plan_fri_witness(q.vals, 1ull << q.log, pos_by_log[q.log], dec[q.log], p.fri_wit);
+      std::vector<Ref> dummy;
+      plan_merkle_decommit(first_merkle, first_cols, dec, dummy, p.hash_wit, p.col_wit);
+      plans.push_back(p);
+    }
+    std::vector<uint32_t> lq = fold_positions(queries, 1);
+    for (auto& fl : inner) {
+      Plan p;
+      std::map<int, std::vector<uint32_t>> dec;
+      plan_fri_witness(fl.vals, 1ull << fl.log, lq, dec[fl.log], p.fri_wit);
+      std::vector<std::pair<const uint32_t*, int>> lc;
+      for (int k = 0; k < 4; ++k) lc.push_back({fl.vals + ((uint64_t)k << fl.log), fl.log});
+      std::vector<Ref> dummy;
+      plan_merkle_decommit(fl.merkle, lc, dec, dummy, p.hash_wit, p.col_wit);
+      plans.push_back(p);
+      lq = fold_positions(lq, 1);
+    }
+    for (auto* t : trees) {
+      Plan p;
+      std::vector<std::pair<const uint32_t*, int>> sorted;
+      std::map<int, std::vector<uint32_t>> qmap;
+      for (auto& c : t->cols) {
+        sorted.push_back({c.lde, c.log_size + lb});
+        qmap[c.log_size + lb] = pos_by_log[c.log_size + lb];
+      }
+      std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
+      plan_merkle_decommit(t->merkle, sorted, qmap, p.queried, p.hash_wit, p.col_wit);
+      plans.push_back(p);
+    }
+    std::vector<GatherEntry> entries;
+    uint32_t out_words = 0;
+    auto add_refs = [&](const std::vector<Ref>& refs) {
+      for (auto& r : refs) {
+        entries.push_back({arena_.word_offset(r.ptr), r.len, out_words});
+        out_words += r.len;
+      }
+    };
+    for (auto& p : plans) {
+      add_refs(p.fri_wit);
+      add_refs(p.queried);
+      add_refs(p.hash_wit);
+      add_refs(p.col_wit);
+    }
+    std::vector<uint32_t> gathered(out_words);
+    if (!entries.empty()) {
+      GatherEntry* d_e = (GatherEntry*)arena_.alloc_bytes(entries.size() * sizeof(GatherEntry));
+      uint32_t* d_o = arena_.alloc_words(out_words);
+      lmn_h2d(d_e, entries.data(), entries.size() * sizeof(GatherEntry), stream_);
+      launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
+      lmn_d2h(gathered.data(), d_o, (size_t)out_words * 4, stream_);
+      lmn_sync(stream_);
+    }
+    size_t g = 0;
+    auto take_q = [&](size_t nrefs) {
+      std::vector<QM31> v;
+      for (size_t i = 0; i < nrefs / 4; ++i) {
+        v.push_back({gathered[g], gathered[g + 1], gathered[g + 2], gathered[g + 3]});
+        g += 4;
+      }
+      return v;
+    };
+    auto take_u32 = [&](size_t n) {
+      std::vector<uint32_t> v(gathered.begin() + g, gathered.begin() + g + n);
+      g += n;
+      return v;
+    };
+    auto take_hashes = [&](size_t n) {
+      std::vector<Hash32> v(n);
+      for (size_t i = 0; i < n; ++i) {
+        memcpy(v[i].w, &gathered[g], 32);
+        g += 8;
+      }
+      return v;
+    };
+    size_t pi = 0;
+    auto fill_layer = [&](FriLayerProof& lp, const Hash32& root) {
+      Plan& p = plans[pi++];
+      lp.fri_witness = take_q(p.fri_wit.size());
+      take_u32(p.queried.size());
+      lp.decommitment.hash_witness = take_hashes(p.hash_wit.size());
+      lp.decommitment.column_witness = take_u32(p.col_wit.size());
+      lp.commitment = root;
+    };
+    fill_layer(proof.first_layer, first_merkle.root);
+    proof.inner_layers.resize(inner.size());
+    for (size_t i = 0; i < inner.size(); ++i) fill_layer(proof.inner_layers[i], inner[i].merkle.root);
+    for (int t = 0; t < 4; ++t) {
+      Plan& p = plans[pi++];
+      take_q(p.fri_wit.size());
+      proof.queried_values.push_back(take_u32(p.queried.size()));
+      Decommitment d;
+      d.hash_witness = take_hashes(p.hash_wit.size());
+      d.column_witness = take_u32(p.col_wit.size());
+      proof.decommitments.push_back(d);
+    }
+  }
+  total_guard.reset();
+  lmn_sync(stream_);
+
+  // ---- timings
+  float acc[C_N] = {0};
+  for (auto& sp : log->spans) acc[sp.cat] += lmn_event_elapsed_ms(sp.a, sp.b);
+  timings.total_ms = acc[C_TOTAL];
+  timings.transpose_ms = acc[C_TRANSPOSE];
+  timings.main_commit_ms = acc[C_MAIN_COMMIT];
+  timings.logup_ms = acc[C_LOGUP];
+  timings.interaction_commit_ms = acc[C_INTER_COMMIT];
+  timings.composition_ms = acc[C_COMPOSITION];
+  timings.composition_commit_ms = acc[C_COMP_COMMIT];
+  timings.oods_ms = acc[C_OODS];
+  timings.quotients_ms = acc[C_QUOT];
+  timings.fri_ms = acc[C_FRI];
+  timings.decommit_ms = acc[C_DECOMMIT];
+  timings.fft_ms = acc[C_FFT];
+  timings.merkle_ms = acc[C_MERKLE];
+  return proof_to_bincode(proof);
+}
+
+// ------------------------------------------------------------------------------------ level-2 ops
+void Context::op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size) {
+  ensure_twiddles((int)log_size);
+  size_t bytes = ((size_t)ncols << log_size) * 4;
+  arena_.reserve(bytes + (1u << 20));
+  arena_.reset();
+  uint32_t* d = arena_.alloc_words((size_t)ncols << log_size);
+  lmn_h2d(d, cols, bytes, stream_);
+  launch_ifft(d, 1ull << log_size, d, 1ull << log_size, (int)ncols, (int)log_size, itw((int)log_size), stream_);
+  lmn_d2h(cols, d, bytes, stream_);
+  lmn_sync(stream_);
+}
+
+void Context::op_evaluate(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
+                          uint32_t* out) {
+  if (log_coeffs > log_domain) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "log_coeffs > log_domain");
+  ensure_twiddles((int)log_domain);
+  size_t in_w = (size_t)ncols << log_coeffs, out_w = (size_t)ncols << log_domain;
+  arena_.reserve((in_w + out_w) * 4 + (1u << 20));
+  arena_.reset();
+  uint32_t* d_in = arena_.alloc_words(in_w);
+  uint32_t* d_out = arena_.alloc_words(out_w);
+  lmn_h2d(d_in, coeffs, in_w * 4, stream_);
+  launch_fft(d_out, 1ull << log_domain, d_in, 1ull << log_coeffs, (int)log_coeffs, (int)ncols, (int)log_domain,
+             tw((int)log_domain), stream_);
+  lmn_d2h(out, d_out, out_w * 4, stream_);
+  lmn_sync(stream_);
+}
+
+void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols, uint8_t root[32]) {
+  size_t words = 0;
+  uint32_t max_log = 0;
+  for (uint32_t c = 0; c < ncols; ++c) {
+    words += 1ull << log_sizes[c];
+    max_log = std::max(max_log, log_sizes[c]);
+  }
+  arena_.reserve((words + (16ull << max_log)) * 4 + (1u << 20));
+  arena_.reset();
+  std::vector<std::pair<const uint32_t*, int>> sorted;
+  for (uint32_t c = 0; c < ncols; ++c) {
+    uint32_t* d = arena_.alloc_words(1ull << log_sizes[c]);
+    lmn_h2d(d, cols[c], (4ull << log_sizes[c]), stream_);
+    sorted.push_back({d, (int)log_sizes[c]});
+  }
+  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
+  g_log(this)->reset();
+  DevMerkle m;
+  build_merkle(m, sorted);
+  memcpy(root, m.root.w, 32);
+}
+
+void Context::op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const uint32_t pt[8], uint32_t out[4]) {
+  arena_.reserve((4ull << log_size) + (8u << 20));
+  arena_.reset();
+  uint32_t* d = arena_.alloc_words(1ull << log_size);
+  lmn_h2d(d, coeffs, 4ull << log_size, stream_);
+  QPt p{{pt[0], pt[1], pt[2], pt[3]}, {pt[4], pt[5], pt[6], pt[7]}};
+  std::vector<QM31> r = eval_at_points({{d, (int)log_size, 0}}, {p}, (int)log_size);
+  out[0] = r[0].a;
+  out[1] = r[0].b;
+  out[2] = r[0].c;
+  out[3] = r[0].d;
+}
+
+// tiled FFT vs one-layer-per-launch kernels on pseudo-random data (device-side differential check)
+void Context::op_fft_selftest(uint32_t log_size, uint32_t ncols) {
+  ensure_twiddles((int)log_size);
+  size_t w = (size_t)ncols << log_size;
+  arena_.reserve(w * 8 + (1u << 20));
+  arena_.reset();
+  std::vector<uint32_t> h(w);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (auto& v : h) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    v = (uint32_t)(st >> 33) % P31;
+  }
+  uint32_t* a = arena_.alloc_words(w);
+  uint32_t* b = arena_.alloc_words(w);
+  uint64_t n = 1ull << log_size;
+  for (int inverse = 0; inverse < 2; ++inverse) {
+    lmn_h2d(a, h.data(), w * 4, stream_);
+    lmn_h2d(b, h.data(), w * 4, stream_);
+    if (inverse) {
+      launch_ifft(a, n, a, n, (int)ncols, (int)log_size, itw((int)log_size), stream_);
+      launch_fft_simple(b, n, (int)ncols, (int)log_size, itw((int)log_size), true, stream_);
+    } else {
+      launch_fft(a, n, a, n, (int)log_size, (int)ncols, (int)log_size, tw((int)log_size), stream_);
+      launch_fft_simple(b, n, (int)ncols, (int)log_size, tw((int)log_size), false, stream_);
+    }
+    std::vector<uint32_t> ra(w), rb(w);
+    lmn_d2h(ra.data(), a, w * 4, stream_);
+    lmn_d2h(rb.data(), b, w * 4, stream_);
+    lmn_sync(stream_);
+    for (size_t i = 0; i < w; ++i)
+      if (ra[i] != rb[i])
+        throw LmnError(LMN_ERR_INTERNAL, std::string("fft selftest mismatch (inverse=") + std::to_string(inverse) +
+                                             ") at word " + std::to_string(i));
+  }
+}
+
+}  // namespace lmn

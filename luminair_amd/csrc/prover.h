@@ -1,0 +1,101 @@
+// Device-resident prover context and the `prove` orchestration that replaces
+// /root/reference/crates/prover/src/prover.rs:28-319 on MI355X.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/luminair_hip.h"
+#include "host.h"
+#include "kernels.h"
+
+namespace lmn {
+
+struct ComponentSpec {
+  int kind;
+  int n_cols;
+  int is_last_col;
+  int n_rel;
+  int rel_mult[3], rel_val[3], rel_id[3];
+  int n_local;  // number of local constraints (including zero slots)
+};
+const ComponentSpec* component_spec(int kind);
+
+// bump allocator over one device slab; reset per proof
+class Arena {
+ public:
+  ~Arena();
+  void reserve(size_t bytes);
+  void reset() { off_ = 0; }
+  void* alloc_bytes(size_t bytes);
+  uint32_t* alloc_words(size_t words) { return (uint32_t*)alloc_bytes(words * 4); }
+  uint64_t word_offset(const void* p) const { return (uint64_t)((const char*)p - base_) / 4; }
+  const uint32_t* base_words() const { return (const uint32_t*)base_; }
+  size_t capacity() const { return cap_; }
+  size_t used() const { return off_; }
+
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0;
+};
+
+struct DevColumn {
+  int log_size;      // polynomial (coefficient) log size
+  uint32_t* coeffs;  // 2^log_size
+  uint32_t* lde;     // 2^(log_size + log_blowup), bit-reversed canonic-domain evaluations
+};
+
+struct DevMerkle {
+  int max_log = -1;
+  std::vector<uint32_t*> layers;  // layers[k]: 2^k hashes of 8 words
+  Hash32 root;
+};
+
+struct DevTree {
+  std::vector<DevColumn> cols;
+  DevMerkle merkle;
+};
+
+struct StageTimer;
+
+class Context {
+ public:
+  Context(int device, const lmn_config& cfg);
+  ~Context();
+  std::vector<uint8_t> prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings);
+
+  // level-2 ops
+  void op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size);
+  void op_evaluate(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain, uint32_t* out);
+  void op_merkle_root(const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols, uint8_t root[32]);
+  void op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const uint32_t pt[8], uint32_t out[4]);
+  void op_fft_selftest(uint32_t log_size, uint32_t ncols);
+
+  void* upload(const void* host, size_t bytes);
+  void device_free(void* p);
+
+  lmn_config cfg;
+  lmn_timings timings{};
+  std::string last_error;
+
+ private:
+  void ensure_twiddles(int max_domain_log);
+  TwPtrs tw(int domain_log) const;
+  TwPtrs itw(int domain_log) const;
+  // commit `cols` (coefficients already in place) -> LDE + Merkle
+  void lde_and_merkle(DevTree& tree);
+  void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted);
+  void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
+  std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
+
+  int device_;
+  lmn_stream_t stream_{};
+  Arena arena_;
+  int tw_max_log_ = 0;
+  // twiddle tables: Y[m] (m>=1), X[k] (k>=2), forward + inverse, device pointers
+  std::vector<uint32_t*> twY_, twX_, itwY_, itwX_;
+  std::vector<void*> tw_allocs_;
+  friend struct StageTimer;
+};
+
+}  // namespace lmn

@@ -1,0 +1,59 @@
+"""`prove(pie, settings)` — same name, argument meaning and error behaviour as
+`/root/reference/crates/prover/src/prover.rs:28-31`, executed by the HIP backend."""
+from __future__ import annotations
+
+from typing import Optional
+
+from . import backend
+from .pie import CircuitSettings, LuminairError, LuminairPie, LuminairProof
+
+_ERR_VARIANT = {
+    backend.ERR_EMPTY_TRACE: "TraceError(EmptyTrace)",
+    backend.ERR_MAIN_TRACE: "MainTraceEvalGenError",
+    backend.ERR_INTERACTION_TRACE: "InteractionTraceEvalGenError",
+    backend.ERR_CONSTRAINTS: "ProverError(ConstraintsNotSatisfied)",
+    backend.ERR_SERIALIZATION: "SerializationError",
+    backend.ERR_INVALID_ARGUMENT: "InvalidArgument",
+    backend.ERR_OUT_OF_MEMORY: "OutOfMemory",
+    backend.ERR_NO_DEVICE: "NoDevice",
+    backend.ERR_INTERNAL: "Internal",
+}
+
+
+class Prover:
+    """A prover bound to one GPU; keeps twiddles and the device arena cached across proofs
+    (the reference recomputes twiddles per call, prover.rs:38-42)."""
+
+    def __init__(self, device: int = 0, protocol_variant: int = backend.VARIANT_KAT, library=None, **pcs):
+        lib = library or backend.default_library()
+        cfg = lib.default_config()
+        cfg.protocol_variant = protocol_variant
+        for k, v in pcs.items():
+            setattr(cfg, k, v)
+        try:
+            self.ctx = backend.Context(device, cfg, lib)
+        except backend.LuminairBackendError as e:
+            raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
+
+    def prove(self, pie: LuminairPie, settings: Optional[CircuitSettings] = None) -> LuminairProof:
+        if settings is not None and settings.lookups:
+            raise LuminairError("InvalidArgument", "lookup tables are outside the hot-path scope")
+        tables = [(int(t.kind), t.rows, t.n_rows) for t in pie.trace_tables]
+        try:
+            return LuminairProof(self.ctx.prove_tables(tables))
+        except backend.LuminairBackendError as e:
+            raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
+
+    def timings(self) -> dict:
+        return self.ctx.timings()
+
+
+_default: Optional[Prover] = None
+
+
+def prove(pie: LuminairPie, settings: Optional[CircuitSettings] = None) -> LuminairProof:
+    """Drop-in for the reference's free function `prove(pie, settings)` on GPU 0."""
+    global _default
+    if _default is None:
+        _default = Prover(0)
+    return _default.prove(pie, settings)

@@ -1,0 +1,136 @@
+"""Synthetic `LuminairPie` generators for the BASELINE.json configs.
+
+They emit exactly the rows `gen_trace` would record for the named graphs
+(`crates/graph/src/op/prim.rs:967-1013` Add, `:1090-1139` Mul, `:388-431` Recip,
+`:52-88` Inputs): AoS uint32 rows in `Column::index()` order, values = `Fixed<12>::to_m31()`.
+Seeds are numpy PCG64 seeds; the default seed 42 follows the reference tests
+(`crates/graph/src/tests/mod.rs:202-214`).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+P = (1 << 31) - 1
+SCALE = 1 << 12
+KIND_ADD, KIND_MUL, KIND_RECIP, KIND_INPUTS = 0, 1, 2, 15
+
+
+def to_m31(v: np.ndarray) -> np.ndarray:
+    """Fixed<12>::to_m31: negatives map to P - |v|."""
+    v = np.asarray(v, dtype=np.int64)
+    return np.where(v >= 0, v, P + v).astype(np.uint32)
+
+
+def _ids(n, node, a, b=None):
+    idx = np.arange(n, dtype=np.int64)
+    last = (idx == n - 1).astype(np.int64)
+    cols = [np.full(n, node), np.full(n, a)]
+    if b is not None:
+        cols.append(np.full(n, b))
+    cols += [idx, last, np.full(n, node), np.full(n, a)]
+    if b is not None:
+        cols.append(np.full(n, b))
+    cols.append(idx + 1)
+    return cols
+
+
+def add_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(0, 0, 0)) -> np.ndarray:
+    lhs, rhs = np.asarray(lhs, np.int64), np.asarray(rhs, np.int64)
+    n = len(lhs)
+    out = lhs + rhs
+    cols = _ids(n, node, lhs_id, rhs_id) + [to_m31(lhs), to_m31(rhs), to_m31(out)]
+    cols += [np.full(n, m % P) for m in mults]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def mul_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(0, 0, 0)) -> np.ndarray:
+    """Operands >= 0 (the sign convention of numerair's rem is unverified)."""
+    lhs, rhs = np.asarray(lhs, np.int64), np.asarray(rhs, np.int64)
+    n = len(lhs)
+    prod = lhs * rhs
+    out, rem = prod >> 12, prod & (SCALE - 1)
+    cols = _ids(n, node, lhs_id, rhs_id) + [to_m31(lhs), to_m31(rhs), to_m31(out), to_m31(rem)]
+    cols += [np.full(n, m % P) for m in mults]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def recip_rows(inp, node=2, input_id=0, mults=(0, 0)) -> np.ndarray:
+    inp = np.asarray(inp, np.int64)
+    n = len(inp)
+    out = (SCALE * SCALE) // inp
+    rem = SCALE * SCALE - inp * out
+    cols = _ids(n, node, input_id) + [to_m31(inp), to_m31(out), to_m31(rem), np.full(n, SCALE)]
+    cols += [np.full(n, m % P) for m in mults]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def inputs_rows(vals, node, multiplicity) -> np.ndarray:
+    vals = np.asarray(vals, np.int64)
+    n = len(vals)
+    idx = np.arange(n, dtype=np.int64)
+    last = (idx == n - 1).astype(np.int64)
+    cols = [np.full(n, node), idx, last, np.full(n, node), idx + 1, to_m31(vals), np.full(n, multiplicity % P)]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def config2_add_only(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
+    """BASELINE config 2a: one Add table, all multiplicities 0 (logup sums are trivially 0)."""
+    rng = np.random.default_rng(seed)
+    lhs = rng.integers(-2048, 2048, size=n_rows)
+    rhs = rng.integers(-2048, 2048, size=n_rows)
+    return [(KIND_ADD, add_rows(lhs, rhs))]
+
+
+def config2_graph_faithful(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
+    """BASELINE config 2b (needs the PINNED variant): Add consumes both inputs with mult -1,
+    an Inputs table of 2n rows yields them with multiplicity 1."""
+    rng = np.random.default_rng(seed)
+    lhs = rng.integers(-2048, 2048, size=n_rows)
+    rhs = rng.integers(-2048, 2048, size=n_rows)
+    add = add_rows(lhs, rhs, mults=(-1, -1, 0))
+    inp = np.concatenate([inputs_rows(lhs, 0, 1), inputs_rows(rhs, 1, 1)])
+    return [(KIND_ADD, add), (KIND_INPUTS, inp)]
+
+
+def chain_graph(n: int, seed: int = 42, with_recip: bool = True) -> List[Tuple[int, np.ndarray]]:
+    """c = a*b (node 3); d = c + w (node 4); e = recip(d) (node 5) on n-element tensors, in the
+    KAT-era multiplicity rule (graph initializers are consumed with multiplicity 0), so the
+    logup sums cancel: Mul yields c once, Add consumes c and yields d once, Recip consumes d."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(1, 2048, size=n)
+    b = rng.integers(1, 2048, size=n)
+    w = rng.integers(8, 2048, size=n)
+    c = (a * b) >> 12
+    d = c + w
+    tabs = [(KIND_ADD, add_rows(c, w, node=4, lhs_id=3, rhs_id=8, mults=(-1, 0, 1 if with_recip else 0))),
+            (KIND_MUL, mul_rows(a, b, node=3, lhs_id=6, rhs_id=7, mults=(0, 0, 1)))]
+    if with_recip:
+        tabs.append((KIND_RECIP, recip_rows(d, node=5, input_id=4, mults=(-1, 0))))
+    return tabs
+
+
+def config3_mixed(log_add: int = 21, log_mul: int = 20, log_recip: int = 20, seed: int = 42):
+    """BASELINE config 3: Add 2^21 + Mul 2^20 + Recip 2^20 rows in one pie (independent ops,
+    all multiplicities 0)."""
+    rng = np.random.default_rng(seed)
+    na, nm, nr = 1 << log_add, 1 << log_mul, 1 << log_recip
+    return [(KIND_ADD, add_rows(rng.integers(-2048, 2048, size=na), rng.integers(-2048, 2048, size=na))),
+            (KIND_MUL, mul_rows(rng.integers(0, 2048, size=nm), rng.integers(0, 2048, size=nm), node=5, lhs_id=3,
+                                rhs_id=4)),
+            (KIND_RECIP, recip_rows(rng.integers(4, 2048, size=nr), node=7, input_id=6))]
+
+
+def simple_example() -> List[Tuple[int, np.ndarray]]:
+    """`examples/simple/src/main.rs:15-22`: c=a*b; d=c+w; e=c*d on 2x2 tensors — the tables of
+    SURVEY.md Appendix A.10 (KAT-era multiplicities)."""
+    a, b, w = [1, 2, 3, 4], [10, 20, 30, 40], [-1, -1, -1, -1]
+    S = SCALE
+    a, b, w = np.array(a) * S, np.array(b) * S, np.array(w) * S
+    c = (a * b) >> 12
+    d = c + w
+    add = add_rows(c, w, node=4, lhs_id=3, rhs_id=8, mults=(-1, 0, 1))
+    mul = np.concatenate([mul_rows(a, b, node=3, lhs_id=6, rhs_id=7, mults=(0, 0, 2)),
+                          mul_rows(c, d, node=5, lhs_id=3, rhs_id=4, mults=(-1, -1, 0))])
+    return [(KIND_ADD, add), (KIND_MUL, mul)]

@@ -1,0 +1,82 @@
+"""Host orchestration + kernel indexing logic, run through the TEST-ONLY kernel emulation build
+(tests/emu: the same HIP sources compiled with g++ -DLMN_EMU, one fiber per GPU thread) and compared
+byte-for-byte with the oracle.  This is CPU-side debugging coverage, not the parity proof: the
+parity tests proper are tests/test_gpu_parity.py (-m gpu), which call the real HIP library."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from luminair_amd import backend, synthetic as syn
+from oracle.proof import to_bincode
+from oracle.prover import prove as oracle_prove
+
+
+@pytest.fixture(scope="module")
+def emu_ctx(root):
+    so = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    srcs = [os.path.join(root, "luminair_amd", "csrc", f) for f in os.listdir(os.path.join(root, "luminair_amd", "csrc"))
+            if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(root, "tests", "emu", "emu_runtime.cpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run([os.path.join(root, "tests", "emu", "build_emu.sh")], check=True, capture_output=True)
+    return backend.Context(0, None, backend.Library(so))
+
+
+def _both(ctx, tabs):
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs]))
+    return got, want
+
+
+def test_emu_reproduces_kat(emu_ctx, kat_bytes):
+    tabs = syn.simple_example()
+    assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == kat_bytes
+
+
+@pytest.mark.parametrize("name,tabs", [
+    ("add-ragged-100", syn.config2_add_only(100, 1)),
+    ("chain-300", syn.chain_graph(300, 3)),
+    ("mixed-sizes", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])]),
+    ("single-row", syn.chain_graph(1, 6)),
+])
+def test_emu_matches_oracle(emu_ctx, name, tabs):
+    got, want = _both(emu_ctx, tabs)
+    assert got == want, name
+
+
+def test_emu_error_codes(emu_ctx):
+    with pytest.raises(backend.LuminairBackendError) as e:
+        emu_ctx.prove_tables([(0, np.zeros((0, 15), np.uint32), 0)])
+    assert e.value.code == backend.ERR_EMPTY_TRACE
+    bad = syn.config2_add_only(64, 9)[0][1].copy()
+    bad[3, 11] ^= 1
+    with pytest.raises(backend.LuminairBackendError) as e:
+        emu_ctx.prove_tables([(0, bad, len(bad))])
+    assert e.value.code == backend.ERR_CONSTRAINTS
+    with pytest.raises(backend.LuminairBackendError) as e:   # Sin component is out of scope
+        emu_ctx.prove_tables([(3, np.zeros((4, 12), np.uint32), 4)])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    with pytest.raises(backend.LuminairBackendError) as e:   # wrong table order
+        t = syn.chain_graph(16, 1)
+        emu_ctx.prove_tables([(t[1][0], t[1][1], 16), (t[0][0], t[0][1], 16)])
+    assert e.value.code == backend.ERR_CONSTRAINTS
+
+
+def test_emu_level2_ops(emu_ctx):
+    from oracle import fft
+    from oracle.field import P, QM31
+    from oracle.merkle import MerkleTree
+    rng = np.random.default_rng(5)
+    ev = rng.integers(0, P, size=(3, 1 << 7), dtype=np.uint64)
+    co = emu_ctx.interpolate(ev.astype(np.uint32))
+    assert np.array_equal(co, fft.interpolate(ev).astype(np.uint32))
+    lde = emu_ctx.evaluate(co, 9)
+    assert np.array_equal(lde, fft.evaluate(co.astype(np.uint64), 9).astype(np.uint32))
+    cols = [rng.integers(0, P, size=1 << k, dtype=np.uint64).astype(np.uint32) for k in (6, 6, 5, 6, 3)]
+    assert emu_ctx.merkle_root(cols) == MerkleTree(cols).root()
+    pt = [int(v) for v in rng.integers(0, P, size=8)]
+    c = rng.integers(0, P, size=1 << 12, dtype=np.uint64)
+    want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
+    assert emu_ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
+    emu_ctx.fft_selftest(13, 1)
