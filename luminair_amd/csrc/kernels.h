@@ -35,6 +35,33 @@ void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32
 void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
                          lmn_stream_t s);
 
+// fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
+// The start level's columns are given as runs of contiguous equal-size columns.
+constexpr int MERKLE_MAX_SEG = 4;
+constexpr int MERKLE_MAX_SUB = 3;     // per-lane register subtree: 2^3 start nodes
+constexpr int MERKLE_MAX_FUSED = 11;  // levels above the start level covered by one launch
+struct MerkleSegs {
+  const uint32_t* base[MERKLE_MAX_SEG];
+  int n[MERKLE_MAX_SEG];
+};
+struct MerkleLevels {
+  uint32_t* p[MERKLE_MAX_FUSED + 1];  // p[0] = start level output, p[l] = l levels above it
+};
+void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s);
+// one block, size <= 1024 start nodes, nfused <= 10
+void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int nfused, lmn_stream_t s);
+
+// ---- device-resident channel (FRI commit loop): digest <- H(digest || root); alpha <- draw_felt()
+struct DevChannel {
+  uint32_t digest[8];
+  uint32_t n_sent;
+  uint32_t variant;
+};
+void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
+                               lmn_stream_t s);
+
 // ---- gather: out[dst_off[e] + k] = arena[src_off[e] + k], k < len[e]
 struct GatherEntry {
   uint64_t src_off;  // word offset into arena
@@ -98,13 +125,16 @@ int eval_num_chunks(int log_n);
 
 // ---- a9: FRI quotients
 constexpr int QUOT_MAX_BATCH = 4;
+constexpr int QUOT_MAX_ENTRIES = 512;
+struct QuotEntry {
+  const uint32_t* col;         // column of 2^log_size words
+  QM31 c;                      // alpha^k * c for this (batch, column) sample
+};
 struct QuotientArgs {
   int log_size;
-  const uint32_t* const* cols; // device array of column pointers (all of size 2^log_size)
   int nbatch;
-  int batch_start[QUOT_MAX_BATCH + 1];  // range into col_idx / coeff_c
-  const int* col_idx;          // device
-  const QM31* coeff_c;         // device: alpha^k * c per (batch, column)
+  int batch_start[QUOT_MAX_BATCH + 1];  // range into entries
+  const QuotEntry* entries;    // device
   QM31 A[QUOT_MAX_BATCH], B[QUOT_MAX_BATCH], batch_coeff[QUOT_MAX_BATCH];
   CM31 prx[QUOT_MAX_BATCH], pry[QUOT_MAX_BATCH], pix[QUOT_MAX_BATCH], piy[QUOT_MAX_BATCH];
   const uint32_t* tw_y;        // layer-0 twiddles of the domain (y at storage 2h)
@@ -114,9 +144,10 @@ struct QuotientArgs {
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s);
 
 // ---- a9: FRI folds.  Secure columns are 4 coordinate arrays at stride = length.
+// alpha is read from device memory (written by the device-resident channel).
 void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
-                                  QM31 alpha, int accumulate, lmn_stream_t s);
-void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, QM31 alpha,
+                                  const QM31* alpha, int accumulate, lmn_stream_t s);
+void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, const QM31* alpha,
                       lmn_stream_t s);
 
 }  // namespace lmn

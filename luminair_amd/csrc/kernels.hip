@@ -250,6 +250,208 @@ void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int 
   LMN_LAUNCH(k_merkle_layer, dim3(cdiv(size, TPB)), dim3(TPB), 0, s, prev, cols, ncols, size, out);
 }
 
+// Fused Merkle subtree.  Every lane owns 2^sub consecutive start-level nodes and reduces them to one
+// subtree root in registers (post-order, private LDS slots as the merge stack: all 64 lanes of a
+// wave stay busy on every compression); the block's subtree roots then climb further levels
+// through LDS.  All levels are written to HBM (decommitment needs them).
+// Start-level columns are described as up to MERKLE_MAX_SEG runs of contiguous columns
+// (column c of a run lives at base + c*size), so no per-column pointer loads are needed.
+LMN_D const uint32_t* merkle_col_ptr(const MerkleSegs& sg, int c, uint64_t size) {
+  // c is compile-time after unrolling; the comparisons are wave-uniform scalar work
+  int n0 = sg.n[0], n1 = n0 + sg.n[1], n2 = n1 + sg.n[2];
+  if (c < n0) return sg.base[0] + (uint64_t)c * size;
+  if (c < n1) return sg.base[1] + (uint64_t)(c - n0) * size;
+  if (c < n2) return sg.base[2] + (uint64_t)(c - n1) * size;
+  return sg.base[3] + (uint64_t)(c - n2) * size;
+}
+
+LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                             uint32_t i, uint32_t h[8]) {
+  b2_init(h);
+  uint32_t m[16];
+  int c0 = 0;  // first column of the current block
+  if (prev) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
+    uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+    m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+    m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+    if (ncols == 0) {
+      b2_compress(h, m, 64u, 0xffffffffu);
+      return;
+    }
+    b2_compress(h, m, 64u, 0u);
+  }
+  const uint32_t total = (prev ? 64u : 0u) + 4u * (uint32_t)ncols;
+  uint32_t done = prev ? 64u : 0u;
+  while (c0 < ncols) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int c = c0 + k;
+      m[k] = c < ncols ? merkle_col_ptr(sg, c, size)[i] : 0u;
+    }
+    c0 += 16;
+    bool last = c0 >= ncols;
+    done += 64u;
+    b2_compress(h, m, last ? total : done, last ? 0xffffffffu : 0u);
+  }
+}
+
+LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
+  uint4* o4 = reinterpret_cast<uint4*>(o);
+  o4[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  o4[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// LDS climb shared by both kernels: `n_here` hashes of this block sit in sh[idx*8..]; levels
+// first..last are produced (level l has lvl_size0 >> (l - first + 1) nodes in total).
+template <int BLOCK>
+LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, int last, uint32_t lvl_size,
+                            uint32_t cur[8]) {
+  for (int l = first; l <= last; ++l) {
+    __syncthreads();
+    lvl_size >>= 1;
+    const uint32_t active = (uint32_t)BLOCK >> (l - first + 1);
+    const uint32_t node = blockIdx.x * active + threadIdx.x;
+    const bool on = threadIdx.x < active && node < lvl_size;
+    if (on) {
+      uint32_t m[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = sh[threadIdx.x * 16 + k];
+      b2_init(cur);
+      b2_compress(cur, m, 64u, 0xffffffffu);
+      store_hash(outs.p[l] + (uint64_t)node * 8, cur);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = cur[k];
+    }
+  }
+}
+
+LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
+                          MerkleLevels outs, int sub, int nfused) {
+  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 8 * TPB];  // [level][word][thread]
+  LMN_SHARED uint32_t sh[TPB * 8];
+  const uint32_t per = 1u << sub;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // subtree index
+  const uint32_t nsub = size >> sub;
+  uint32_t cur[8];
+  if (t < nsub) {
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t node = t * per + j;
+      merkle_hash_start(prev, sg, ncols, size, node, cur);
+      store_hash(outs.p[0] + (uint64_t)node * 8, cur);
+      uint32_t jj = j;
+      int lvl = 0;
+      while (jj & 1u) {
+        uint32_t m[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          m[k] = stack[(lvl * 8 + k) * TPB + threadIdx.x];
+          m[8 + k] = cur[k];
+        }
+        b2_init(cur);
+        b2_compress(cur, m, 64u, 0xffffffffu);
+        jj >>= 1;
+        ++lvl;
+        store_hash(outs.p[lvl] + (uint64_t)(node >> lvl) * 8, cur);
+      }
+      if (lvl < sub) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stack[(lvl * 8 + k) * TPB + threadIdx.x] = cur[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = cur[k];
+  }
+  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, nsub, cur);
+}
+
+// Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
+constexpr int MERKLE_SMALL_BLOCK = 1024;
+LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
+                          MerkleLevels outs, int nfused) {
+  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  const uint32_t i = threadIdx.x;
+  uint32_t cur[8];
+  if (i < size) {
+    merkle_hash_start(prev, sg, ncols, size, i, cur);
+    store_hash(outs.p[0] + (uint64_t)i * 8, cur);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+  }
+  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size, cur);
+}
+
+void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 || (size >> sub) == 0)
+    throw LmnError(-100, "merkle_fused: bad arguments");
+  LMN_LAUNCH(k_merkle_fused, dim3(cdiv(size >> sub, TPB)), dim3(TPB), 0, s, prev, sg, ncols, size, outs, sub, nfused);
+}
+
+void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int nfused, lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
+  LMN_LAUNCH(k_merkle_small, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, prev, sg, ncols, size, outs, nfused);
+}
+
+// =============================================================================================
+// Device-resident Fiat-Shamir steps for the FRI commit loop (no host round trip per layer)
+// =============================================================================================
+LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
+  uint32_t m[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = ch->digest[k];
+  m[8] = ch->n_sent;
+#pragma unroll
+  for (int k = 9; k < 16; ++k) m[k] = 0u;
+  b2_init(out);
+  // KAT variant: digest || u64 counter zero-padded to 32 bytes (64-byte message);
+  // PINNED variant: digest || u32 counter || 0x00 (37-byte message)
+  b2_compress(out, m, ch->variant == 0u ? 64u : 37u, 0xffffffffu);
+  ch->n_sent += 1u;
+}
+
+LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ root, QM31* out_alpha,
+                                uint32_t* root_copy) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t m[16], h[8];
+  for (int k = 0; k < 8; ++k) {
+    m[k] = ch->digest[k];
+    m[8 + k] = root[k];
+    root_copy[k] = root[k];
+  }
+  b2_init(h);
+  b2_compress(h, m, 64u, 0xffffffffu);
+  for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
+  ch->n_sent = 0u;
+  for (;;) {
+    uint32_t w[8];
+    chan_draw_words(ch, w);
+    bool ok = true;
+    for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
+    if (!ok) continue;
+    QM31 a;
+    a.a = w[0] >= P31 ? w[0] - P31 : w[0];
+    a.b = w[1] >= P31 ? w[1] - P31 : w[1];
+    a.c = w[2] >= P31 ? w[2] - P31 : w[2];
+    a.d = w[3] >= P31 ? w[3] - P31 : w[3];
+    *out_alpha = a;
+    break;
+  }
+}
+
+void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
+                               lmn_stream_t s) {
+  LMN_LAUNCH(k_chan_mix_root_draw, dim3(1), dim3(64), 0, s, ch, root, out_alpha, root_copy);
+}
+
 // =============================================================================================
 // gather
 // =============================================================================================
@@ -646,6 +848,12 @@ LMN_HD uint32_t domain_y(const uint32_t* tw_y, uint32_t s) {
 }
 
 LMN_KERNEL k_quotients(QuotientArgs a) {
+  // (column pointer, alpha^k * c) table staged once per block in LDS: the per-column loop then
+  // reads wave-uniform LDS words instead of chasing pointers through global memory
+  LMN_SHARED QuotEntry tab[QUOT_MAX_ENTRIES];
+  const int nent = a.batch_start[a.nbatch];
+  for (int e = threadIdx.x; e < nent; e += blockDim.x) tab[e] = a.entries[e];
+  __syncthreads();
   const uint64_t L = 1ull << a.log_size;
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= L) return;
@@ -654,27 +862,42 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
   // denominators (CM31) and their batched inverses
   CM31 den[QUOT_MAX_BATCH];
   uint32_t nrm[QUOT_MAX_BATCH], pre[QUOT_MAX_BATCH];
-  for (int b = 0; b < a.nbatch; ++b) {
-    CM31 dx{m_sub(a.prx[b].a, x), a.prx[b].b};
-    CM31 dy{m_sub(a.pry[b].a, y), a.pry[b].b};
-    den[b] = c_sub(c_mul(dx, a.piy[b]), c_mul(dy, a.pix[b]));
-    nrm[b] = c_norm(den[b]);
+#pragma unroll
+  for (int b = 0; b < QUOT_MAX_BATCH; ++b) {
+    if (b < a.nbatch) {
+      CM31 dx{m_sub(a.prx[b].a, x), a.prx[b].b};
+      CM31 dy{m_sub(a.pry[b].a, y), a.pry[b].b};
+      den[b] = c_sub(c_mul(dx, a.piy[b]), c_mul(dy, a.pix[b]));
+      nrm[b] = c_norm(den[b]);
+    } else {
+      den[b] = CM31{1u, 0u};
+      nrm[b] = 1u;
+    }
     pre[b] = b == 0 ? nrm[b] : m_mul(pre[b - 1], nrm[b]);
   }
-  uint32_t inv = m_inv(pre[a.nbatch - 1]);
+  uint32_t inv = m_inv(pre[QUOT_MAX_BATCH - 1]);
   CM31 dinv[QUOT_MAX_BATCH];
-  for (int b = a.nbatch - 1; b >= 0; --b) {
+#pragma unroll
+  for (int b = QUOT_MAX_BATCH - 1; b >= 0; --b) {
     uint32_t ni = b == 0 ? inv : m_mul(inv, pre[b - 1]);
     inv = m_mul(inv, nrm[b]);
     dinv[b] = CM31{m_mul(den[b].a, ni), m_mul(m_neg(den[b].b), ni)};
   }
   QM31 row = q_zero();
-  for (int b = 0; b < a.nbatch; ++b) {
+#pragma unroll
+  for (int b = 0; b < QUOT_MAX_BATCH; ++b) {
+    if (b >= a.nbatch) break;
     QM31 num = q_zero();
-    for (int k = a.batch_start[b]; k < a.batch_start[b + 1]; ++k) {
-      uint32_t f = a.cols[a.col_idx[k]][s];
-      num = q_add(num, q_mul_m(a.coeff_c[k], f));
+    const int k1 = a.batch_start[b + 1];
+    int k = a.batch_start[b];
+    for (; k + 4 <= k1; k += 4) {
+      uint32_t f0 = tab[k].col[s], f1 = tab[k + 1].col[s], f2 = tab[k + 2].col[s], f3 = tab[k + 3].col[s];
+      num = q_add(num, q_mul_m(tab[k].c, f0));
+      num = q_add(num, q_mul_m(tab[k + 1].c, f1));
+      num = q_add(num, q_mul_m(tab[k + 2].c, f2));
+      num = q_add(num, q_mul_m(tab[k + 3].c, f3));
     }
+    for (; k < k1; ++k) num = q_add(num, q_mul_m(tab[k].c, tab[k].col[s]));
     num = q_sub(num, q_add(q_mul_m(a.A[b], y), a.B[b]));
     row = q_add(q_mul(row, a.batch_coeff[b]), q_mul_c(num, dinv[b]));
   }
@@ -687,6 +910,7 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
 
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
   if (a.nbatch < 1 || a.nbatch > QUOT_MAX_BATCH) throw LmnError(-100, "quotients: bad batch count");
+  if (a.batch_start[a.nbatch] > QUOT_MAX_ENTRIES) throw LmnError(-100, "quotients: too many column samples");
   LMN_LAUNCH(k_quotients, dim3(cdiv(1ull << a.log_size, TPB)), dim3(TPB), 0, s, a);
 }
 
@@ -694,10 +918,11 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
 // a9  FRI folds
 // =============================================================================================
 LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t src_len,
-                  const uint32_t* __restrict__ itw, QM31 alpha, QM31 alpha_sq, int accumulate) {
+                  const uint32_t* __restrict__ itw, const QM31* __restrict__ alpha_ptr, int accumulate) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = src_len >> 1;
   if (i >= n) return;
+  const QM31 alpha = *alpha_ptr;
   const uint64_t L = src_len;
   QM31 a{src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
   QM31 b{src[2 * i + 1], src[L + 2 * i + 1], src[2 * L + 2 * i + 1], src[3 * L + 2 * i + 1]};
@@ -706,7 +931,7 @@ LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, 
   QM31 r = q_add(f0, q_mul(alpha, f1));
   if (accumulate) {
     QM31 d{dst[i], dst[(uint64_t)n + i], dst[2ull * n + i], dst[3ull * n + i]};
-    r = q_add(q_mul(d, alpha_sq), r);
+    r = q_add(q_mul(d, q_mul(alpha, alpha)), r);
   }
   dst[i] = r.a;
   dst[(uint64_t)n + i] = r.b;
@@ -715,13 +940,12 @@ LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, 
 }
 
 void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
-                                  QM31 alpha, int accumulate, lmn_stream_t s) {
-  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_y, alpha,
-             q_mul(alpha, alpha), accumulate);
+                                  const QM31* alpha, int accumulate, lmn_stream_t s) {
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_y, alpha, accumulate);
 }
-void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, QM31 alpha,
+void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, const QM31* alpha,
                       lmn_stream_t s) {
-  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_x, alpha, q_one(), 0);
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_x, alpha, 0);
 }
 
 }  // namespace lmn

@@ -57,6 +57,12 @@ inline void lmn_d2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
 }
 inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) { LMN_HIP_CHECK(hipMemsetAsync(dst, v, n, s)); }
 inline void lmn_sync(lmn_stream_t s) { LMN_HIP_CHECK(hipStreamSynchronize(s)); }
+inline void* lmn_host_alloc_pinned(size_t bytes) {
+  void* p = nullptr;
+  LMN_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  return p;
+}
+inline void lmn_host_free_pinned(void* p) { (void)hipHostFree(p); }
 typedef hipEvent_t lmn_event_t;
 inline lmn_event_t lmn_event_create() {
   hipEvent_t e;
@@ -95,6 +101,10 @@ void lmn_emu_syncthreads();
 #define __syncthreads() lmn_emu_syncthreads()
 #define LMN_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(lmn_emu_dyn_smem)
 typedef int lmn_stream_t;
+struct uint4 {
+  unsigned x, y, z, w;
+};
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline unsigned __brev(unsigned x) {
   unsigned r = 0;
   for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
@@ -121,6 +131,8 @@ inline void lmn_d2h(void* d, const void* s, size_t n, lmn_stream_t) { memcpy(d, 
 inline void lmn_d2d(void* d, const void* s, size_t n, lmn_stream_t) { memmove(d, s, n); }
 inline void lmn_memset(void* d, int v, size_t n, lmn_stream_t) { memset(d, v, n); }
 inline void lmn_sync(lmn_stream_t) {}
+inline void* lmn_host_alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
+inline void lmn_host_free_pinned(void* p) { free(p); }
 #include <chrono>
 typedef double* lmn_event_t;
 inline lmn_event_t lmn_event_create() { return new double(0.0); }

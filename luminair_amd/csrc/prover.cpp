@@ -119,6 +119,8 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
 #else
   stream_ = 0;
 #endif
+  pin_cap_ = 32u << 20;
+  pin_base_ = (char*)lmn_host_alloc_pinned(pin_cap_);
   if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
   if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
   if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
@@ -139,9 +141,34 @@ Context::~Context() {
     m.erase(it);
   }
   for (void* p : tw_allocs_) lmn_dev_free(p);
+  if (pin_base_) lmn_host_free_pinned(pin_base_);
 #ifndef LMN_EMU
   (void)hipStreamDestroy(stream_);
 #endif
+}
+
+void* Context::pin_alloc(size_t bytes) {
+  size_t a = (pin_off_ + 63) & ~(size_t)63;
+  if (a + bytes > pin_cap_) throw LmnError(LMN_ERR_OUT_OF_MEMORY, "pinned staging buffer exhausted");
+  pin_off_ = a + bytes;
+  return pin_base_ + a;
+}
+void* Context::stage_upload(const void* host, size_t bytes) {
+  void* d = arena_.alloc_bytes(bytes ? bytes : 4);
+  if (bytes == 0) return d;
+  void* p = pin_alloc(bytes);
+  memcpy(p, host, bytes);
+  lmn_h2d(d, p, bytes, stream_);
+  return d;
+}
+const void* Context::stage_download(const void* dev, size_t bytes) {
+  void* p = pin_alloc(bytes ? bytes : 4);
+  if (bytes) lmn_d2h(p, dev, bytes, stream_);
+  return p;
+}
+void Context::fetch_root_async(DevMerkle& m) {
+  if (m.layers.empty() || !m.layers[0]) return;
+  m.root_pinned = (const uint32_t*)stage_download(m.layers[0], 32);
 }
 
 void* Context::upload(const void* host, size_t bytes) {
@@ -247,7 +274,9 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
   timings.merkle_bytes += (uint64_t)size * (4ull * ncols + 32ull + (prev ? 64ull : 0ull));
 }
 
-// Merkle tree over columns sorted by size (descending, stable): SURVEY.md Appendix A.4
+// Merkle tree over columns sorted by size (descending, stable): SURVEY.md Appendix A.4.
+// Levels are produced by fused subtree launches: a start level (children hashes and/or its own
+// columns) plus up to 8 following levels that have no columns of their own.
 void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted) {
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].second;
   m.layers.assign(m.max_log + 1, nullptr);
@@ -255,26 +284,63 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
     m.root = b2_hash_words(nullptr, 0);
     return;
   }
-  // one device pointer table for all columns
-  std::vector<const uint32_t*> ptrs(cols_sorted.size());
-  for (size_t i = 0; i < cols_sorted.size(); ++i) ptrs[i] = cols_sorted[i].first;
-  const uint32_t** dptrs = (const uint32_t**)arena_.alloc_bytes(ptrs.size() * sizeof(void*));
-  lmn_h2d((void*)dptrs, ptrs.data(), ptrs.size() * sizeof(void*), stream_);
-  lmn_sync(stream_);  // ptrs is a stack vector
-  size_t pos = 0;
-  const uint32_t* prev = nullptr;
-  StageTimer t(this, g_log(this), stream_, C_MERKLE);
-  for (int log = m.max_log; log >= 0; --log) {
-    size_t start = pos;
-    while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
-    uint32_t size = 1u << log;
-    uint32_t* out = arena_.alloc_words((size_t)size * 8);
-    merkle_layer_timed(prev, dptrs + start, (int)(pos - start), size, out);
-    m.layers[log] = out;
-    prev = out;
+  for (int log = m.max_log; log >= 0; --log) m.layers[log] = arena_.alloc_words((size_t)8 << log);
+  // columns per level
+  std::vector<std::vector<const uint32_t*>> per_level(m.max_log + 1);
+  for (auto& c : cols_sorted) per_level[c.second].push_back(c.first);
+  {
+    StageTimer t(this, g_log(this), stream_, C_MERKLE);
+    const uint32_t* prev = nullptr;
+    int level = m.max_log;
+    while (level >= 0) {
+      auto& lc = per_level[level];
+      // runs of contiguous equal-size columns
+      MerkleSegs sg{};
+      int nseg = 0;
+      bool seg_ok = true;
+      for (size_t k = 0; k < lc.size(); ++k) {
+        if (nseg > 0 && lc[k] == sg.base[nseg - 1] + ((uint64_t)sg.n[nseg - 1] << level)) {
+          sg.n[nseg - 1]++;
+        } else if (nseg < MERKLE_MAX_SEG) {
+          sg.base[nseg] = lc[k];
+          sg.n[nseg] = 1;
+          ++nseg;
+        } else {
+          seg_ok = false;
+          break;
+        }
+      }
+      if (!seg_ok) {
+        // rare scattered level: pointer-table kernel, one level per launch
+        const uint32_t** dptrs = (const uint32_t**)stage_upload(lc.data(), lc.size() * sizeof(void*));
+        merkle_layer_timed(prev, dptrs, (int)lc.size(), 1u << level, m.layers[level]);
+        prev = m.layers[level];
+        level -= 1;
+        continue;
+      }
+      int plain = 0;
+      while (level - plain - 1 >= 0 && per_level[level - plain - 1].empty()) ++plain;
+      MerkleLevels outs{};
+      int nfused;
+      if (level <= 10) {
+        nfused = std::min(plain, 10);
+        for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
+        launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, stream_);
+      } else {
+        nfused = std::min(std::min(plain, MERKLE_MAX_FUSED), level - 10);
+        // per-lane subtree depth: only as deep as still leaves >= 2^17 lanes (latency-bound below that)
+        int sub = std::max(0, std::min(std::min(MERKLE_MAX_SUB, nfused), level - 17));
+        nfused = std::min(nfused, sub + 8);
+        for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
+        launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_);
+      }
+      timings.merkle_launches++;
+      timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
+      for (int l = 1; l <= nfused; ++l) timings.merkle_bytes += ((uint64_t)1 << (level - l)) * 96ull;
+      prev = m.layers[level - nfused];
+      level -= nfused + 1;
+    }
   }
-  lmn_d2h(m.root.w, m.layers[0], 32, stream_);
-  lmn_sync(stream_);
 }
 
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches)
@@ -302,6 +368,7 @@ void Context::lde_and_merkle(DevTree& tree) {
   for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb});
   std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
   build_merkle(tree.merkle, sorted);
+  fetch_root_async(tree.merkle);
 }
 
 // ------------------------------------------------------------------------------------ host-side AIR at a point
@@ -412,16 +479,12 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
       for (uint32_t j = 0; j < (1u << k); ++j) H[j + (1u << k)] = q_mul(H[j], maps[EVAL_LB + k]);
   }
   int max_chunks = eval_num_chunks(max_log);
-  EvalJob* d_jobs = (EvalJob*)arena_.alloc_bytes(jobs.size() * sizeof(EvalJob));
-  QM31* d_lo = (QM31*)arena_.alloc_bytes(lo_tab.size() * sizeof(QM31));
-  QM31* d_hi = (QM31*)arena_.alloc_bytes(hi_tab.size() * sizeof(QM31));
+  EvalJob* d_jobs = upload_vec(jobs);
+  QM31* d_lo = upload_vec(lo_tab);
+  QM31* d_hi = upload_vec(hi_tab);
   QM31* d_out = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));
-  lmn_h2d(d_jobs, jobs.data(), jobs.size() * sizeof(EvalJob), stream_);
-  lmn_h2d(d_lo, lo_tab.data(), lo_tab.size() * sizeof(QM31), stream_);
-  lmn_h2d(d_hi, hi_tab.data(), hi_tab.size() * sizeof(QM31), stream_);
   launch_eval_at_point(d_jobs, (int)jobs.size(), d_lo, d_hi, hi_n, max_log, d_out, max_chunks, stream_);
-  std::vector<QM31> partial(jobs.size() * (size_t)max_chunks);
-  lmn_d2h(partial.data(), d_out, partial.size() * sizeof(QM31), stream_);
+  const QM31* partial = (const QM31*)stage_download(d_out, jobs.size() * (size_t)max_chunks * sizeof(QM31));
   lmn_sync(stream_);
   std::vector<QM31> res(jobs.size());
   for (size_t j = 0; j < jobs.size(); ++j) {
@@ -564,6 +627,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   ensure_twiddles(max_lde);
   arena_.reserve(words * 4);
   arena_.reset();
+  pin_off_ = 0;
 
   Channel channel(cfg.protocol_variant);
   Proof proof;
@@ -624,6 +688,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
     lde_and_merkle(tree1);
+    lmn_sync(stream_);
+    tree1.merkle.finish_root();
     channel.mix_root(tree1.merkle.root);
   }
 
@@ -671,22 +737,25 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       }
       for (int c = 0; c < nic; ++c) tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, nullptr});
     }
-    // claimed sums back to the host for the transcript
-    std::vector<QM31> cs(2 * inst.size());
-    for (size_t i = 0; i < inst.size(); ++i) lmn_d2h(&cs[2 * i], inst[i].d_claimed_shift, 2 * sizeof(QM31), stream_);
+  }
+  {
+    // commit the interaction tree first (it does not depend on the transcript), then fetch the
+    // claimed sums and the root with a single synchronisation
+    StageTimer st(this, log, stream_, C_INTER_COMMIT);
+    lde_and_merkle(tree2);
+    std::vector<const QM31*> cs(inst.size());
+    for (size_t i = 0; i < inst.size(); ++i)
+      cs[i] = (const QM31*)stage_download(inst[i].d_claimed_shift, 2 * sizeof(QM31));
     lmn_sync(stream_);
+    tree2.merkle.finish_root();
     for (size_t i = 0; i < inst.size(); ++i) {
-      inst[i].claimed = cs[2 * i];
-      proof.interaction_claim[inst[i].spec->kind] = {true, cs[2 * i]};
+      inst[i].claimed = cs[i][0];
+      proof.interaction_claim[inst[i].spec->kind] = {true, cs[i][0]};
     }
   }
   for (int k = 0; k < n_slots; ++k)
     if (proof.interaction_claim[k].first) channel.mix_felts({proof.interaction_claim[k].second});
-  {
-    StageTimer st(this, log, stream_, C_INTER_COMMIT);
-    lde_and_merkle(tree2);
-    channel.mix_root(tree2.merkle.root);
-  }
+  channel.mix_root(tree2.merkle.root);
 
   // ---- stwo::prover::prove (prover.rs:312): composition polynomial
   const QM31 comp_alpha = channel.draw_felt();
@@ -755,6 +824,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   {
     StageTimer st(this, log, stream_, C_COMP_COMMIT);
     lde_and_merkle(tree3);
+    lmn_sync(stream_);
+    tree3.merkle.finish_root();
     channel.mix_root(tree3.merkle.root);
   }
   DevTree* trees[4] = {&tree0, &tree1, &tree2, &tree3};
@@ -883,18 +954,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         a.piy[b] = {pt.y.c, pt.y.d};
       }
       a.batch_start[batch_point.size()] = (int)col_idx.size();
-      std::vector<const uint32_t*> ptrs;
-      for (auto* f : cols) ptrs.push_back(f->lde);
-      const uint32_t** d_ptrs = (const uint32_t**)arena_.alloc_bytes(ptrs.size() * sizeof(void*));
-      int* d_idx = (int*)arena_.alloc_bytes(col_idx.size() * sizeof(int));
-      QM31* d_c = (QM31*)arena_.alloc_bytes(coeff_c.size() * sizeof(QM31));
-      lmn_h2d((void*)d_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), stream_);
-      lmn_h2d(d_idx, col_idx.data(), col_idx.size() * sizeof(int), stream_);
-      lmn_h2d(d_c, coeff_c.data(), coeff_c.size() * sizeof(QM31), stream_);
-      lmn_sync(stream_);
-      a.cols = d_ptrs;
-      a.col_idx = d_idx;
-      a.coeff_c = d_c;
+      if (col_idx.size() > (size_t)QUOT_MAX_ENTRIES) throw LmnError(LMN_ERR_INTERNAL, "too many column samples");
+      std::vector<QuotEntry> entries(col_idx.size());
+      for (size_t k = 0; k < col_idx.size(); ++k) entries[k] = {cols[col_idx[k]]->lde, coeff_c[k]};
+      a.entries = upload_vec(entries);
       a.tw_y = twY_[ls];
       a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
       a.out = arena_.alloc_words(4ull << ls);
@@ -918,15 +981,26 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     StageTimer st(this, log, stream_, C_FRI);
     for (auto& q : quots)
       for (int k = 0; k < 4; ++k) first_cols.push_back({q.vals + ((uint64_t)k << q.log), q.log});
-    build_merkle(first_merkle, first_cols);
-    channel.mix_root(first_merkle.root);
-    QM31 alpha = channel.draw_felt();
+    // The FRI commit loop runs without host round trips: a device-resident copy of the channel
+    // mixes each layer root and draws the folding alpha; the host replays the same steps afterwards.
     int ls0 = quots[0].log;
+    const int last_size_log = (int)cfg.log_last_layer + lb;
+    const int max_layers = ls0 + 1;
+    DevChannel hc{};
+    memcpy(hc.digest, channel.digest().w, 32);
+    hc.n_sent = 0;
+    hc.variant = cfg.protocol_variant;
+    DevChannel* d_ch = (DevChannel*)stage_upload(&hc, sizeof hc);
+    QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
+    uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);
+    int n_roots = 0;
+    build_merkle(first_merkle, first_cols);
+    launch_chan_mix_root_draw(d_ch, first_merkle.layers[0], d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+    ++n_roots;
     int layer_log = ls0 - 1;
     uint32_t* layer = arena_.alloc_words(4ull << layer_log);
-    launch_fold_circle_into_line(layer, quots[0].vals, 1u << ls0, itwY_[ls0], alpha, 0, stream_);
+    launch_fold_circle_into_line(layer, quots[0].vals, 1u << ls0, itwY_[ls0], d_alphas + (n_roots - 1), 0, stream_);
     size_t qi = 1;
-    const int last_size_log = (int)cfg.log_last_layer + lb;
     while (layer_log > last_size_log) {
       FriLayer fl;
       fl.log = layer_log;
@@ -934,27 +1008,43 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       std::vector<std::pair<const uint32_t*, int>> lc;
       for (int k = 0; k < 4; ++k) lc.push_back({layer + ((uint64_t)k << layer_log), layer_log});
       build_merkle(fl.merkle, lc);
-      channel.mix_root(fl.merkle.root);
-      alpha = channel.draw_felt();
+      launch_chan_mix_root_draw(d_ch, fl.merkle.layers[0], d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+      ++n_roots;
+      const QM31* d_alpha = d_alphas + (n_roots - 1);
       uint32_t* next = arena_.alloc_words(4ull << (layer_log - 1));
       // line domain of log L has the x-coordinates of CanonicCoset(L+1)'s half coset
-      launch_fold_line(next, layer, 1u << layer_log, itwX_[layer_log + 1], alpha, stream_);
+      launch_fold_line(next, layer, 1u << layer_log, itwX_[layer_log + 1], d_alpha, stream_);
       inner.push_back(fl);
       layer = next;
       layer_log -= 1;
       while (qi < quots.size() && quots[qi].log - 1 == layer_log) {
-        launch_fold_circle_into_line(layer, quots[qi].vals, 1u << quots[qi].log, itwY_[quots[qi].log], alpha, 1,
+        launch_fold_circle_into_line(layer, quots[qi].vals, 1u << quots[qi].log, itwY_[quots[qi].log], d_alpha, 1,
                                      stream_);
         ++qi;
       }
     }
+    // one sync: roots + alphas back, then replay the transcript on the host channel
+    const uint32_t* h_roots = (const uint32_t*)stage_download(d_roots, (size_t)n_roots * 32);
+    const QM31* h_alphas = (const QM31*)stage_download(d_alphas, (size_t)n_roots * sizeof(QM31));
     if (qi != quots.size()) throw LmnError(LMN_ERR_INTERNAL, "FRI: unconsumed columns");
     last_log = layer_log;
-    std::vector<uint32_t> raw(4ull << last_log);
-    lmn_d2h(raw.data(), layer, raw.size() * 4, stream_);
+    const uint32_t* raw = (const uint32_t*)stage_download(layer, (size_t)16 << last_log);
     lmn_sync(stream_);
-    uint32_t n = 1u << last_log;
-    for (uint32_t i = 0; i < n; ++i) last_vals.push_back({raw[i], raw[n + i], raw[2 * n + i], raw[3 * n + i]});
+    {
+      uint32_t n = 1u << last_log;
+      for (uint32_t i = 0; i < n; ++i) last_vals.push_back({raw[i], raw[n + i], raw[2 * n + i], raw[3 * n + i]});
+    }
+    for (int r = 0; r < n_roots; ++r) {
+      Hash32 root;
+      memcpy(root.w, &h_roots[(size_t)r * 8], 32);
+      if (r == 0)
+        first_merkle.root = root;
+      else
+        inner[r - 1].merkle.root = root;
+      channel.mix_root(root);
+      QM31 a = channel.draw_felt();
+      if (!q_eq(a, h_alphas[r])) throw LmnError(LMN_ERR_INTERNAL, "device/host transcript divergence in FRI");
+    }
   }
   // last layer: interpolate the line evaluation (bit-reversed over LineDomain(half_odds(last_log)))
   {
@@ -1072,13 +1162,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       add_refs(p.hash_wit);
       add_refs(p.col_wit);
     }
-    std::vector<uint32_t> gathered(out_words);
+    const uint32_t* gathered = nullptr;
     if (!entries.empty()) {
-      GatherEntry* d_e = (GatherEntry*)arena_.alloc_bytes(entries.size() * sizeof(GatherEntry));
+      GatherEntry* d_e = upload_vec(entries);
       uint32_t* d_o = arena_.alloc_words(out_words);
-      lmn_h2d(d_e, entries.data(), entries.size() * sizeof(GatherEntry), stream_);
       launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
-      lmn_d2h(gathered.data(), d_o, (size_t)out_words * 4, stream_);
+      gathered = (const uint32_t*)stage_download(d_o, (size_t)out_words * 4);
       lmn_sync(stream_);
     }
     size_t g = 0;
@@ -1091,7 +1180,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       return v;
     };
     auto take_u32 = [&](size_t n) {
-      std::vector<uint32_t> v(gathered.begin() + g, gathered.begin() + g + n);
+      std::vector<uint32_t> v(gathered + g, gathered + g + n);
       g += n;
       return v;
     };
@@ -1195,6 +1284,9 @@ void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_si
   g_log(this)->reset();
   DevMerkle m;
   build_merkle(m, sorted);
+  fetch_root_async(m);
+  lmn_sync(stream_);
+  m.finish_root();
   memcpy(root, m.root.w, 32);
 }
 

@@ -49,6 +49,11 @@ struct DevMerkle {
   int max_log = -1;
   std::vector<uint32_t*> layers;  // layers[k]: 2^k hashes of 8 words
   Hash32 root;
+  const uint32_t* root_pinned = nullptr;  // pending async download of layers[0]
+  void finish_root() {
+    if (root_pinned) memcpy(root.w, root_pinned, 32);
+    root_pinned = nullptr;
+  }
 };
 
 struct DevTree {
@@ -87,6 +92,18 @@ class Context {
   void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
+
+  // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
+  void* pin_alloc(size_t bytes);
+  void* stage_upload(const void* host, size_t bytes);           // -> device pointer (arena), async
+  const void* stage_download(const void* dev, size_t bytes);    // -> pinned host pointer, valid after sync
+  template <class T>
+  T* upload_vec(const std::vector<T>& v) {
+    return (T*)stage_upload(v.data(), v.size() * sizeof(T));
+  }
+  void fetch_root_async(DevMerkle& m);   // m.root_pinned valid after the next sync
+  char* pin_base_ = nullptr;
+  size_t pin_cap_ = 0, pin_off_ = 0;
 
   int device_;
   lmn_stream_t stream_{};
