@@ -62,6 +62,17 @@ struct DevChannel {
 void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
                                lmn_stream_t s);
 
+// FRI tail: layers of log size first_log, first_log-1, ... (n_layers of them, all <= 2^10) committed
+// and folded in one single-block launch.  layers[li].next is the evaluation buffer of the next layer.
+struct FriTailLayer {
+  const uint32_t* vals;        // 4 x 2^L line evaluation (coordinate-major)
+  uint32_t* next;              // 4 x 2^(L-1): fold output
+  const uint32_t* itw;         // 1/x twiddles of the line domain of log size L
+  uint32_t* merkle[11];        // merkle[l]: 2^l hashes, l = 0..L
+};
+void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
+                     uint32_t* roots_out, lmn_stream_t s);
+
 // ---- gather: out[dst_off[e] + k] = arena[src_off[e] + k], k < len[e]
 struct GatherEntry {
   uint64_t src_off;  // word offset into arena

@@ -453,6 +453,109 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 }
 
 // =============================================================================================
+// FRI tail: all layers of size <= 1024 in ONE single-block launch: per layer Merkle-commit the
+// line evaluation (LDS tree), mix the root into the device-resident channel, draw the folding
+// alpha, fold.  Every layer's evaluations and tree levels still go to HBM for decommitment.
+// =============================================================================================
+LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, int n_layers, int first_log,
+                      QM31* alphas_out, uint32_t* roots_out) {
+  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  LMN_SHARED QM31 s_alpha;
+  const uint32_t i = threadIdx.x;
+  for (int li = 0; li < n_layers; ++li) {
+    const FriTailLayer ly = layers[li];
+    const int L = first_log - li;
+    const uint32_t size = 1u << L;
+    uint32_t cur[8];
+    if (i < size) {
+      uint32_t m[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = 0u;
+      m[0] = ly.vals[i];
+      m[1] = ly.vals[size + i];
+      m[2] = ly.vals[2 * size + i];
+      m[3] = ly.vals[3 * size + i];
+      b2_init(cur);
+      b2_compress(cur, m, 16u, 0xffffffffu);
+      store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+    }
+    uint32_t lvl_size = size;
+    for (int l = L - 1; l >= 0; --l) {
+      __syncthreads();
+      lvl_size >>= 1;
+      const bool on = i < lvl_size;
+      if (on) {
+        uint32_t m[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k] = sh[i * 16 + k];
+        b2_init(cur);
+        b2_compress(cur, m, 64u, 0xffffffffu);
+        store_hash(ly.merkle[l] + (uint64_t)i * 8, cur);
+      }
+      __syncthreads();
+      if (on) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+      }
+    }
+    __syncthreads();
+    if (i == 0) {
+      // channel: digest <- H(digest || root); alpha <- draw_felt()
+      uint32_t m[16], h[8];
+      for (int k = 0; k < 8; ++k) {
+        m[k] = ch->digest[k];
+        m[8 + k] = sh[k];
+        roots_out[li * 8 + k] = sh[k];
+      }
+      b2_init(h);
+      b2_compress(h, m, 64u, 0xffffffffu);
+      for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
+      ch->n_sent = 0u;
+      for (;;) {
+        uint32_t w[8];
+        chan_draw_words(ch, w);
+        bool ok = true;
+        for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
+        if (!ok) continue;
+        QM31 a;
+        a.a = w[0] >= P31 ? w[0] - P31 : w[0];
+        a.b = w[1] >= P31 ? w[1] - P31 : w[1];
+        a.c = w[2] >= P31 ? w[2] - P31 : w[2];
+        a.d = w[3] >= P31 ? w[3] - P31 : w[3];
+        s_alpha = a;
+        alphas_out[li] = a;
+        break;
+      }
+    }
+    __syncthreads();
+    const QM31 alpha = s_alpha;
+    const uint32_t n = size >> 1;
+    if (i < n) {
+      QM31 a{ly.vals[2 * i], ly.vals[size + 2 * i], ly.vals[2 * size + 2 * i], ly.vals[3 * size + 2 * i]};
+      QM31 b{ly.vals[2 * i + 1], ly.vals[size + 2 * i + 1], ly.vals[2 * size + 2 * i + 1],
+             ly.vals[3 * size + 2 * i + 1]};
+      QM31 f0 = q_add(a, b);
+      QM31 f1 = q_mul_m(q_sub(a, b), ly.itw[i]);
+      QM31 r = q_add(f0, q_mul(alpha, f1));
+      ly.next[i] = r.a;
+      ly.next[n + i] = r.b;
+      ly.next[2 * n + i] = r.c;
+      ly.next[3 * n + i] = r.d;
+    }
+    __syncthreads();
+  }
+}
+
+void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
+                     uint32_t* roots_out, lmn_stream_t s) {
+  if (first_log > 10 || n_layers < 1 || n_layers > first_log) throw LmnError(-100, "fri_tail: bad arguments");
+  LMN_LAUNCH(k_fri_tail, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, ch, layers, n_layers, first_log, alphas_out,
+             roots_out);
+}
+
+// =============================================================================================
 // gather
 // =============================================================================================
 LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,

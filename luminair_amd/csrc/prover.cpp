@@ -330,6 +330,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
         nfused = std::min(std::min(plain, MERKLE_MAX_FUSED), level - 10);
         // per-lane subtree depth: only as deep as still leaves >= 2^17 lanes (latency-bound below that)
         int sub = std::max(0, std::min(std::min(MERKLE_MAX_SUB, nfused), level - 17));
+        if (const char* e = getenv("LMN_MERKLE_SUB")) sub = std::min(std::min(atoi(e), nfused), MERKLE_MAX_SUB);
         nfused = std::min(nfused, sub + 8);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_);
@@ -1002,6 +1003,35 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     launch_fold_circle_into_line(layer, quots[0].vals, 1u << ls0, itwY_[ls0], d_alphas + (n_roots - 1), 0, stream_);
     size_t qi = 1;
     while (layer_log > last_size_log) {
+      if (layer_log <= 10 && qi == quots.size()) {
+        // all remaining layers fit one block: commit + fold them in a single launch
+        int n_tail = layer_log - last_size_log;
+        std::vector<FriTailLayer> tl(n_tail);
+        for (int li = 0; li < n_tail; ++li) {
+          int L = layer_log - li;
+          FriLayer fl;
+          fl.log = L;
+          fl.vals = layer;
+          fl.merkle.max_log = L;
+          fl.merkle.layers.assign(L + 1, nullptr);
+          for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
+          uint32_t* next = arena_.alloc_words(4ull << (L - 1));
+          tl[li].vals = layer;
+          tl[li].next = next;
+          tl[li].itw = itwX_[L + 1];
+          for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
+          inner.push_back(fl);
+          layer = next;
+        }
+        FriTailLayer* d_tl = upload_vec(tl);
+        {
+          StageTimer t(this, log, stream_, C_MERKLE);
+          launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+        }
+        n_roots += n_tail;
+        layer_log = last_size_log;
+        break;
+      }
       FriLayer fl;
       fl.log = layer_log;
       fl.vals = layer;
