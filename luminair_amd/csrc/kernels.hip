@@ -3,6 +3,8 @@
 // trace data).  See DESIGN.md for the per-kernel roofline notes.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace lmn {
 
 constexpr int TPB = 256;
@@ -101,6 +103,139 @@ LMN_KERNEL k_fft_pass(uint32_t* data, uint64_t col_stride, const uint32_t* src,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staged variant: each lane keeps 2^R points (R <= 4) in registers and runs R butterfly layers
+// on them before exchanging through LDS, so a 12-layer tile needs 2 LDS exchanges instead of 12
+// and the per-layer index arithmetic disappears.  Tile geometry as in k_fft_pass.
+// ---------------------------------------------------------------------------------------------
+constexpr int FFT_MAX_STAGES = 4;
+struct FftStagePlan {
+  int lo, hi, cb;
+  int nst;
+  int first[FFT_MAX_STAGES];  // first layer of each stage, ascending
+  int R[FFT_MAX_STAGES];      // layers per stage (1..4)
+};
+
+LMN_HD uint32_t fft_lds_pad(uint32_t e) { return e + (e >> 5); }
+
+template <int R, bool INV>
+LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_layer, int hi, uint32_t H,
+                             uint32_t mhigh) {
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int r = INV ? rr : R - 1 - rr;
+    const int L = first_layer + r;
+    const uint32_t* __restrict__ t = tw.l[L];
+    const uint32_t hb = (H << (hi - L - 1)) + (mhigh << (R - 1 - r));
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      if (j & (1 << r)) continue;
+      const uint32_t w = t[hb + (uint32_t)(j >> (r + 1))];
+      const uint32_t a = v[j], b = v[j | (1 << r)];
+      if (INV) {
+        v[j] = m_add(a, b);
+        v[j | (1 << r)] = m_mul(m_sub(a, b), w);
+      } else {
+        const uint32_t x = m_mul(b, w);
+        v[j] = m_add(a, x);
+        v[j | (1 << r)] = m_sub(a, x);
+      }
+    }
+  }
+}
+
+template <int R, bool INV>
+LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t src_len, uint64_t base, int lo,
+                     int hi, int cb, int first_layer, uint32_t H, bool from_global, bool to_global, const TwPtrs& tw,
+                     uint32_t scale) {
+  const int p = first_layer - lo + cb;           // bit position of the stage's first layer in the tile index
+  const uint32_t tile_elems = 1u << (hi - lo + cb);
+  const uint32_t ngroups = tile_elems >> R;
+  const uint32_t cmask = (1u << cb) - 1u;
+  for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    const uint32_t e0 = ((g >> p) << (p + R)) | (g & ((1u << p) - 1u));
+    uint32_t v[1 << R];
+    if (from_global) {
+      if (p == 0 && cb == 0 && R >= 2) {
+        const uint64_t gi = base + e0;
+        if (gi < src_len) {
+          const uint4* q = reinterpret_cast<const uint4*>(scol + gi);
+#pragma unroll
+          for (int k = 0; k < (1 << R) / 4; ++k) {
+            uint4 x = q[k];
+            v[4 * k] = x.x;
+            v[4 * k + 1] = x.y;
+            v[4 * k + 2] = x.z;
+            v[4 * k + 3] = x.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < (1 << R); ++j) v[j] = 0u;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) {
+          const uint32_t e = e0 + ((uint32_t)j << p);
+          const uint64_t gi = base + ((uint64_t)(e >> cb) << lo) + (e & cmask);
+          v[j] = gi < src_len ? scol[gi] : 0u;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) v[j] = sm[fft_lds_pad(e0 + ((uint32_t)j << p))];
+    }
+    const uint32_t m0 = e0 >> cb;
+    radix_butterflies<R, INV>(v, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
+    if (to_global) {
+      if (INV && scale != 1u) {
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) v[j] = m_mul(v[j], scale);
+      }
+      if (p == 0 && cb == 0 && R >= 2) {
+        uint4* q = reinterpret_cast<uint4*>(col + base + e0);
+#pragma unroll
+        for (int k = 0; k < (1 << R) / 4; ++k) q[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) {
+          const uint32_t e = e0 + ((uint32_t)j << p);
+          col[base + ((uint64_t)(e >> cb) << lo) + (e & cmask)] = v[j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) sm[fft_lds_pad(e0 + ((uint32_t)j << p))] = v[j];
+    }
+  }
+}
+
+template <bool INV>
+LMN_KERNEL k_fft_staged(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride,
+                        uint64_t src_len, FftStagePlan pl, TwPtrs tw, uint32_t scale, int ncols, int cpb) {
+  LMN_DYN_SMEM(uint32_t, sm);
+  const uint32_t tile = blockIdx.x;
+  const uint32_t q = tile & ((1u << (pl.lo - pl.cb)) - 1u);
+  const uint32_t H = tile >> (pl.lo - pl.cb);
+  const uint64_t base = ((uint64_t)H << pl.hi) + ((uint64_t)q << pl.cb);
+  for (int cc = 0; cc < cpb; ++cc) {
+    const int c = blockIdx.y * cpb + cc;
+    if (c >= ncols) break;
+    uint32_t* col = data + (uint64_t)c * col_stride;
+    const uint32_t* scol = src + (uint64_t)c * src_stride;
+    for (int k = 0; k < pl.nst; ++k) {
+      const int s = INV ? k : pl.nst - 1 - k;
+      const bool fg = k == 0, tg = k == pl.nst - 1;
+      switch (pl.R[s]) {
+        case 1: fft_stage<1, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
+        case 2: fft_stage<2, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
+        case 3: fft_stage<3, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
+        default: fft_stage<4, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 struct FftPass {
   int lo, hi, cb;
 };
@@ -130,24 +265,55 @@ static uint32_t inv_pow2(int log_n) {
   return 1u << e;
 }
 
+static void split_stages(FftStagePlan& pl) {
+  int rbits = pl.hi - pl.lo;
+  int nst = (rbits + 3) / 4;
+  pl.nst = nst;
+  int f = pl.lo;
+  for (int k = 0; k < nst; ++k) {
+    int r = (rbits - (f - pl.lo) + (nst - k) - 1) / (nst - k);  // balanced split, each <= 4
+    pl.first[k] = f;
+    pl.R[k] = r;
+    f += r;
+  }
+}
+
 template <bool INV>
 static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int log_src,
                     int ncols, int log_n, const TwPtrs& tw, lmn_stream_t s) {
   if (log_n < 1) throw LmnError(-100, "fft: log_n < 1");
+  static const bool use_v1 = getenv("LMN_FFT_V1") != nullptr;
   FftPass passes[8];
   int np = plan_passes(log_n, passes);
   for (int k = 0; k < np; ++k) {
     const FftPass& p = INV ? passes[k] : passes[np - 1 - k];
     int rbits = p.hi - p.lo;
     unsigned tiles = 1u << (log_n - rbits - p.cb);
-    size_t smem = (size_t)4 << (rbits + p.cb);
     bool last = INV && k == np - 1;
     uint32_t scale = last ? inv_pow2(log_n) : 1u;
     const uint32_t* psrc = k == 0 ? src : data;
     uint64_t pstride = k == 0 ? src_stride : col_stride;
     uint64_t plen = k == 0 ? (1ull << log_src) : (1ull << log_n);
-    LMN_LAUNCH(k_fft_pass<INV>, dim3(tiles, ncols), dim3(TPB), smem, s, data, col_stride, psrc, pstride, plen, p.lo,
-               p.hi, p.cb, tw, scale);
+    if (use_v1) {
+      size_t smem = (size_t)4 << (rbits + p.cb);
+      LMN_LAUNCH(k_fft_pass<INV>, dim3(tiles, ncols), dim3(TPB), smem, s, data, col_stride, psrc, pstride, plen,
+                 p.lo, p.hi, p.cb, tw, scale);
+      continue;
+    }
+    FftStagePlan pl{};
+    pl.lo = p.lo;
+    pl.hi = p.hi;
+    pl.cb = p.cb;
+    split_stages(pl);
+    uint32_t tile_elems = 1u << (rbits + p.cb);
+    size_t smem = (size_t)4 * (tile_elems + (tile_elems >> 5) + 1);
+    // several columns per block when there are plenty of tiles: twiddles stay hot in L1/L2
+    int cpb = tiles >= 2048 ? 3 : (tiles >= 512 ? 2 : 1);
+    if (cpb > ncols) cpb = ncols;
+    unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
+    int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
+    LMN_LAUNCH(k_fft_staged<INV>, dim3(tiles, gy), dim3(threads), smem, s, data, col_stride, psrc, pstride, plen, pl,
+               tw, scale, ncols, cpb);
   }
   return np;
 }
