@@ -499,41 +499,56 @@ LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, i
 
 LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
                           MerkleLevels outs, int sub, int nfused) {
-  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 8 * TPB];  // [level][word][thread]
+  // Wave-cooperative subtree: in batch j lane l hashes start node W0 + 64*j + l (coalesced column
+  // loads and hash stores).  Siblings sit in neighbouring lanes, so after every second batch the
+  // lanes swap one hash with lane^1 and ALL 64 lanes compress one level-1 parent (even lanes for the
+  // older batch, odd lanes for the newer one); after every fourth batch the same with lane^2, etc.
+  // Each lane keeps its pending hash per level in private LDS slots (word 8 = node index).
+  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 9 * TPB];  // [level][word][thread]
   LMN_SHARED uint32_t sh[TPB * 8];
   const uint32_t per = 1u << sub;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // subtree index
-  const uint32_t nsub = size >> sub;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t W0 = (t >> 6) * (64u << sub);
   uint32_t cur[8];
-  if (t < nsub) {
-    for (uint32_t j = 0; j < per; ++j) {
-      const uint32_t node = t * per + j;
-      merkle_hash_start(prev, sg, ncols, size, node, cur);
-      store_hash(outs.p[0] + (uint64_t)node * 8, cur);
-      uint32_t jj = j;
-      int lvl = 0;
-      while (jj & 1u) {
-        uint32_t m[16];
+  uint32_t cur_idx = 0;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t node = W0 + 64u * j + lane;
+    cur_idx = node;
+    merkle_hash_start(prev, sg, ncols, size, node, cur);
+    store_hash(outs.p[0] + (uint64_t)node * 8, cur);
+    uint32_t jj = j;
+    int lvl = 0;
+    while (jj & 1u) {
+      const bool b = ((lane >> lvl) & 1u) != 0u;
+      uint32_t m[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          m[k] = stack[(lvl * 8 + k) * TPB + threadIdx.x];
-          m[8 + k] = cur[k];
-        }
-        b2_init(cur);
-        b2_compress(cur, m, 64u, 0xffffffffu);
-        jj >>= 1;
-        ++lvl;
-        store_hash(outs.p[lvl] + (uint64_t)(node >> lvl) * 8, cur);
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t st = stack[(lvl * 9 + k) * TPB + threadIdx.x];
+        const uint32_t recv = lmn_shfl_xor(b ? st : cur[k], 1 << lvl);
+        m[k] = b ? recv : st;
+        m[8 + k] = b ? cur[k] : recv;
       }
-      if (lvl < sub) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) stack[(lvl * 8 + k) * TPB + threadIdx.x] = cur[k];
-      }
+      const uint32_t sidx = stack[(lvl * 9 + 8) * TPB + threadIdx.x];
+      cur_idx = (b ? cur_idx : sidx) >> 1;
+      b2_init(cur);
+      b2_compress(cur, m, 64u, 0xffffffffu);
+      jj >>= 1;
+      ++lvl;
+      store_hash(outs.p[lvl] + (uint64_t)cur_idx * 8, cur);
     }
+    if (lvl < sub) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = cur[k];
+      for (int k = 0; k < 8; ++k) stack[(lvl * 9 + k) * TPB + threadIdx.x] = cur[k];
+      stack[(lvl * 9 + 8) * TPB + threadIdx.x] = cur_idx;
+    }
   }
-  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, nsub, cur);
+  {
+    const uint32_t local = cur_idx - blockIdx.x * TPB;  // this block owns level-`sub` nodes [b*TPB, (b+1)*TPB)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[local * 8 + k] = cur[k];
+  }
+  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub, cur);
 }
 
 // Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
@@ -555,7 +570,8 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s) {
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
-  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 || (size >> sub) == 0)
+  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
+      size % ((uint32_t)TPB << sub) != 0)
     throw LmnError(-100, "merkle_fused: bad arguments");
   LMN_LAUNCH(k_merkle_fused, dim3(cdiv(size >> sub, TPB)), dim3(TPB), 0, s, prev, sg, ncols, size, outs, sub, nfused);
 }

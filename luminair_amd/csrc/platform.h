@@ -20,6 +20,7 @@
 #define LMN_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; T* name = reinterpret_cast<T*>(name##_raw)
 #define LMN_SHARED __shared__
 typedef hipStream_t lmn_stream_t;
+#define lmn_shfl_xor(v, mask) __shfl_xor((v), (mask), 64)
 
 struct LmnError : std::runtime_error {
   int code;
@@ -101,6 +102,14 @@ void lmn_emu_syncthreads();
 #define __syncthreads() lmn_emu_syncthreads()
 #define LMN_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(lmn_emu_dyn_smem)
 typedef int lmn_stream_t;
+extern unsigned lmn_emu_shfl_scratch[1024];
+inline unsigned lmn_shfl_xor(unsigned v, int mask) {  // all lanes of the block must call it together
+  lmn_emu_shfl_scratch[threadIdx.x] = v;
+  lmn_emu_syncthreads();
+  unsigned r = lmn_emu_shfl_scratch[threadIdx.x ^ (unsigned)mask];
+  lmn_emu_syncthreads();
+  return r;
+}
 struct uint4 {
   unsigned x, y, z, w;
 };

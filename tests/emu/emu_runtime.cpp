@@ -10,6 +10,7 @@
 thread_local uint3e threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 thread_local unsigned char* lmn_emu_dyn_smem = nullptr;
+unsigned lmn_emu_shfl_scratch[1024];
 
 namespace {
 constexpr size_t kStack = 256 * 1024;
