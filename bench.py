@@ -149,20 +149,39 @@ def main(argv=None):
     one(0)
     latency_ms = 1e3 * (time.perf_counter() - t0)
 
-    # roofline of the dominant kernel family, from HIP events recorded on the prover's own stream
-    # during the last timed step (lmn_timings)
+    # roofline per kernel family, from HIP events recorded by the library on the prover's own stream
+    # around every transform / tree of the solo proof above (lmn_timings).  `traffic` comes from the
+    # committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
+    # applied: 2*FETCH_SIZE + WRITE_SIZE), per launch like `achieved`.
     tm = prover.timings()
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+            pmc = json.load(f)["kernels"]
+    except Exception:
+        pass
     fams = {
-        "k_fft_pass": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"]),
-        "k_merkle_layer": (tm["merkle_ms"], tm["merkle_bytes"], tm["merkle_launches"]),
+        "k_fft_staged": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"], ["k_fft_staged<false>", "k_fft_staged<true>"]),
+        "k_merkle_fused": (tm["merkle_ms"], tm["merkle_bytes"], tm["merkle_launches"],
+                           ["k_merkle_fused", "k_merkle_small", "k_fri_tail"]),
     }
+
+    def roof(name):
+        ms, nbytes, launches, pmc_names = fams[name]
+        launches = max(launches, 1)
+        achieved = nbytes / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        got = [pmc[k] for k in pmc_names if k in pmc]
+        if got:
+            tot_l = sum(g["launches"] for g in got)
+            traffic = sum(g["hbm_bytes_per_launch_corrected"] * g["launches"] for g in got) / max(tot_l, 1)
+        return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches_per_proof": launches,
+                "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": nbytes / launches}
+
     dom = max(fams, key=lambda k: fams[k][0])
-    ms, nbytes, launches = fams[dom]
-    achieved = (nbytes / max(launches, 1)) / (1e-3 * ms / max(launches, 1)) / 1e9 if ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launches_per_proof": launches, "avg_launch_ms": ms / max(launches, 1),
-                "algorithmic_bytes_per_launch": nbytes / max(launches, 1)}
+    roofline = roof(dom)
+    roofline_other = [roof(k) for k in fams if k != dom]
 
     line = {
         "metric": "proofs/sec, 2^%d-row Add trace" % args.log_rows, "value": agg["value"], "unit": "proofs/s",
@@ -177,6 +196,7 @@ def main(argv=None):
         "prove_latency_ms": latency_ms,
         "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         "roofline": roofline,
+        "roofline_other": roofline_other,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows)

@@ -80,3 +80,22 @@ def test_emu_level2_ops(emu_ctx):
     want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
     assert emu_ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
     emu_ctx.fft_selftest(13, 1)
+
+
+def test_emu_pinned_variant_with_inputs_component(root):
+    """17-slot claim + Inputs table (mixed column sizes inside one Merkle tree)."""
+    from oracle.channel import ProtocolVariant
+    so = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    lib = backend.Library(so)
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    tabs = syn.config2_graph_faithful(100, 3)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED))
+    assert got == want
+    # the KAT-variant context has no claim slot for kind 15
+    kat_ctx = backend.Context(0, None, lib)
+    with pytest.raises(backend.LuminairBackendError) as e:
+        kat_ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT

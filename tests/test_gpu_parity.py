@@ -126,3 +126,37 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
 def test_gpu_fft_tiled_equals_layerwise(gpu_prover, log):
     """Device-side differential check at full sizes: LDS-tiled passes vs one-layer-per-launch."""
     gpu_prover.ctx.fft_selftest(log, 2)
+
+
+# ---- LuminAIR-HEAD claim layout (17 slots) + Inputs component: BASELINE config 2b "graph-faithful"
+@pytest.fixture(scope="module")
+def gpu_prover_pinned(hip_lib_path):
+    from luminair_amd import backend
+    return luminair_amd.Prover(0, protocol_variant=backend.VARIANT_PINNED)
+
+
+def _oracle_bytes_pinned(tabs):
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    return to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED))
+
+
+@pytest.mark.parametrize("name,tabs", [
+    ("2b-100", syn.config2_graph_faithful(100, 3)),
+    ("2b-2^12", syn.config2_graph_faithful(1 << 12, 4)),
+    ("add-only-pinned", syn.config2_add_only(300, 5)),
+])
+def test_gpu_pinned_variant_equals_oracle(gpu_prover_pinned, name, tabs):
+    got = _gpu_bytes(gpu_prover_pinned, tabs)
+    assert got == _oracle_bytes_pinned(tabs), name
+
+
+def test_gpu_config2b_full_size_verifies(gpu_prover_pinned):
+    """Add 2^20 rows (mult -1/-1/0) + Inputs 2^21 rows: mixed-size Merkle trees, logup sums cancel."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import from_bincode
+    from oracle.verifier import verify
+    p = from_bincode(_gpu_bytes(gpu_prover_pinned, syn.config2_graph_faithful(1 << 20, 42)), 17)
+    assert p.claim[0] == 20 and p.claim[15] == 21
+    verify(p, ProtocolVariant.PINNED)

@@ -151,3 +151,13 @@ def test_unbalanced_logup_fails_verification_only():
     proof = prove([(k, r.astype(np.uint64)) for k, r in tabs])
     with pytest.raises(VerificationError, match="InvalidLogUp"):
         verify(proof)
+
+
+def test_oracle_pinned_variant_proves_and_verifies():
+    """LuminAIR-HEAD layout (17 claim slots, Inputs component) — parity unpinned, self-consistent."""
+    tabs = syn.config2_graph_faithful(100, 3)
+    proof = prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED)
+    assert len(proof.claim) == 17 and proof.claim[0] == 7 and proof.claim[15] == 8
+    verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.PINNED)
+    with pytest.raises(Exception):
+        verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.KAT)   # different transcript encodings
