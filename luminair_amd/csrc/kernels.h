@@ -133,6 +133,10 @@ constexpr int EVAL_LB = 10;
 void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, const QM31* hi_tab, uint32_t hi_stride,
                           int max_log, QM31* partial_out /* njobs x max_chunks */, int max_chunks, lmn_stream_t s);
 int eval_num_chunks(int log_n);
+void launch_eval_tables(const QM31* maps, int maps_stride, int npoints, QM31* lo_tab, QM31* hi_tab, uint32_t hi_n,
+                        int hi_bits, lmn_stream_t s);
+void launch_eval_reduce(const EvalJob* jobs, int njobs, const QM31* partial, int max_chunks, QM31* out,
+                        lmn_stream_t s);
 
 // ---- a9: FRI quotients
 constexpr int QUOT_MAX_BATCH = 4;

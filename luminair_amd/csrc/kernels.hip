@@ -759,26 +759,30 @@ void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n
 // =============================================================================================
 int logup_num_blocks(uint32_t n) { return (int)cdiv(n, TPB); }
 
+template <int K>
 LMN_KERNEL k_logup_fracs(LogupArgs a) {
   LMN_SHARED uint64_t red[TPB * 4];
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   QM31 S = q_zero();
   if (r < a.n) {
-    QM31 den[3], pre[3];
-    for (int j = 0; j < a.k; ++j) {
+    QM31 den[K], pre[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
       QM31 d = q_sub(q_add_m(q_mul_m(a.alpha, a.id[j][r]), a.val[j][r]), a.z);
       den[j] = d;
       pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
     }
-    QM31 inv = q_inv(pre[a.k - 1]);
-    QM31 invs[3];
-    for (int j = a.k - 1; j >= 0; --j) {
+    QM31 inv = q_inv(pre[K - 1]);
+    QM31 invs[K];
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
       invs[j] = j == 0 ? inv : q_mul(inv, pre[j - 1]);
       inv = q_mul(inv, den[j]);
     }
-    for (int j = 0; j < a.k; ++j) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
       S = q_add(S, q_mul_m(invs[j], a.mult[j][r]));
-      if (j < a.k - 1) {
+      if (j < K - 1) {
         uint32_t* o = a.inter + (uint64_t)(4 * j) * a.n + r;
         o[0] = S.a;
         o[(uint64_t)a.n] = S.b;
@@ -802,7 +806,13 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
 }
 
 void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s) {
-  LMN_LAUNCH(k_logup_fracs, dim3(logup_num_blocks(a.n)), dim3(TPB), 0, s, a);
+  dim3 g(logup_num_blocks(a.n)), b(TPB);
+  switch (a.k) {
+    case 1: LMN_LAUNCH(k_logup_fracs<1>, g, b, 0, s, a); break;
+    case 2: LMN_LAUNCH(k_logup_fracs<2>, g, b, 0, s, a); break;
+    case 3: LMN_LAUNCH(k_logup_fracs<3>, g, b, 0, s, a); break;
+    default: throw LmnError(-100, "logup: unsupported relation count");
+  }
 }
 
 LMN_KERNEL k_logup_reduce(const uint32_t* __restrict__ partials, int nblocks, uint32_t n_inv, QM31* out) {
@@ -1096,12 +1106,26 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
   const uint32_t hpc = total_hi / (uint32_t)nchunks;
   const QM31* L = lo_tab + ((uint64_t)job.point << EVAL_LB);
   const QM31* Hh = hi_tab + (uint64_t)job.point * hi_stride;
+  // each lane owns at most 4 lo positions (tid + 256k): keep their basis values in registers
+  QM31 Lr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
+    Lr[k] = lo < lo_n ? L[lo] : q_zero();
+  }
   QM31 acc = q_zero();
   for (uint32_t hh = 0; hh < hpc; ++hh) {
-    uint32_t hi = chunk * hpc + hh;
-    QM31 inner = q_zero();
-    for (uint32_t lo = threadIdx.x; lo < lo_n; lo += blockDim.x)
-      inner = q_add(inner, q_mul_m(L[lo], job.coeffs[((uint64_t)hi << lb) + lo]));
+    const uint32_t hi = chunk * hpc + hh;
+    const uint32_t* __restrict__ cp = job.coeffs + ((uint64_t)hi << lb);
+    uint32_t cv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
+      cv[k] = lo < lo_n ? cp[lo] : 0u;
+    }
+    QM31 inner = q_mul_m(Lr[0], cv[0]);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) inner = q_add(inner, q_mul_m(Lr[k], cv[k]));
     acc = q_add(acc, q_mul(Hh[hi], inner));
   }
   red[threadIdx.x] = acc;
@@ -1118,6 +1142,57 @@ void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, co
   (void)max_log;
   LMN_LAUNCH(k_eval_at_point, dim3(max_chunks, njobs), dim3(TPB), 0, s, jobs, lo_tab, hi_tab, hi_stride, partial_out,
              max_chunks);
+}
+
+// basis tables on the device: lo[p][j] = prod_{k<EVAL_LB} maps[p][k]^(bit k of j); hi[p][j] likewise
+// with maps[p][EVAL_LB + k].  maps = [y, x, pi(x), pi^2(x), ...] per sample point.
+LMN_KERNEL k_eval_tables(const QM31* __restrict__ maps, int maps_stride, QM31* __restrict__ lo_tab,
+                         QM31* __restrict__ hi_tab, uint32_t hi_n, int hi_bits) {
+  const int p = blockIdx.y;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const QM31* mp = maps + (uint64_t)p * maps_stride;
+  const uint32_t lo_n = 1u << EVAL_LB;
+  if (j < lo_n) {
+    QM31 acc = q_one();
+    for (int k = 0; k < EVAL_LB; ++k)
+      if ((j >> k) & 1u) acc = q_mul(acc, mp[k]);
+    lo_tab[(uint64_t)p * lo_n + j] = acc;
+  }
+  if (j < hi_n) {
+    QM31 acc = q_one();
+    for (int k = 0; k < hi_bits; ++k)
+      if ((j >> k) & 1u) acc = q_mul(acc, mp[EVAL_LB + k]);
+    hi_tab[(uint64_t)p * hi_n + j] = acc;
+  }
+}
+
+void launch_eval_tables(const QM31* maps, int maps_stride, int npoints, QM31* lo_tab, QM31* hi_tab, uint32_t hi_n,
+                        int hi_bits, lmn_stream_t s) {
+  uint32_t n = hi_n > (1u << EVAL_LB) ? hi_n : (1u << EVAL_LB);
+  LMN_LAUNCH(k_eval_tables, dim3(cdiv(n, TPB), npoints), dim3(TPB), 0, s, maps, maps_stride, lo_tab, hi_tab, hi_n,
+             hi_bits);
+}
+
+// out[job] = sum over that job's chunks of partial[job][chunk]
+LMN_KERNEL k_eval_reduce(const EvalJob* __restrict__ jobs, const QM31* __restrict__ partial, int max_chunks,
+                         QM31* __restrict__ out) {
+  LMN_SHARED QM31 red[TPB];
+  const int job = blockIdx.x;
+  const int nc = eval_num_chunks_hd(jobs[job].log_n);
+  QM31 acc = q_zero();
+  for (int c = threadIdx.x; c < nc; c += blockDim.x) acc = q_add(acc, partial[(uint64_t)job * max_chunks + c]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = q_add(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[job] = red[0];
+}
+
+void launch_eval_reduce(const EvalJob* jobs, int njobs, const QM31* partial, int max_chunks, QM31* out,
+                        lmn_stream_t s) {
+  LMN_LAUNCH(k_eval_reduce, dim3(njobs), dim3(TPB), 0, s, jobs, partial, max_chunks, out);
 }
 
 // =============================================================================================

@@ -57,7 +57,18 @@ inline void lmn_d2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
   LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
 }
 inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) { LMN_HIP_CHECK(hipMemsetAsync(dst, v, n, s)); }
-inline void lmn_sync(lmn_stream_t s) { LMN_HIP_CHECK(hipStreamSynchronize(s)); }
+// Spin on hipStreamQuery instead of blocking in hipStreamSynchronize: the prover synchronises 6
+// times per proof and the blocking wake-up latency (tens of microseconds) would sit on the critical path.
+inline void lmn_sync(lmn_stream_t s) {
+  for (;;) {
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) LMN_HIP_CHECK(e);
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
 inline void* lmn_host_alloc_pinned(size_t bytes) {
   void* p = nullptr;
   LMN_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));

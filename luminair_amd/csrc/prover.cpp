@@ -459,42 +459,32 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
   const uint32_t lo_n = 1u << EVAL_LB;
   const int hi_bits = max_log > EVAL_LB ? max_log - EVAL_LB : 0;
   const uint32_t hi_n = 1u << hi_bits;
-  std::vector<QM31> lo_tab((size_t)np * lo_n), hi_tab((size_t)np * hi_n);
+  const int nmaps = std::max(max_log, EVAL_LB);
+  // mappings per point: y, x, pi(x), pi^2(x), ...  (tables themselves are expanded on the device)
+  std::vector<QM31> maps((size_t)np * nmaps);
   for (int p = 0; p < np; ++p) {
-    // mappings: y, x, pi(x), pi^2(x), ...
-    std::vector<QM31> maps;
-    maps.push_back(points[p].y);
-    maps.push_back(points[p].x);
+    QM31* mp = &maps[(size_t)p * nmaps];
+    mp[0] = points[p].y;
+    mp[1] = points[p].x;
     QM31 cur = points[p].x;
-    for (int k = 2; k < std::max(max_log, EVAL_LB); ++k) {
+    for (int k = 2; k < nmaps; ++k) {
       cur = q_sub_m(q_add(q_sqr(cur), q_sqr(cur)), 1u);
-      maps.push_back(cur);
+      mp[k] = cur;
     }
-    QM31* L = &lo_tab[(size_t)p * lo_n];
-    L[0] = q_one();
-    for (int k = 0; k < EVAL_LB; ++k)
-      for (uint32_t j = 0; j < (1u << k); ++j) L[j + (1u << k)] = q_mul(L[j], maps[k]);
-    QM31* H = &hi_tab[(size_t)p * hi_n];
-    H[0] = q_one();
-    for (int k = 0; k < hi_bits; ++k)
-      for (uint32_t j = 0; j < (1u << k); ++j) H[j + (1u << k)] = q_mul(H[j], maps[EVAL_LB + k]);
   }
   int max_chunks = eval_num_chunks(max_log);
   EvalJob* d_jobs = upload_vec(jobs);
-  QM31* d_lo = upload_vec(lo_tab);
-  QM31* d_hi = upload_vec(hi_tab);
-  QM31* d_out = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));
-  launch_eval_at_point(d_jobs, (int)jobs.size(), d_lo, d_hi, hi_n, max_log, d_out, max_chunks, stream_);
-  const QM31* partial = (const QM31*)stage_download(d_out, jobs.size() * (size_t)max_chunks * sizeof(QM31));
+  QM31* d_maps = upload_vec(maps);
+  QM31* d_lo = (QM31*)arena_.alloc_bytes((size_t)np * lo_n * sizeof(QM31));
+  QM31* d_hi = (QM31*)arena_.alloc_bytes((size_t)np * hi_n * sizeof(QM31));
+  QM31* d_part = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));
+  QM31* d_out = (QM31*)arena_.alloc_bytes(jobs.size() * sizeof(QM31));
+  launch_eval_tables(d_maps, nmaps, np, d_lo, d_hi, hi_n, hi_bits, stream_);
+  launch_eval_at_point(d_jobs, (int)jobs.size(), d_lo, d_hi, hi_n, max_log, d_part, max_chunks, stream_);
+  launch_eval_reduce(d_jobs, (int)jobs.size(), d_part, max_chunks, d_out, stream_);
+  const QM31* res = (const QM31*)stage_download(d_out, jobs.size() * sizeof(QM31));
   lmn_sync(stream_);
-  std::vector<QM31> res(jobs.size());
-  for (size_t j = 0; j < jobs.size(); ++j) {
-    QM31 acc = q_zero();
-    int nc = eval_num_chunks(jobs[j].log_n);
-    for (int c = 0; c < nc; ++c) acc = q_add(acc, partial[j * max_chunks + c]);
-    res[j] = acc;
-  }
-  return res;
+  return std::vector<QM31>(res, res + jobs.size());
 }
 
 // ------------------------------------------------------------------------------------ decommit planning
