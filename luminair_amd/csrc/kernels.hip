@@ -971,15 +971,16 @@ LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint3
   return QM31{base[s], base[stride + s], base[2 * stride + s], base[3 * stride + s]};
 }
 
-// logup constraints for NREL relations; rel_mult/rel_val/rel_id index into the row array
+// logup constraints for NREL relations; values are passed by value (no indexed private arrays:
+// those get promoted to LDS and cost occupancy)
 template <int NREL>
-LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t* c, const int* rel_mult,
-                             const int* rel_val, const int* rel_id, uint32_t s, uint64_t E) {
+LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t (&mult)[NREL],
+                             const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], uint32_t s, uint64_t E) {
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
     QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * E, E, s);
-    QM31 den = q_sub(q_add_m(q_mul_m(a.alpha, c[rel_id[j]]), c[rel_val[j]]), a.z);
+    QM31 den = q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
     QM31 diff;
     if (j < NREL - 1) {
       diff = q_sub(cur, prev);
@@ -988,71 +989,66 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32
       QM31 pr = load_secure(a.inter + (uint64_t)(4 * j) * E, E, ps);
       diff = q_add(q_sub(q_sub(cur, pr), prev), a.claimed_shift[1]);
     }
-    ca.add_q(q_sub_m(q_mul(diff, den), c[rel_mult[j]]));
+    ca.add_q(q_sub_m(q_mul(diff, den), mult[j]));
     prev = cur;
   }
 }
 
+template <int KIND>
 LMN_KERNEL k_composition(CompositionArgs a) {
   const uint64_t E = 1ull << a.eval_log;
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= E) return;
   ConsAcc ca{q_zero(), a.coeff, 0};
-  if (a.kind == 0 || a.kind == 1) {
+  const uint32_t* __restrict__ mn = a.main + s;
+#define LMN_COL(k) mn[(uint64_t)(k) * E]
+  if (KIND == 0 || KIND == 1) {
     // Add (15 cols) / Mul (16 cols: rem inserted at 12)
-    const bool mul = a.kind == 1;
-    uint32_t c[16];
-    if (mul)
-      load_row<16>(a.main, E, s, c);
-    else
-      load_row<15>(a.main, E, s, c);
-    const uint32_t node = c[0], lhs_id = c[1], rhs_id = c[2], idx = c[3], is_last = c[4];
-    const uint32_t lhs = c[9], rhs = c[10], out = c[11];
+    constexpr bool mul = KIND == 1;
+    constexpr int mo = mul ? 13 : 12;
+    const uint32_t node = LMN_COL(0), lhs_id = LMN_COL(1), rhs_id = LMN_COL(2), idx = LMN_COL(3), is_last = LMN_COL(4);
+    const uint32_t n_node = LMN_COL(5), n_lhs = LMN_COL(6), n_rhs = LMN_COL(7), n_idx = LMN_COL(8);
+    const uint32_t lhs = LMN_COL(9), rhs = LMN_COL(10), out = LMN_COL(11);
+    const uint32_t m0 = LMN_COL(mo), m1 = LMN_COL(mo + 1), m2 = LMN_COL(mo + 2);
     ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
     if (mul) {
-      const uint32_t rem = c[12];
+      const uint32_t rem = LMN_COL(12);
       ca.add_m(m_sub(m_mul(lhs, rhs), m_add(m_mul(out, 4096u), rem)));
       ca.add_m(0u);  // second eval_fixed_mul slot: zero on rem == 0 (KAT-pinned form)
     } else {
       ca.add_m(m_sub(out, m_add(lhs, rhs)));
     }
     const uint32_t not_last = m_sub(1u, is_last);
-    ca.add_m(m_mul(not_last, m_sub(c[5], node)));
-    ca.add_m(m_mul(not_last, m_sub(c[6], lhs_id)));
-    ca.add_m(m_mul(not_last, m_sub(c[7], rhs_id)));
-    ca.add_m(m_mul(not_last, m_sub(m_sub(c[8], idx), 1u)));
-    const int mo = mul ? 13 : 12;
-    const int rel_mult[3] = {mo, mo + 1, mo + 2};
-    const int rel_val[3] = {9, 10, 11};
-    const int rel_id[3] = {1, 2, 0};
-    logup_constraints<3>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
-  } else if (a.kind == 2) {
-    uint32_t c[13];
-    load_row<13>(a.main, E, s, c);
-    const uint32_t is_last = c[3];
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_lhs, lhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
+    logup_constraints<3>(ca, a, rm, rv, ri, s, E);
+  } else if (KIND == 2) {
+    const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
+    const uint32_t n_node = LMN_COL(4), n_in = LMN_COL(5), n_idx = LMN_COL(6);
+    const uint32_t inp = LMN_COL(7), out = LMN_COL(8), rem = LMN_COL(9), scale = LMN_COL(10);
+    const uint32_t m0 = LMN_COL(11), m1 = LMN_COL(12);
     ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
-    ca.add_m(m_sub(m_sqr(c[10]), m_add(m_mul(c[7], c[8]), c[9])));
+    ca.add_m(m_sub(m_sqr(scale), m_add(m_mul(inp, out), rem)));
     const uint32_t not_last = m_sub(1u, is_last);
-    ca.add_m(m_mul(not_last, m_sub(c[4], c[0])));
-    ca.add_m(m_mul(not_last, m_sub(c[5], c[1])));
-    ca.add_m(m_mul(not_last, m_sub(m_sub(c[6], c[2]), 1u)));
-    const int rel_mult[2] = {11, 12};
-    const int rel_val[2] = {7, 8};
-    const int rel_id[2] = {1, 0};
-    logup_constraints<2>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
+    logup_constraints<2>(ca, a, rm, rv, ri, s, E);
   } else {
-    uint32_t c[7];
-    load_row<7>(a.main, E, s, c);
-    const uint32_t is_last = c[2];
+    const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
+    const uint32_t val = LMN_COL(5), mult = LMN_COL(6);
     ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
     const uint32_t not_last = m_sub(1u, is_last);
-    ca.add_m(m_mul(not_last, m_sub(c[3], c[0])));
-    ca.add_m(m_mul(not_last, m_sub(m_sub(c[4], c[1]), 1u)));
-    const int rel_mult[1] = {6};
-    const int rel_val[1] = {5};
-    const int rel_id[1] = {0};
-    logup_constraints<1>(ca, a, c, rel_mult, rel_val, rel_id, s, E);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[1] = {mult}, rv[1] = {val}, ri[1] = {node};
+    logup_constraints<1>(ca, a, rm, rv, ri, s, E);
   }
+#undef LMN_COL
   QM31 r = q_mul_m(ca.acc, a.zinv[(s >> a.log_size) & 1u]);
   uint32_t* o = a.out + s;
   if (a.accumulate) {
@@ -1069,7 +1065,14 @@ LMN_KERNEL k_composition(CompositionArgs a) {
 
 void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
   if (a.eval_log != a.log_size + 1) throw LmnError(-100, "composition: eval domain must be log_size+1");
-  LMN_LAUNCH(k_composition, dim3(cdiv(1ull << a.eval_log, TPB)), dim3(TPB), 0, s, a);
+  dim3 g(cdiv(1ull << a.eval_log, TPB)), b(TPB);
+  switch (a.kind) {
+    case 0: LMN_LAUNCH(k_composition<0>, g, b, 0, s, a); break;
+    case 1: LMN_LAUNCH(k_composition<1>, g, b, 0, s, a); break;
+    case 2: LMN_LAUNCH(k_composition<2>, g, b, 0, s, a); break;
+    case 15: LMN_LAUNCH(k_composition<15>, g, b, 0, s, a); break;
+    default: throw LmnError(-100, "composition: unsupported component kind");
+  }
 }
 
 LMN_KERNEL k_secure_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, uint64_t n) {
