@@ -34,6 +34,10 @@ def test_gpu_reproduces_reference_kat(gpu_prover, kat_bytes):
     ("chain-2^13", syn.chain_graph(1 << 13, 7)),
     ("config3-small", syn.config3_mixed(14, 13, 13, 8)),
     ("add-2^16", syn.config2_add_only(1 << 16, 42)),
+    ("mul-only-ragged", [syn.chain_graph(1000, 9)[1]]),
+    ("recip-only", [syn.chain_graph(257, 10)[2]]),
+    ("pow2-plus-one", syn.config2_add_only((1 << 10) + 1, 11)),
+    ("pow2-minus-one", syn.config2_add_only((1 << 11) - 1, 12)),
 ])
 def test_gpu_proof_equals_oracle_proof(gpu_prover, name, tabs):
     got = _gpu_bytes(gpu_prover, tabs)
@@ -82,6 +86,27 @@ def test_gpu_config3_mixed_2_22_rows_verifies(gpu_prover):
     p = from_bincode(_gpu_bytes(gpu_prover, syn.config3_mixed(21, 20, 20, 5)), 8)
     assert p.claim[:3] == [21, 20, 20]
     verify(p)
+
+
+def test_gpu_largest_single_table_2_22_rows_verifies(gpu_prover):
+    """Maximum size exercised: one Add table of 2^22 rows (LDE 2^23, composition LDE 2^24)."""
+    from oracle.proof import from_bincode
+    from oracle.verifier import verify
+    p = from_bincode(_gpu_bytes(gpu_prover, syn.config2_add_only(1 << 22, 3)), 8)
+    assert p.claim[0] == 22
+    verify(p)
+
+
+def test_gpu_two_contexts_concurrently(hip_lib_path):
+    """Independent contexts (own stream + arena) proving at the same time give the same bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+    provers = [luminair_amd.Prover(0) for _ in range(3)]
+    tabs = [syn.chain_graph(1 << 12, 20 + i) for i in range(3)]
+    want = [_gpu_bytes(provers[0], t) for t in tabs]
+    with ThreadPoolExecutor(3) as ex:
+        for _ in range(3):
+            got = list(ex.map(lambda it: _gpu_bytes(it[0], it[1]), zip(provers, tabs)))
+            assert got == want
 
 
 def test_gpu_error_behaviour(gpu_prover):
