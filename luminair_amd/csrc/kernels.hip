@@ -309,9 +309,13 @@ static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uin
     size_t smem = (size_t)4 * (tile_elems + (tile_elems >> 5) + 1);
     // several columns per block when there are plenty of tiles: twiddles stay hot in L1/L2
     int cpb = tiles >= 2048 ? 3 : (tiles >= 512 ? 2 : 1);
+    static const int env_cpb = getenv("LMN_FFT_CPB") ? atoi(getenv("LMN_FFT_CPB")) : 0;
+    static const int env_thr = getenv("LMN_FFT_THREADS") ? atoi(getenv("LMN_FFT_THREADS")) : 0;
+    if (env_cpb > 0) cpb = env_cpb;
     if (cpb > ncols) cpb = ncols;
     unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
     int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
+    if (env_thr > 0) threads = env_thr;
     LMN_LAUNCH(k_fft_staged<INV>, dim3(tiles, gy), dim3(threads), smem, s, data, col_stride, psrc, pstride, plen, pl,
                tw, scale, ncols, cpb);
   }

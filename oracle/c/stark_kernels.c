@@ -1,0 +1,409 @@
+/* oracle/c/stark_kernels.c — plain-C restatement of the per-row work of the LuminAIR `prove` path.
+ *
+ * TEST INFRASTRUCTURE ONLY (checker + `cpu_baseline` leg of bench.py); never linked into the product.
+ * It restates, as scalar loops (+ OpenMP over rows/columns), the algorithms stwo runs behind
+ *   /root/reference/crates/prover/src/prover.rs:56-59,179,298 (interpolate / evaluate / Blake2s Merkle),
+ *   crates/air/src/components/add/witness.rs:126-167        (LogupTraceGenerator),
+ *   crates/air/src/components/{add,mul,recip}/component.rs, inputs/components.rs (constraint quotients),
+ *   prover.rs:312 stwo::prover::prove                       (eval_at_point, FRI quotients, folds),
+ * following SURVEY.md Appendix A.  The stwo sources are un-vendored (Cargo.toml:21-30), so the
+ * published algorithm is restated; oracle/cbackend.py checks every function here against the numpy
+ * oracle, which is pinned bit-for-bit on the reference's known-answer proof.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define P 0x7fffffffu
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+static inline u32 madd(u32 a, u32 b) { u32 s = a + b; return s >= P ? s - P : s; }
+static inline u32 msub(u32 a, u32 b) { return a >= b ? a - b : a + P - b; }
+static inline u32 mneg(u32 a) { return a ? P - a : 0; }
+static inline u32 mmul(u32 a, u32 b) {
+  u64 p = (u64)a * b;
+  u32 s = (u32)(p & P) + (u32)(p >> 31);
+  return s >= P ? s - P : s;
+}
+static u32 mpow(u32 a, u32 e) {
+  u32 r = 1;
+  while (e) {
+    if (e & 1) r = mmul(r, a);
+    a = mmul(a, a);
+    e >>= 1;
+  }
+  return r;
+}
+static inline u32 minv(u32 a) { return mpow(a, P - 2); }
+
+typedef struct { u32 a, b; } cm;
+typedef struct { u32 a, b, c, d; } qm;
+static inline cm cadd(cm x, cm y) { cm r = {madd(x.a, y.a), madd(x.b, y.b)}; return r; }
+static inline cm csub(cm x, cm y) { cm r = {msub(x.a, y.a), msub(x.b, y.b)}; return r; }
+static inline cm cmul(cm x, cm y) {
+  cm r = {msub(mmul(x.a, y.a), mmul(x.b, y.b)), madd(mmul(x.a, y.b), mmul(x.b, y.a))};
+  return r;
+}
+static inline cm cmulr(cm x) { cm r = {msub(madd(x.a, x.a), x.b), madd(x.a, madd(x.b, x.b))}; return r; } /* (2+i)x */
+static inline cm cinv(cm x) {
+  u32 n = minv(madd(mmul(x.a, x.a), mmul(x.b, x.b)));
+  cm r = {mmul(x.a, n), mmul(mneg(x.b), n)};
+  return r;
+}
+static inline qm qadd(qm x, qm y) { qm r = {madd(x.a, y.a), madd(x.b, y.b), madd(x.c, y.c), madd(x.d, y.d)}; return r; }
+static inline qm qsub(qm x, qm y) { qm r = {msub(x.a, y.a), msub(x.b, y.b), msub(x.c, y.c), msub(x.d, y.d)}; return r; }
+static inline qm qmulm(qm x, u32 m) { qm r = {mmul(x.a, m), mmul(x.b, m), mmul(x.c, m), mmul(x.d, m)}; return r; }
+static inline qm qmul(qm x, qm y) {
+  cm A = {x.a, x.b}, B = {x.c, x.d}, C = {y.a, y.b}, D = {y.c, y.d};
+  cm lo = cadd(cmul(A, C), cmulr(cmul(B, D)));
+  cm hi = cadd(cmul(A, D), cmul(B, C));
+  qm r = {lo.a, lo.b, hi.a, hi.b};
+  return r;
+}
+static inline qm qmulc(qm x, cm c) {
+  cm A = {x.a, x.b}, B = {x.c, x.d};
+  cm lo = cmul(A, c), hi = cmul(B, c);
+  qm r = {lo.a, lo.b, hi.a, hi.b};
+  return r;
+}
+static inline qm qinv(qm x) {
+  cm A = {x.a, x.b}, B = {x.c, x.d};
+  cm den = csub(cmul(A, A), cmulr(cmul(B, B)));
+  cm di = cinv(den);
+  cm lo = cmul(A, di), hi = cmul(B, di);
+  qm r = {lo.a, lo.b, mneg(hi.a), mneg(hi.b)};
+  return r;
+}
+static inline qm qfromm(u32 m) { qm r = {m, 0, 0, 0}; return r; }
+static const qm QZERO = {0, 0, 0, 0};
+
+/* ---------------------------------------------------------------------------------------------
+ * Circle FFT, one layer at a time (Appendix A.2).  data: ncols columns of 2^log_n words.
+ * tw[i] = twiddles of layer i (2^(log_n-1-i) words): forward twiddles, or their inverses when
+ * inverse != 0 (the caller passes the matching table).  Inverse also scales by 2^-log_n.
+ * ------------------------------------------------------------------------------------------- */
+void orc_circle_fft(u32* data, long ncols, int log_n, const u32* const* tw, int inverse) {
+  const long n = 1L << log_n;
+  const long half_n = n >> 1;
+  const u32 sc = minv(mpow(2, (u32)log_n));
+#pragma omp parallel
+  {
+    for (int s = 0; s < log_n; ++s) {
+      const int i = inverse ? s : log_n - 1 - s;
+      const u32* t = tw[i];
+      const long hmask = (1L << i) - 1;
+      /* flat butterfly index over all columns: (column, h, l) */
+#pragma omp for schedule(static)
+      for (long f = 0; f < ncols * half_n; ++f) {
+        const long c = f / half_n, bfly = f - c * half_n;
+        const long h = bfly >> i, l = bfly & hmask;
+        u32* lo = data + c * n + (h << (i + 1)) + l;
+        u32* hi = lo + (1L << i);
+        const u32 w = t[h];
+        if (inverse) {
+          u32 a = *lo, b = *hi;
+          *lo = madd(a, b);
+          *hi = mmul(msub(a, b), w);
+        } else {
+          u32 x = mmul(*hi, w);
+          u32 a = *lo;
+          *lo = madd(a, x);
+          *hi = msub(a, x);
+        }
+      } /* implicit barrier between layers */
+    }
+    if (inverse) {
+#pragma omp for schedule(static)
+      for (long k = 0; k < ncols * n; ++k) data[k] = mmul(data[k], sc);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Blake2s (RFC 7693) over rows of 32-bit words: out[i] = blake2s(words[i][0..w)) (Appendix A.4).
+ * ------------------------------------------------------------------------------------------- */
+static const u32 IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                          0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+static const unsigned char SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+static inline u32 rotr(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
+static void compress(u32 h[8], const u32 m[16], u32 t, u32 f) {
+  u32 v[16];
+  for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+  v[12] ^= t;
+  v[14] ^= f;
+#define G(a, b, c, d, x, y)                                           \
+  v[a] += v[b] + (x); v[d] = rotr(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 12); \
+  v[a] += v[b] + (y); v[d] = rotr(v[d] ^ v[a], 8);  v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 7);
+  for (int r = 0; r < 10; ++r) {
+    const unsigned char* s = SIGMA[r];
+    G(0, 4, 8, 12, m[s[0]], m[s[1]]) G(1, 5, 9, 13, m[s[2]], m[s[3]])
+    G(2, 6, 10, 14, m[s[4]], m[s[5]]) G(3, 7, 11, 15, m[s[6]], m[s[7]])
+    G(0, 5, 10, 15, m[s[8]], m[s[9]]) G(1, 6, 11, 12, m[s[10]], m[s[11]])
+    G(2, 7, 8, 13, m[s[12]], m[s[13]]) G(3, 4, 9, 14, m[s[14]], m[s[15]])
+  }
+#undef G
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+void orc_blake2s_rows(const u32* words, long n, int w, u32* out) {
+  const int nblocks = w == 0 ? 1 : (w + 15) / 16;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n; ++i) {
+    u32 h[8];
+    for (int k = 0; k < 8; ++k) h[k] = IV[k];
+    h[0] ^= 0x01010020u;
+    const u32* row = words + i * (long)w;
+    for (int b = 0; b < nblocks; ++b) {
+      u32 m[16];
+      for (int k = 0; k < 16; ++k) { int j = 16 * b + k; m[k] = j < w ? row[j] : 0; }
+      int last = b + 1 == nblocks;
+      compress(h, m, last ? (u32)(4 * w) : (u32)(64 * (b + 1)), last ? 0xffffffffu : 0);
+    }
+    memcpy(out + 8 * i, h, 32);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Logup (Appendix A.6): S_j[r] = S_{j-1}[r] + mult_j[r] / (val_j[r] + alpha*id_j[r] - z).
+ * cols: k relations x (val, id, mult) pointers, each n words.  out: k secure columns as 4k base
+ * columns of n words (running sums, NOT yet prefix-summed); claimed = sum over rows of S_{k-1}.
+ * ------------------------------------------------------------------------------------------- */
+void orc_logup_columns(const u32* const* val, const u32* const* id, const u32* const* mult, int k, long n,
+                       const u32 z[4], const u32 alpha[4], u32* out, u32 claimed[4]) {
+  const qm Z = {z[0], z[1], z[2], z[3]}, A = {alpha[0], alpha[1], alpha[2], alpha[3]};
+  u64 acc[4] = {0, 0, 0, 0};
+#pragma omp parallel
+  {
+    u64 loc[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static)
+    for (long r = 0; r < n; ++r) {
+      qm S = QZERO;
+      for (int j = 0; j < k; ++j) {
+        qm den = qsub(qadd(qfromm(val[j][r]), qmulm(A, id[j][r])), Z);
+        S = qadd(S, qmulm(qinv(den), mult[j][r]));
+        u32* o = out + (long)(4 * j) * n + r;
+        o[0] = S.a; o[n] = S.b; o[2 * n] = S.c; o[3 * n] = S.d;
+      }
+      loc[0] += S.a; loc[1] += S.b; loc[2] += S.c; loc[3] += S.d;
+    }
+#pragma omp critical
+    for (int t = 0; t < 4; ++t) acc[t] += loc[t] % P;
+  }
+  for (int t = 0; t < 4; ++t) claimed[t] = (u32)(acc[t] % P);
+}
+
+/* last column: T[order[i]] = sum_{i' <= i} (S[order[i']] - shift), order = coset-order storage indices */
+void orc_logup_prefix(u32* col4, long n, const int64_t* order, const u32 shift[4]) {
+  for (int t = 0; t < 4; ++t) {
+    u32* c = col4 + (long)t * n;
+    u32 run = 0;
+    for (long i = 0; i < n; ++i) {
+      long s = order[i];
+      run = madd(run, msub(c[s], shift[t]));
+      c[s] = run;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Constraint quotients of one component on its eval domain (Appendix A.7).
+ * kind: 0 Add, 1 Mul, 2 Recip, 15 Inputs.  main: n_cols columns of E words; inter: 4*n_rel columns;
+ * prev_idx[s] = storage index of the previous trace row of s; coeff: alpha powers (QM31) in
+ * constraint order; zinv[s]: 1/Z per row; out: 4 x E (+= when accumulate).
+ * ------------------------------------------------------------------------------------------- */
+static int local_constraints(int kind, const u32* c, u32* out) {
+  int k = 0;
+  if (kind == 0 || kind == 1) {
+    u32 is_last = c[4], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    if (kind == 0) {
+      out[k++] = msub(c[11], madd(c[9], c[10]));
+    } else {
+      out[k++] = msub(mmul(c[9], c[10]), madd(mmul(c[11], 4096), c[12]));
+      out[k++] = 0; /* second eval_fixed_mul slot: zero for rem == 0 (KAT-pinned), see oracle/air.py */
+    }
+    out[k++] = mmul(nl, msub(c[5], c[0]));
+    out[k++] = mmul(nl, msub(c[6], c[1]));
+    out[k++] = mmul(nl, msub(c[7], c[2]));
+    out[k++] = mmul(nl, msub(msub(c[8], c[3]), 1));
+  } else if (kind == 2) {
+    u32 is_last = c[3], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    out[k++] = msub(mmul(c[10], c[10]), madd(mmul(c[7], c[8]), c[9]));
+    out[k++] = mmul(nl, msub(c[4], c[0]));
+    out[k++] = mmul(nl, msub(c[5], c[1]));
+    out[k++] = mmul(nl, msub(msub(c[6], c[2]), 1));
+  } else {
+    u32 is_last = c[2], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    out[k++] = mmul(nl, msub(c[3], c[0]));
+    out[k++] = mmul(nl, msub(msub(c[4], c[1]), 1));
+  }
+  return k;
+}
+
+void orc_composition(int kind, int n_cols, int n_rel, const int* rel_mult, const int* rel_val, const int* rel_id,
+                     const u32* main, const u32* inter, long E, const int64_t* prev_idx, const u32 z[4],
+                     const u32 alpha[4], const u32 shift[4], const u32* coeff /* 4 words each */,
+                     const u32* zinv, u32* out, int accumulate) {
+  const qm Z = {z[0], z[1], z[2], z[3]}, A = {alpha[0], alpha[1], alpha[2], alpha[3]};
+  const qm SH = {shift[0], shift[1], shift[2], shift[3]};
+#pragma omp parallel for schedule(static)
+  for (long s = 0; s < E; ++s) {
+    u32 c[32], lc[16];
+    for (int k = 0; k < n_cols; ++k) c[k] = main[(long)k * E + s];
+    int nl = local_constraints(kind, c, lc);
+    qm acc = QZERO;
+    int k = 0;
+    for (; k < nl; ++k) {
+      qm cf = {coeff[4 * k], coeff[4 * k + 1], coeff[4 * k + 2], coeff[4 * k + 3]};
+      acc = qadd(acc, qmulm(cf, lc[k]));
+    }
+    qm prev = QZERO;
+    for (int j = 0; j < n_rel; ++j, ++k) {
+      const u32* b = inter + (long)(4 * j) * E;
+      qm cur = {b[s], b[E + s], b[2 * E + s], b[3 * E + s]};
+      qm den = qsub(qadd(qfromm(c[rel_val[j]]), qmulm(A, c[rel_id[j]])), Z);
+      qm diff;
+      if (j < n_rel - 1) {
+        diff = qsub(cur, prev);
+      } else {
+        long ps = prev_idx[s];
+        qm pr = {b[ps], b[E + ps], b[2 * E + ps], b[3 * E + ps]};
+        diff = qadd(qsub(qsub(cur, pr), prev), SH);
+      }
+      qm cons = qsub(qmul(diff, den), qfromm(c[rel_mult[j]]));
+      qm cf = {coeff[4 * k], coeff[4 * k + 1], coeff[4 * k + 2], coeff[4 * k + 3]};
+      acc = qadd(acc, qmul(cons, cf));
+      prev = cur;
+    }
+    acc = qmulm(acc, zinv[s]);
+    u32* o = out + s;
+    if (accumulate) {
+      acc.a = madd(acc.a, o[0]); acc.b = madd(acc.b, o[E]); acc.c = madd(acc.c, o[2 * E]); acc.d = madd(acc.d, o[3 * E]);
+    }
+    o[0] = acc.a; o[E] = acc.b; o[2 * E] = acc.c; o[3 * E] = acc.d;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * eval_at_point: sum_j coeff_j * prod_k maps[k]^(bit k of j)  (Appendix A.2 basis; Horner-style fold)
+ * ------------------------------------------------------------------------------------------- */
+void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 4 */, u32 out[4]) {
+  const long n = 1L << log_n;
+  qm* acc = (qm*)malloc(sizeof(qm) * (size_t)(n > 1 ? n / 2 : 1));
+  if (log_n == 0) {
+    out[0] = coeffs[0]; out[1] = out[2] = out[3] = 0;
+    free(acc);
+    return;
+  }
+  {
+    const int k = log_n - 1;
+    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
+    const long half = n / 2;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < half; ++i) acc[i] = qadd(qfromm(coeffs[i]), qmulm(m, coeffs[half + i]));
+  }
+  for (int k = log_n - 2; k >= 0; --k) {
+    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
+    const long half = 1L << k;
+#pragma omp parallel for schedule(static) if (half > 4096)
+    for (long i = 0; i < half; ++i) acc[i] = qadd(acc[i], qmul(acc[half + i], m));
+  }
+  out[0] = acc[0].a; out[1] = acc[0].b; out[2] = acc[0].c; out[3] = acc[0].d;
+  free(acc);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * FRI quotients over one LDE domain (Appendix A.8).  Batches: for batch b, entries
+ * [bstart[b], bstart[b+1]) of (col index, a, b, c) line coefficients (already alpha-weighted);
+ * point (px, py) as QM31; batch_coeff = alpha^|batch|.  xs/ys: domain points in storage order.
+ * ------------------------------------------------------------------------------------------- */
+void orc_quotients(const u32* const* cols, long L, int nbatch, const int* bstart, const int* col_idx,
+                   const u32* la, const u32* lb, const u32* lc /* 4 words per entry */, const u32* pts /* 8/batch */,
+                   const u32* batch_coeff /* 4/batch */, const u32* xs, const u32* ys, u32* out) {
+#pragma omp parallel for schedule(static)
+  for (long s = 0; s < L; ++s) {
+    const u32 x = xs[s], y = ys[s];
+    qm row = QZERO;
+    for (int b = 0; b < nbatch; ++b) {
+      qm num = QZERO;
+      for (int e = bstart[b]; e < bstart[b + 1]; ++e) {
+        qm A = {la[4 * e], la[4 * e + 1], la[4 * e + 2], la[4 * e + 3]};
+        qm B = {lb[4 * e], lb[4 * e + 1], lb[4 * e + 2], lb[4 * e + 3]};
+        qm C = {lc[4 * e], lc[4 * e + 1], lc[4 * e + 2], lc[4 * e + 3]};
+        qm value = qmulm(C, cols[col_idx[e]][s]);
+        qm linear = qadd(qmulm(A, y), B);
+        num = qadd(num, qsub(value, linear));
+      }
+      const u32* p = pts + 8 * b;
+      cm prx = {p[0], p[1]}, pix = {p[2], p[3]}, pry = {p[4], p[5]}, piy = {p[6], p[7]};
+      cm dx = {msub(prx.a, x), prx.b}, dy = {msub(pry.a, y), pry.b};
+      cm den = csub(cmul(dx, piy), cmul(dy, pix));
+      qm bc = {batch_coeff[4 * b], batch_coeff[4 * b + 1], batch_coeff[4 * b + 2], batch_coeff[4 * b + 3]};
+      row = qadd(qmul(row, bc), qmulc(num, cinv(den)));
+    }
+    out[s] = row.a; out[L + s] = row.b; out[2 * L + s] = row.c; out[3 * L + s] = row.d;
+  }
+}
+
+/* FRI fold of adjacent pairs: dst[i] = [dst[i]*alpha^2 +] (a+b) + alpha*((a-b)*itw[i])  (Appendix A.8) */
+void orc_fold(u32* dst, const u32* src, long src_len, const u32* itw, const u32 alpha[4], int accumulate) {
+  const qm AL = {alpha[0], alpha[1], alpha[2], alpha[3]};
+  const qm AL2 = qmul(AL, AL);
+  const long n = src_len / 2, L = src_len;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n; ++i) {
+    qm a = {src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
+    qm b = {src[2 * i + 1], src[L + 2 * i + 1], src[2 * L + 2 * i + 1], src[3 * L + 2 * i + 1]};
+    qm r = qadd(qadd(a, b), qmul(AL, qmulm(qsub(a, b), itw[i])));
+    if (accumulate) {
+      qm d = {dst[i], dst[n + i], dst[2 * n + i], dst[3 * n + i]};
+      r = qadd(qmul(d, AL2), r);
+    }
+    dst[i] = r.a; dst[n + i] = r.b; dst[2 * n + i] = r.c; dst[3 * n + i] = r.d;
+  }
+}
+
+/* One Merkle layer straight from column pointers (Appendix A.4):
+ * out[i] = blake2s(prev[2i] || prev[2i+1] || cols[0][i] .. cols[ncols-1][i]); prev may be NULL. */
+void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long size, u32* out) {
+  const int npre = prev ? 16 : 0;
+  const int w = npre + ncols;
+  const int nblocks = w == 0 ? 1 : (w + 15) / 16;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < size; ++i) {
+    u32 h[8];
+    for (int k = 0; k < 8; ++k) h[k] = IV[k];
+    h[0] ^= 0x01010020u;
+    for (int b = 0; b < nblocks; ++b) {
+      u32 m[16];
+      for (int k = 0; k < 16; ++k) {
+        int j = 16 * b + k;
+        m[k] = j < npre ? prev[16 * i + j] : (j < w ? cols[j - npre][i] : 0);
+      }
+      int last = b + 1 == nblocks;
+      compress(h, m, last ? (u32)(4 * w) : (u32)(64 * (b + 1)), last ? 0xffffffffu : 0);
+    }
+    memcpy(out + 8 * i, h, 32);
+  }
+}
+
+/* out[i] = 1/v[i] (Montgomery batch inversion in chunks, chunks in parallel) */
+void orc_batch_inverse(const u32* v, long n, u32* out) {
+  const long chunk = 4096;
+#pragma omp parallel for schedule(static)
+  for (long c0 = 0; c0 < n; c0 += chunk) {
+    long c1 = c0 + chunk < n ? c0 + chunk : n;
+    u32 pre[4096];
+    u32 acc = 1;
+    for (long i = c0; i < c1; ++i) { pre[i - c0] = acc; acc = mmul(acc, v[i]); }
+    u32 inv = minv(acc);
+    for (long i = c1; i-- > c0;) { out[i] = mmul(inv, pre[i - c0]); inv = mmul(inv, v[i]); }
+  }
+}

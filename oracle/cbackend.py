@@ -1,0 +1,264 @@
+"""Kernel set over the plain-C restatement (oracle/c/stark_kernels.c) — test infrastructure only.
+
+Same interface as `oracle.prover.NumpyKernels`; columns are uint32 arrays and secure columns are
+coordinate-major (4, L) uint32 arrays.  Every C function is cross-checked against the numpy
+restatement (which is pinned on the reference's known-answer proof) in tests/test_oracle_c.py.
+Used (a) to compare full-size GPU proofs byte-for-byte and (b) as bench.py's `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List
+
+import numpy as np
+
+from .circle import CanonicCoset, LineDomain, coset_order_storage_indices, coset_vanishing_x
+from .fft import domain_twiddles, point_mappings
+from .field import P, QM31, ONE, m_inv_vec
+from .merkle import MerkleTree
+from .prover import prev_row_indices, quotient_batches
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "c", "liboracle_kernels.so")
+U32 = np.uint32
+
+
+def build():
+    src = os.path.join(_HERE, "c", "stark_kernels.c")
+    if not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
+        subprocess.run(["make", "-C", os.path.join(_HERE, "c")], check=True, capture_output=True)
+    return _SO
+
+
+def _q4(q: QM31):
+    return (C.c_uint32 * 4)(*q.v)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CKernels:
+    name = "c"
+
+    def __init__(self, threads: int = 0):
+        self.lib = C.CDLL(build())
+        if threads:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        self._tw = {}
+
+    # ---- twiddles (computed by the numpy restatement of the domain; uploaded as uint32 tables)
+    def _twiddles(self, log_n, inverse):
+        key = (log_n, inverse)
+        if key not in self._tw:
+            tws, itws = domain_twiddles(log_n)
+            arrs = [np.ascontiguousarray(t, dtype=U32) for t in (itws if inverse else tws)]
+            for a, b in zip(arrs, tws):   # forward/inverse tables must be element-wise inverses
+                assert not inverse or int(a[0]) * int(b[0]) % P == 1
+            ptrs = (C.c_void_p * log_n)(*[a.ctypes.data for a in arrs])
+            self._tw[key] = (arrs, ptrs)
+        return self._tw[key][1]
+
+    def _fft(self, data: np.ndarray, log_n: int, inverse: bool):
+        ncols = data.shape[0] if data.ndim == 2 else 1
+        self.lib.orc_circle_fft(_ptr(data), C.c_long(ncols), C.c_int(log_n), self._twiddles(log_n, inverse),
+                                C.c_int(1 if inverse else 0))
+
+    def interpolate_cols(self, cols):
+        cols = [np.asarray(c) for c in cols]
+        out = []
+        i = 0
+        while i < len(cols):      # batch runs of equal size
+            j = i
+            while j < len(cols) and len(cols[j]) == len(cols[i]):
+                j += 1
+            block = np.ascontiguousarray(np.stack(cols[i:j]), dtype=U32)
+            self._fft(block, len(cols[i]).bit_length() - 1, True)
+            out.extend(list(block))
+            i = j
+        return out
+
+    def _evaluate(self, coeffs2d: np.ndarray, log_size: int) -> np.ndarray:
+        n, m = coeffs2d.shape
+        block = np.zeros((n, 1 << log_size), dtype=U32)
+        block[:, :m] = coeffs2d
+        self._fft(block, log_size, False)
+        return block
+
+    def lde(self, coeffs, log_sizes, log_blowup):
+        out = []
+        i = 0
+        while i < len(coeffs):
+            j = i
+            while j < len(coeffs) and log_sizes[j] == log_sizes[i]:
+                j += 1
+            block = self._evaluate(np.stack([np.asarray(c, dtype=U32) for c in coeffs[i:j]]), log_sizes[i] + log_blowup)
+            out.extend(list(block))
+            i = j
+        return out
+
+    def _hash_rows(self, words: np.ndarray) -> np.ndarray:
+        words = np.ascontiguousarray(words, dtype=U32)
+        n, w = words.shape
+        out = np.empty((n, 8), dtype=U32)
+        self.lib.orc_blake2s_rows(_ptr(words), C.c_long(n), C.c_int(w), _ptr(out))
+        return out
+
+    def _merkle_layer(self, prev, cols, size):
+        out = np.empty((size, 8), dtype=U32)
+        cptr = (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+        self.lib.orc_merkle_layer(_ptr(prev) if prev is not None else None, cptr, C.c_int(len(cols)), C.c_long(size),
+                                  _ptr(out))
+        return out
+
+    def merkle(self, cols):
+        return MerkleTree(cols, layer_fn=self._merkle_layer)
+
+    def secure_merkle(self, cols):
+        base = []
+        for c in cols:
+            base.extend([c[k] for k in range(4)])
+        return MerkleTree(base, layer_fn=self._merkle_layer)
+
+    def _inv(self, v):
+        v = np.ascontiguousarray(v, dtype=U32)
+        out = np.empty_like(v)
+        self.lib.orc_batch_inverse(_ptr(v), C.c_long(len(v)), _ptr(out))
+        return out
+
+    def _domain(self, log_size):
+        key = ("dom", log_size)
+        if key not in self._tw:
+            xs, ys = CanonicCoset(log_size).circle_domain().points_bitrev()
+            self._tw[key] = (np.ascontiguousarray(xs, dtype=U32), np.ascontiguousarray(ys, dtype=U32))
+        return self._tw[key]
+
+    def gen_interaction_trace(self, comp, cols, z, alpha):
+        cols = np.ascontiguousarray(cols, dtype=U32)
+        n = cols.shape[1]
+        k = len(comp.relations)
+        P3 = C.c_void_p * k
+        val = P3(*[cols[vc].ctypes.data for (_, (vc, _)) in comp.relations])
+        idp = P3(*[cols[ic].ctypes.data for (_, (_, ic)) in comp.relations])
+        mult = P3(*[cols[mc].ctypes.data for (mc, _) in comp.relations])
+        out = np.empty((4 * k, n), dtype=U32)
+        claimed = (C.c_uint32 * 4)()
+        self.lib.orc_logup_columns(val, idp, mult, C.c_int(k), C.c_long(n), _q4(z), _q4(alpha), _ptr(out), claimed)
+        cl = QM31(*claimed)
+        shift = cl / QM31(n % P)
+        order = np.ascontiguousarray(coset_order_storage_indices(n.bit_length() - 1), dtype=np.int64)
+        last = out[4 * (k - 1):]
+        self.lib.orc_logup_prefix(_ptr(last), C.c_long(n), _ptr(order), _q4(shift))
+        return [out[i] for i in range(4 * k)], cl
+
+    def composition(self, instances, tree1, tree2, z, alpha_rel, powers, n_total):
+        sub = {}
+        k0 = 0
+        for ci in instances:
+            comp = ci.comp
+            e = ci.log_size + 1
+            E = 1 << e
+            nc = comp.n_constraints
+            cp = np.array([powers[n_total - 1 - (k0 + k)].v for k in range(nc)], dtype=U32)
+            k0 += nc
+            main_e = self._evaluate(np.stack([np.asarray(tree1.coeffs[i], dtype=U32) for i in range(*ci.main_span)]), e)
+            inter_e = self._evaluate(np.stack([np.asarray(tree2.coeffs[i], dtype=U32) for i in range(*ci.inter_span)]), e)
+            prev = np.ascontiguousarray(prev_row_indices(ci.log_size, e), dtype=np.int64)
+            zkey = ("zinv", e, ci.log_size)
+            if zkey not in self._tw:
+                xs, _ = self._domain(e)
+                self._tw[zkey] = self._inv(coset_vanishing_x(xs.astype(np.uint64), ci.log_size))
+            zinv = self._tw[zkey]
+            nrel = len(comp.relations)
+            I = C.c_int * nrel
+            rm = I(*[mc for (mc, _) in comp.relations])
+            rv = I(*[vc for (_, (vc, _)) in comp.relations])
+            ri = I(*[ic for (_, (_, ic)) in comp.relations])
+            shift = ci.claimed_sum / QM31((1 << ci.log_size) % P)
+            first = e not in sub
+            if first:
+                sub[e] = np.zeros((4, E), dtype=U32)
+            self.lib.orc_composition(C.c_int(comp.kind), C.c_int(comp.n_cols), C.c_int(nrel), rm, rv, ri, _ptr(main_e),
+                                     _ptr(inter_e), C.c_long(E), _ptr(prev), _q4(z), _q4(alpha_rel), _q4(shift),
+                                     _ptr(cp), _ptr(zinv), _ptr(sub[e]), C.c_int(0 if first else 1))
+        cur = None
+        for e in sorted(sub):
+            vals = sub[e]
+            if cur is not None:
+                ext = self._evaluate(cur, e)
+                vals = ((vals.astype(np.uint64) + ext) % P).astype(U32)
+            vals = np.ascontiguousarray(vals)
+            self._fft(vals, e, True)
+            cur = vals
+        return [cur[k] for k in range(4)]
+
+    def eval_at_point(self, coeffs, pt):
+        coeffs = np.ascontiguousarray(coeffs, dtype=U32)
+        n = len(coeffs).bit_length() - 1
+        maps = np.array([m.v for m in point_mappings(pt[0], pt[1], n)], dtype=U32).reshape(-1, 4)
+        out = (C.c_uint32 * 4)()
+        self.lib.orc_eval_at_point(_ptr(coeffs), C.c_int(n), _ptr(maps), out)
+        return QM31(*out)
+
+    def accumulate_quotients(self, log_size, columns, samples, alpha):
+        L = 1 << log_size
+        cols = [np.ascontiguousarray(c, dtype=U32) for c in columns]
+        batches = quotient_batches(samples)
+        bstart, col_idx, la, lb, lc, pts, bc = [0], [], [], [], [], [], []
+        for (pt, cols_vals) in batches:
+            px, py = pt
+            a_pow = ONE
+            for (ci, val) in cols_vals:
+                a_pow = a_pow * alpha
+                a = val.conj() - val
+                c = py.conj() - py
+                b = val * c - a * py
+                col_idx.append(ci)
+                la.append((a_pow * a).v)
+                lb.append((a_pow * b).v)
+                lc.append((a_pow * c).v)
+            bstart.append(len(col_idx))
+            pts.append(px.v[0:2] + px.v[2:4] + py.v[0:2] + py.v[2:4])
+            bc.append((alpha ** len(cols_vals)).v)
+        xs, ys = self._domain(log_size)
+        out = np.empty((4, L), dtype=U32)
+        cptr = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        arr = lambda v, t: np.ascontiguousarray(np.array(v, dtype=t))
+        bs, cidx = arr(bstart, np.int32), arr(col_idx, np.int32)
+        la_, lb_, lc_, pts_, bc_ = arr(la, U32), arr(lb, U32), arr(lc, U32), arr(pts, U32), arr(bc, U32)
+        self.lib.orc_quotients(cptr, C.c_long(L), C.c_int(len(batches)), _ptr(bs), _ptr(cidx), _ptr(la_), _ptr(lb_),
+                               _ptr(lc_), _ptr(pts_), _ptr(bc_), _ptr(xs), _ptr(ys), _ptr(out))
+        return out
+
+    def fold_circle_into_line(self, dst, src, alpha, log_size):
+        key = ("iy", log_size)
+        if key not in self._tw:
+            self._tw[key] = self._inv(self._domain(log_size)[1][0::2])
+        itw = self._tw[key]
+        n = 1 << (log_size - 1)
+        acc = 1
+        if dst is None:
+            dst = np.zeros((4, n), dtype=U32)
+            acc = 0
+        else:
+            dst = np.ascontiguousarray(dst).copy()
+        self.lib.orc_fold(_ptr(dst), _ptr(np.ascontiguousarray(src)), C.c_long(2 * n), _ptr(itw), _q4(alpha), C.c_int(acc))
+        return dst
+
+    def fold_line(self, vals, alpha, domain: LineDomain):
+        key = ("ix", domain.log_size, domain.coset.initial_index)
+        if key not in self._tw:
+            self._tw[key] = self._inv(domain.xs_bitrev()[0::2])
+        itw = self._tw[key]
+        L = vals.shape[1]
+        dst = np.empty((4, L // 2), dtype=U32)
+        self.lib.orc_fold(_ptr(dst), _ptr(np.ascontiguousarray(vals)), C.c_long(L), _ptr(itw), _q4(alpha), C.c_int(0))
+        return dst
+
+    def secure_len(self, col):
+        return col.shape[1]
+
+    def secure_at(self, col, pos):
+        return QM31(int(col[0, pos]), int(col[1, pos]), int(col[2, pos]), int(col[3, pos]))

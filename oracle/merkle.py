@@ -17,7 +17,9 @@ from .blake2s import blake2s, blake2s_words_vec
 class MerkleTree:
     """layers[k] is a (2^k, 8) uint32 array of node hashes; layers[0] is the root."""
 
-    def __init__(self, columns):
+    def __init__(self, columns, hasher=None, layer_fn=None):
+        """`layer_fn(prev_or_None, cols, size) -> (size, 8) uint32` may replace the numpy layer hashing."""
+        hasher = hasher or blake2s_words_vec
         # stable sort by length descending (stwo: sorted_by_key(Reverse(len)))
         self.columns = [np.ascontiguousarray(c, dtype=np.uint32) for c in columns]
         order = sorted(range(len(self.columns)), key=lambda i: -len(self.columns[i]))
@@ -34,13 +36,17 @@ class MerkleTree:
             while pos < len(self.sorted_columns) and len(self.sorted_columns[pos]) == 1 << log_size:
                 cols.append(self.sorted_columns[pos])
                 pos += 1
+            if layer_fn is not None:
+                prev = layer_fn(prev, cols, 1 << log_size)
+                layers.append(prev)
+                continue
             parts = []
             if prev is not None:
                 parts.append(prev.reshape(1 << log_size, 16))
             if cols:
                 parts.append(np.stack(cols, axis=1))
             words = np.concatenate(parts, axis=1) if parts else np.zeros((1 << log_size, 0), np.uint32)
-            prev = blake2s_words_vec(words)
+            prev = hasher(words)
             layers.append(prev)
         layers.reverse()
         self.layers = layers

@@ -40,18 +40,20 @@ class PcsConfig:
 
 # ----------------------------------------------------------------------------- commitment scheme
 class CommittedTree:
-    def __init__(self, coeffs: List[np.ndarray], log_blowup: int):
-        self.coeffs = [np.asarray(c, dtype=U64) for c in coeffs]
+    def __init__(self, coeffs: List[np.ndarray], log_blowup: int, K=None):
+        K = K or NUMPY_KERNELS
+        self.coeffs = list(coeffs)
         self.log_sizes = [len(c).bit_length() - 1 for c in self.coeffs]
-        self.evals = [evaluate(c, ls + log_blowup) for c, ls in zip(self.coeffs, self.log_sizes)]
-        self.merkle = MerkleTree(self.evals)
+        self.evals = K.lde(self.coeffs, self.log_sizes, log_blowup)
+        self.merkle = K.merkle(self.evals)
 
     def root(self) -> bytes:
         return self.merkle.root()
 
 
-def commit_evals(cols: Sequence[np.ndarray], log_blowup: int) -> CommittedTree:
-    return CommittedTree([interpolate(c) for c in cols], log_blowup)
+def commit_evals(cols: Sequence[np.ndarray], log_blowup: int, K=None) -> CommittedTree:
+    K = K or NUMPY_KERNELS
+    return CommittedTree(K.interpolate_cols(cols), log_blowup, K)
 
 
 # ----------------------------------------------------------------------------- logup
@@ -227,7 +229,7 @@ def fold_positions(positions: List[int], n: int) -> List[int]:
     return out
 
 
-def decommit_positions_and_witness(col: np.ndarray, query_positions: List[int], fold_step: int):
+def decommit_positions_and_witness(col: np.ndarray, query_positions: List[int], fold_step: int, K=None):
     """`compute_decommitment_positions_and_witness_evals` (A.8)."""
     dec, wit = [], []
     i = 0
@@ -241,7 +243,7 @@ def decommit_positions_and_witness(col: np.ndarray, query_positions: List[int], 
             dec.append(pos)
             if pos in subset:
                 continue
-            wit.append(q_to_scalar(col[pos]))
+            wit.append((K or NUMPY_KERNELS).secure_at(col, pos))
     return dec, wit
 
 
@@ -256,6 +258,71 @@ def draw_queries(channel: Blake2sChannel, log_domain_size: int, n_queries: int) 
             cnt += 1
             if cnt == n_queries:
                 return sorted(qs)
+
+
+# ----------------------------------------------------------------------------- kernel sets
+class NumpyKernels:
+    """The per-row work of the prover as vectorised numpy (the KAT-pinned restatement).
+    `oracle/cbackend.py` provides the same interface over the plain-C restatement."""
+    name = "numpy"
+
+    def interpolate_cols(self, cols):
+        return [interpolate(c) for c in cols]
+
+    def lde(self, coeffs, log_sizes, log_blowup):
+        return [evaluate(c, ls + log_blowup) for c, ls in zip(coeffs, log_sizes)]
+
+    def merkle(self, cols):
+        return MerkleTree(cols)
+
+    def gen_interaction_trace(self, comp, cols, z, alpha):
+        return gen_interaction_trace(comp, cols, z, alpha)
+
+    def composition(self, instances, tree1, tree2, z, alpha_rel, powers, n_total):
+        sub: Dict[int, np.ndarray] = {}
+        k0 = 0
+        for ci in instances:
+            e = ci.log_size + 1
+            nc = ci.comp.n_constraints
+            cp = [powers[n_total - 1 - (k0 + k)] for k in range(nc)]
+            k0 += nc
+            main_e = np.stack([evaluate(tree1.coeffs[i], e) for i in range(*ci.main_span)])
+            inter_e = np.stack([evaluate(tree2.coeffs[i], e) for i in range(*ci.inter_span)])
+            val = eval_component_constraints_on_domain(ci, main_e, inter_e, z, alpha_rel, cp, e)
+            sub[e] = q_add(sub[e], val) if e in sub else val
+        cur = None  # coefficient form, (4, 2^e)
+        for e in sorted(sub):
+            vals = sub[e]
+            if cur is not None:
+                vals = q_add(vals, evaluate(cur, e).T)
+            cur = interpolate(np.ascontiguousarray(vals.T))
+        return [cur[k] for k in range(4)]
+
+    def eval_at_point(self, coeffs, pt):
+        return eval_at_point(coeffs, pt)
+
+    def accumulate_quotients(self, log_size, columns, samples, alpha):
+        return accumulate_quotients(log_size, columns, samples, alpha)
+
+    def secure_merkle(self, cols):
+        return secure_merkle(cols)
+
+    def fold_circle_into_line(self, dst, src, alpha, log_size):
+        if dst is None:
+            dst = np.zeros((1 << (log_size - 1), 4), dtype=U64)
+        return fold_circle_into_line(dst, src, alpha, log_size)
+
+    def fold_line(self, vals, alpha, domain):
+        return fold_line(vals, alpha, domain)
+
+    def secure_len(self, col):
+        return col.shape[0]
+
+    def secure_at(self, col, pos):
+        return q_to_scalar(col[pos])
+
+
+NUMPY_KERNELS = NumpyKernels()
 
 
 # ----------------------------------------------------------------------------- prove
@@ -282,17 +349,18 @@ def claim_slots(variant: ProtocolVariant) -> int:
 
 
 def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfig(),
-          variant: ProtocolVariant = ProtocolVariant.KAT, want_trace: bool = False):
+          variant: ProtocolVariant = ProtocolVariant.KAT, want_trace: bool = False, kernels=None):
     """tables: [(kind, AoS rows (n_rows, n_cols) of canonical M31)] in pie order.
 
     Returns LuminairProof (and a ProverTrace if want_trace)."""
+    K = kernels or NUMPY_KERNELS
     tr = ProverTrace()
     channel = Blake2sChannel(variant)
     n_slots = claim_slots(variant)
     lb = config.log_blowup
 
     # PHASE 0: preprocessed trace (no LUT components in the oracle's scope -> empty tree)
-    tree0 = CommittedTree([], lb)
+    tree0 = CommittedTree([], lb, K)
     channel.mix_root(tree0.root())
     tr.digests["root0"] = channel.digest
 
@@ -324,7 +392,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         if claim[kind] is not None:
             channel.mix_u64(claim[kind])
     tr.digests["claims"] = channel.digest
-    tree1 = commit_evals(main_cols, lb)
+    tree1 = commit_evals(main_cols, lb, K)
     channel.mix_root(tree1.root())
     tr.digests["root1"] = channel.digest
 
@@ -342,7 +410,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         if claim[kind] is None:
             continue
         comp, cols = seen[kind]
-        base_cols, claimed = gen_interaction_trace(comp, cols, z, alpha_rel)
+        base_cols, claimed = K.gen_interaction_trace(comp, cols, z, alpha_rel)
         iclaim[kind] = claimed
         # TraceLocationAllocator hands out spans in component (struct) order
         instances.append(ComponentInstance(comp, claim[kind], (main_off, main_off + comp.n_cols),
@@ -353,7 +421,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         if iclaim[kind] is not None:
             channel.mix_felts([iclaim[kind]])
             tr.claimed_sums.append(iclaim[kind])
-    tree2 = commit_evals(inter_cols, lb)
+    tree2 = commit_evals(inter_cols, lb, K)
     channel.mix_root(tree2.root())
     tr.digests["root2"] = channel.digest
 
@@ -365,25 +433,8 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     for _ in range(n_total - 1):
         powers.append(powers[-1] * comp_alpha)
     # composition: per eval-domain size accumulation (DomainEvaluationAccumulator)
-    sub: Dict[int, np.ndarray] = {}
-    k0 = 0
-    for ci in instances:
-        e = ci.log_size + 1
-        nc = ci.comp.n_constraints
-        cp = [powers[n_total - 1 - (k0 + k)] for k in range(nc)]
-        k0 += nc
-        main_e = np.stack([evaluate(tree1.coeffs[i], e) for i in range(*ci.main_span)])
-        inter_e = np.stack([evaluate(tree2.coeffs[i], e) for i in range(*ci.inter_span)])
-        val = eval_component_constraints_on_domain(ci, main_e, inter_e, z, alpha_rel, cp, e)
-        sub[e] = q_add(sub[e], val) if e in sub else val
-    cur = None  # coefficient form, (4, 2^e)
-    for e in sorted(sub):
-        vals = sub[e]
-        if cur is not None:
-            vals = q_add(vals, evaluate(cur, e).T)
-        cur = interpolate(np.ascontiguousarray(vals.T))
-    comp_coeffs = [cur[k] for k in range(4)]
-    tree3 = CommittedTree(comp_coeffs, lb)
+    comp_coeffs = K.composition(instances, tree1, tree2, z, alpha_rel, powers, n_total)
+    tree3 = CommittedTree(comp_coeffs, lb, K)
     channel.mix_root(tree3.root())
     tr.digests["root3"] = channel.digest
     trees = [tree0, tree1, tree2, tree3]
@@ -415,7 +466,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     for ti, tree in enumerate(trees):
         ts = []
         for cidx, coeffs in enumerate(tree.coeffs):
-            ts.append([(pt, eval_at_point(coeffs, pt)) for pt in sample_points[ti][cidx]])
+            ts.append([(pt, K.eval_at_point(coeffs, pt)) for pt in sample_points[ti][cidx]])
         samples.append(ts)
     sampled_values = [[[v for (_, v) in col] for col in ts] for ts in samples]
     channel.mix_felts([v for ts in sampled_values for col in ts for v in col])
@@ -440,12 +491,12 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     quotients = []
     for ls in sizes:
         idx = [i for i, c in enumerate(flat_cols) if len(c) == 1 << ls]
-        qv = accumulate_quotients(ls, [flat_cols[i] for i in idx], [flat_samples[i] for i in idx], quot_alpha)
+        qv = K.accumulate_quotients(ls, [flat_cols[i] for i in idx], [flat_samples[i] for i in idx], quot_alpha)
         quotients.append((ls, qv))
         tr.quotients[ls] = qv
 
     # FRI commit
-    first_tree = secure_merkle([q for _, q in quotients])
+    first_tree = K.secure_merkle([q for _, q in quotients])
     channel.mix_root(first_tree.root())
     tr.fri_roots.append(first_tree.root())
     folding_alpha = channel.draw_felt()
@@ -453,27 +504,27 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     qi = 0
     ls0, q0 = quotients[0]
     layer_log = ls0 - 1
-    layer = fold_circle_into_line(np.zeros((1 << layer_log, 4), dtype=U64), q0, folding_alpha, ls0)
+    layer = K.fold_circle_into_line(None, q0, folding_alpha, ls0)
     line_dom = LineDomain(Coset.half_odds(layer_log))
     qi = 1
     inner = []
     last_size = 1 << (config.log_last_layer + lb)
-    while layer.shape[0] > last_size:
-        mt = secure_merkle([layer])
+    while K.secure_len(layer) > last_size:
+        mt = K.secure_merkle([layer])
         channel.mix_root(mt.root())
         tr.fri_roots.append(mt.root())
         folding_alpha = channel.draw_felt()
         tr.fri_alphas.append(folding_alpha)
         inner.append((layer, mt, layer_log))
-        layer = fold_line(layer, folding_alpha, line_dom)
+        layer = K.fold_line(layer, folding_alpha, line_dom)
         line_dom = line_dom.double()
         layer_log -= 1
         while qi < len(quotients) and quotients[qi][0] - 1 == layer_log:
-            layer = fold_circle_into_line(layer, quotients[qi][1], folding_alpha, quotients[qi][0])
+            layer = K.fold_circle_into_line(layer, quotients[qi][1], folding_alpha, quotients[qi][0])
             qi += 1
     if qi != len(quotients):
         raise ProvingError("FRI: unconsumed columns")
-    coeffs = line_interpolate([q_to_scalar(v) for v in layer], line_dom)
+    coeffs = line_interpolate([K.secure_at(layer, i) for i in range(K.secure_len(layer))], line_dom)
     bound = 1 << config.log_last_layer
     if any(not c.is_zero() for c in coeffs[bound:]):
         raise ProvingError("FRI: invalid degree")
@@ -492,7 +543,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     # first FRI layer
     fw, dec_by_log = [], {}
     for ls, qv in quotients:
-        dpos, wit = decommit_positions_and_witness(qv, positions_by_log[ls], 1)
+        dpos, wit = decommit_positions_and_witness(qv, positions_by_log[ls], 1, K)
         dec_by_log[ls] = dpos
         fw.extend(wit)
     _, hw, cw = first_tree.decommit(dec_by_log)
@@ -500,7 +551,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     inner_proofs = []
     lq = fold_positions(queries, 1)
     for (vals, mt, llog) in inner:
-        dpos, wit = decommit_positions_and_witness(vals, lq, 1)
+        dpos, wit = decommit_positions_and_witness(vals, lq, 1, K)
         _, hw, cw = mt.decommit({llog: dpos})
         inner_proofs.append(FriLayerProof(wit, Decommitment(hw, cw), mt.root()))
         lq = fold_positions(lq, 1)

@@ -47,6 +47,31 @@ def test_gpu_proof_equals_oracle_proof(gpu_prover, name, tabs):
         pytest.fail("%s: proofs differ (len %d vs %d), first difference at byte %d" % (name, len(got), len(want), first))
 
 
+@pytest.fixture(scope="module")
+def c_oracle():
+    from oracle.cbackend import CKernels
+    return CKernels()
+
+
+def test_gpu_full_size_2_20_equals_c_oracle_bytes(gpu_prover, c_oracle):
+    """BASELINE config 2 at FULL size, byte-for-byte: GPU proof == proof of the plain-C restatement
+    (itself pinned on the KAT and cross-checked against the numpy restatement)."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config2_add_only(1 << 20, 42)
+    want = to_bincode(prove(tabs, kernels=c_oracle))
+    got = _gpu_bytes(gpu_prover, tabs)
+    assert got == want
+
+
+def test_gpu_config3_mixed_2_20_total_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
+    """Add 2^19 + Mul 2^18 + Recip 2^18 rows (config 3's shape at 1/4 scale), byte-for-byte."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config3_mixed(19, 18, 18, 8)
+    assert _gpu_bytes(gpu_prover, tabs) == to_bincode(prove(tabs, kernels=c_oracle))
+
+
 def test_gpu_device_resident_rows_give_same_proof(gpu_prover):
     tabs = syn.chain_graph(3000, 11)
     want = _gpu_bytes(gpu_prover, tabs)
