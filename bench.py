@@ -22,6 +22,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+# ALU ceilings measured on MI355X with tools/microbench.hip; informational only
+BLAKE2S_PEAK_GCOMP = 39.0                                  # G compressions/s, chip-wide
+BUTTERFLY_PEAK_G = 1.0 / (1.0 / 6326.0 + 2.0 / 12800.0)    # G butterflies/s = 1 M31 mul + 2 add|sub
 
 
 def parse_args(argv=None):
@@ -175,6 +178,10 @@ def main(argv=None):
         "k_merkle_fused": (tm["merkle_ms"], tm["merkle_bytes"], tm["merkle_launches"],
                            ["k_merkle_fused", "k_merkle_small", "k_fri_tail"]),
     }
+    alu = {
+        "k_fft_staged": (tm["fft_butterflies"], BUTTERFLY_PEAK_G, "G butterflies/s"),
+        "k_merkle_fused": (tm["merkle_compressions"], BLAKE2S_PEAK_GCOMP, "G Blake2s compressions/s"),
+    }
 
     def roof(name):
         ms, nbytes, launches, pmc_names = fams[name]
@@ -185,9 +192,13 @@ def main(argv=None):
         if got:
             tot_l = sum(g["launches"] for g in got)
             traffic = sum(g["hbm_bytes_per_launch_corrected"] * g["launches"] for g in got) / max(tot_l, 1)
+        ops, alu_peak, alu_unit = alu[name]
+        alu_achieved = ops / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches_per_proof": launches,
-                "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": nbytes / launches}
+                "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": nbytes / launches,
+                "alu_ceiling": {"achieved": alu_achieved, "peak_measured": alu_peak, "unit": alu_unit,
+                                "frac": alu_achieved / alu_peak}}
 
     dom = max(fams, key=lambda k: fams[k][0])
     roofline = roof(dom)

@@ -96,6 +96,8 @@ typedef struct lmn_timings {
   uint64_t fft_bytes;    /* algorithmic bytes moved by those FFT launches (8 B per element per transform) */
   uint64_t merkle_bytes; /* algorithmic bytes of the Merkle launches */
   uint32_t fft_launches, merkle_launches;
+  uint64_t fft_butterflies;      /* M31 butterflies (1 mul + 1 add + 1 sub) executed by those FFT launches */
+  uint64_t merkle_compressions;  /* Blake2s compression-function calls executed by the Merkle launches */
 } lmn_timings;
 
 const char* lmn_strerror(int code);

@@ -35,6 +35,15 @@ void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32
 void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
                          lmn_stream_t s);
 
+// ---- device-resident channel (FRI commit loop): digest <- H(digest || root); alpha <- draw_felt()
+struct DevChannel {
+  uint32_t digest[8];
+  uint32_t n_sent;
+  uint32_t variant;
+};
+void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
+                               lmn_stream_t s);
+
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.
 constexpr int MERKLE_MAX_SEG = 4;
@@ -50,17 +59,11 @@ struct MerkleLevels {
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s);
 // one block, size <= 1024 start nodes, nfused <= 10
+// If `ch` is given and this launch reaches the root, it also mixes the root into the device channel
+// and draws the next felt (saves a launch per FRI layer).
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                         const MerkleLevels& outs, int nfused, lmn_stream_t s);
-
-// ---- device-resident channel (FRI commit loop): digest <- H(digest || root); alpha <- draw_felt()
-struct DevChannel {
-  uint32_t digest[8];
-  uint32_t n_sent;
-  uint32_t variant;
-};
-void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
-                               lmn_stream_t s);
+                         const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
+                         lmn_stream_t s);
 
 // FRI tail: layers of log size first_log, first_log-1, ... (n_layers of them, all <= 2^10) committed
 // and folded in one single-block launch.  layers[li].next is the evaluation buffer of the next layer.

@@ -555,41 +555,6 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub, cur);
 }
 
-// Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
-constexpr int MERKLE_SMALL_BLOCK = 1024;
-LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
-                          MerkleLevels outs, int nfused) {
-  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
-  const uint32_t i = threadIdx.x;
-  uint32_t cur[8];
-  if (i < size) {
-    merkle_hash_start(prev, sg, ncols, size, i, cur);
-    store_hash(outs.p[0] + (uint64_t)i * 8, cur);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
-  }
-  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size, cur);
-}
-
-void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s) {
-  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
-  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
-      size % ((uint32_t)TPB << sub) != 0)
-    throw LmnError(-100, "merkle_fused: bad arguments");
-  LMN_LAUNCH(k_merkle_fused, dim3(cdiv(size >> sub, TPB)), dim3(TPB), 0, s, prev, sg, ncols, size, outs, sub, nfused);
-}
-
-void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                         const MerkleLevels& outs, int nfused, lmn_stream_t s) {
-  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
-  if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
-  LMN_LAUNCH(k_merkle_small, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, prev, sg, ncols, size, outs, nfused);
-}
-
-// =============================================================================================
-// Device-resident Fiat-Shamir steps for the FRI commit loop (no host round trip per layer)
-// =============================================================================================
 LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
   uint32_t m[16];
 #pragma unroll
@@ -604,9 +569,8 @@ LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
   ch->n_sent += 1u;
 }
 
-LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ root, QM31* out_alpha,
-                                uint32_t* root_copy) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// digest <- H(digest || root); alpha <- draw_felt(); executed by ONE lane
+LMN_D void chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy) {
   uint32_t m[16], h[8];
   for (int k = 0; k < 8; ++k) {
     m[k] = ch->digest[k];
@@ -631,6 +595,54 @@ LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ roo
     *out_alpha = a;
     break;
   }
+}
+
+// Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
+constexpr int MERKLE_SMALL_BLOCK = 1024;
+LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
+                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
+  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  const uint32_t i = threadIdx.x;
+  uint32_t cur[8];
+  if (i < size) {
+    merkle_hash_start(prev, sg, ncols, size, i, cur);
+    store_hash(outs.p[0] + (uint64_t)i * 8, cur);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+  }
+  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size, cur);
+  // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
+  if (ch != nullptr && (size >> nfused) == 1u) {
+    __syncthreads();
+    if (i == 0) chan_mix_root_draw(ch, sh, alpha_out, root_copy);
+  }
+}
+
+void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
+      size % ((uint32_t)TPB << sub) != 0)
+    throw LmnError(-100, "merkle_fused: bad arguments");
+  LMN_LAUNCH(k_merkle_fused, dim3(cdiv(size >> sub, TPB)), dim3(TPB), 0, s, prev, sg, ncols, size, outs, sub, nfused);
+}
+
+void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
+                         lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
+  LMN_LAUNCH(k_merkle_small, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, prev, sg, ncols, size, outs, nfused, ch,
+             alpha_out, root_copy);
+}
+
+// =============================================================================================
+// Device-resident Fiat-Shamir steps for the FRI commit loop (no host round trip per layer)
+// =============================================================================================
+LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ root, QM31* out_alpha,
+                                uint32_t* root_copy) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  chan_mix_root_draw(ch, root, out_alpha, root_copy);
 }
 
 void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
@@ -688,32 +700,8 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
     }
     __syncthreads();
     if (i == 0) {
-      // channel: digest <- H(digest || root); alpha <- draw_felt()
-      uint32_t m[16], h[8];
-      for (int k = 0; k < 8; ++k) {
-        m[k] = ch->digest[k];
-        m[8 + k] = sh[k];
-        roots_out[li * 8 + k] = sh[k];
-      }
-      b2_init(h);
-      b2_compress(h, m, 64u, 0xffffffffu);
-      for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
-      ch->n_sent = 0u;
-      for (;;) {
-        uint32_t w[8];
-        chan_draw_words(ch, w);
-        bool ok = true;
-        for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
-        if (!ok) continue;
-        QM31 a;
-        a.a = w[0] >= P31 ? w[0] - P31 : w[0];
-        a.b = w[1] >= P31 ? w[1] - P31 : w[1];
-        a.c = w[2] >= P31 ? w[2] - P31 : w[2];
-        a.d = w[3] >= P31 ? w[3] - P31 : w[3];
-        s_alpha = a;
-        alphas_out[li] = a;
-        break;
-      }
+      chan_mix_root_draw(ch, sh, &alphas_out[li], roots_out + li * 8);
+      s_alpha = alphas_out[li];
     }
     __syncthreads();
     const QM31 alpha = s_alpha;

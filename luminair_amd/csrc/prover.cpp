@@ -5,6 +5,7 @@
 #include "prover.h"
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <map>
 #include <set>
@@ -272,12 +273,14 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
   launch_merkle_layer(prev, cols, ncols, size, out, stream_);
   timings.merkle_launches++;
   timings.merkle_bytes += (uint64_t)size * (4ull * ncols + 32ull + (prev ? 64ull : 0ull));
+  timings.merkle_compressions += (uint64_t)size * std::max<uint64_t>(1, ((prev ? 16 : 0) + (uint64_t)ncols + 15) / 16);
 }
 
 // Merkle tree over columns sorted by size (descending, stable): SURVEY.md Appendix A.4.
 // Levels are produced by fused subtree launches: a start level (children hashes and/or its own
 // columns) plus up to 8 following levels that have no columns of their own.
-void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted) {
+void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
+                           DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].second;
   m.layers.assign(m.max_log + 1, nullptr);
   if (cols_sorted.empty()) {
@@ -288,6 +291,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
   // columns per level
   std::vector<std::vector<const uint32_t*>> per_level(m.max_log + 1);
   for (auto& c : cols_sorted) per_level[c.second].push_back(c.first);
+  bool chan_done = false;
   {
     StageTimer t(this, g_log(this), stream_, C_MERKLE);
     const uint32_t* prev = nullptr;
@@ -325,7 +329,10 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
       if (level <= 10) {
         nfused = std::min(plain, 10);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
-        launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, stream_);
+        bool to_root = level - nfused == 0;
+        launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, to_root ? ch : nullptr, alpha_out,
+                            root_copy, stream_);
+        if (to_root && ch) chan_done = true;
       } else {
         nfused = std::min(std::min(plain, MERKLE_MAX_FUSED), level - 10);
         // per-lane subtree depth: only as deep as still leaves >= 2^17 lanes (latency-bound below that)
@@ -338,10 +345,16 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
       timings.merkle_launches++;
       timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
       for (int l = 1; l <= nfused; ++l) timings.merkle_bytes += ((uint64_t)1 << (level - l)) * 96ull;
+      {
+        uint64_t words = (prev ? 16 : 0) + lc.size();
+        timings.merkle_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
+        for (int l = 1; l <= nfused; ++l) timings.merkle_compressions += (uint64_t)1 << (level - l);
+      }
       prev = m.layers[level - nfused];
       level -= nfused + 1;
     }
   }
+  if (ch && !chan_done) launch_chan_mix_root_draw(ch, m.layers[0], alpha_out, root_copy, stream_);
 }
 
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches)
@@ -361,6 +374,7 @@ void Context::lde_and_merkle(DevTree& tree) {
       StageTimer t(this, g_log(this), stream_, C_FFT);
       timings.fft_launches += launch_fft(lde, L, tree.cols[i].coeffs, n, log, ncols, log + lb, tw(log + lb), stream_);
       timings.fft_bytes += (uint64_t)ncols * (4ull * n + 4ull * L);
+      timings.fft_butterflies += (uint64_t)ncols * (L / 2) * (uint64_t)(log + lb);
     }
     for (int c = 0; c < ncols; ++c) tree.cols[i + c].lde = lde + (uint64_t)c * L;
     i = j;
@@ -560,6 +574,20 @@ static void plan_fri_witness(const uint32_t* col, uint64_t len, const std::vecto
   }
 }
 
+// optional host-side wall-clock marks (LMN_HOST_PROFILE=1), printed to stderr
+struct HostMarks {
+  bool on = getenv("LMN_HOST_PROFILE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  void mark(const char* what) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host] %-28s +%8.1f us  (t=%8.1f)\n", what,
+            std::chrono::duration<double, std::micro>(now - last).count(),
+            std::chrono::duration<double, std::micro>(now - t0).count());
+    last = now;
+  }
+};
+
 // ------------------------------------------------------------------------------------ prove
 std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
 #ifndef LMN_EMU
@@ -569,6 +597,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   if (settings && settings->has_lookups) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "lookup tables are out of scope");
   const int lb = (int)cfg.log_blowup;
   const int n_slots = cfg.protocol_variant == LMN_VARIANT_KAT ? 8 : 17;
+  HostMarks hm;
   EventLog* log = g_log(this);
   log->reset();
   memset(&timings, 0, sizeof timings);
@@ -671,6 +700,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_ifft(coeffs, n, ci.trace_evals, n, nc, ci.log_size, itw(ci.log_size), stream_);
         timings.fft_bytes += (uint64_t)nc * 8ull * n;
+        timings.fft_butterflies += (uint64_t)nc * (n / 2) * (uint64_t)ci.log_size;
       }
       ci.main_start = off;
       off += nc;
@@ -725,6 +755,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_ifft(ievals, n, ievals, n, nic, ci.log_size, itw(ci.log_size), stream_);
         timings.fft_bytes += (uint64_t)nic * 8ull * n;
+        timings.fft_butterflies += (uint64_t)nic * (n / 2) * (uint64_t)ci.log_size;
       }
       for (int c = 0; c < nic; ++c) tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, nullptr});
     }
@@ -799,12 +830,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_fft(ext, E, cur, 1ull << cur_log, cur_log, 4, e, tw(e), stream_);
         timings.fft_bytes += 4ull * (4ull << cur_log) + 4ull * 4ull * E;
+        timings.fft_butterflies += 4ull * (E / 2) * (uint64_t)e;
         launch_secure_add(vals, ext, 4 * E, stream_);
       }
       {
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_ifft(vals, E, vals, E, 4, e, itw(e), stream_);
         timings.fft_bytes += 4ull * 8ull * E;
+        timings.fft_butterflies += 4ull * (E / 2) * (uint64_t)e;
       }
       cur = vals;
       cur_log = e;
@@ -985,8 +1018,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
     uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);
     int n_roots = 0;
-    build_merkle(first_merkle, first_cols);
-    launch_chan_mix_root_draw(d_ch, first_merkle.layers[0], d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+    build_merkle(first_merkle, first_cols, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots);
     ++n_roots;
     int layer_log = ls0 - 1;
     uint32_t* layer = arena_.alloc_words(4ull << layer_log);
@@ -1018,6 +1050,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
           StageTimer t(this, log, stream_, C_MERKLE);
           launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
         }
+        for (int li = 0; li < n_tail; ++li) timings.merkle_compressions += (2ull << (layer_log - li));
         n_roots += n_tail;
         layer_log = last_size_log;
         break;
@@ -1027,8 +1060,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       fl.vals = layer;
       std::vector<std::pair<const uint32_t*, int>> lc;
       for (int k = 0; k < 4; ++k) lc.push_back({layer + ((uint64_t)k << layer_log), layer_log});
-      build_merkle(fl.merkle, lc);
-      launch_chan_mix_root_draw(d_ch, fl.merkle.layers[0], d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+      build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots);
       ++n_roots;
       const QM31* d_alpha = d_alphas + (n_roots - 1);
       uint32_t* next = arena_.alloc_words(4ull << (layer_log - 1));
@@ -1043,6 +1075,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         ++qi;
       }
     }
+    hm.mark("fri enqueued");
     // one sync: roots + alphas back, then replay the transcript on the host channel
     const uint32_t* h_roots = (const uint32_t*)stage_download(d_roots, (size_t)n_roots * 32);
     const QM31* h_alphas = (const QM31*)stage_download(d_alphas, (size_t)n_roots * sizeof(QM31));
@@ -1066,6 +1099,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       if (!q_eq(a, h_alphas[r])) throw LmnError(LMN_ERR_INTERNAL, "device/host transcript divergence in FRI");
     }
   }
+  hm.mark("fri synced+replayed");
   // last layer: interpolate the line evaluation (bit-reversed over LineDomain(half_odds(last_log)))
   {
     std::vector<std::vector<QM31>> chunks{last_vals};
@@ -1111,6 +1145,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     channel.mix_felts(coeffs);
   }
 
+  hm.mark("last layer");
   // ---- proof of work + queries
   proof.proof_of_work = channel.grind(cfg.pow_bits);
   channel.mix_u64(proof.proof_of_work);
@@ -1129,6 +1164,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   std::map<int, std::vector<uint32_t>> pos_by_log;
   for (int ls : sizes) pos_by_log[ls] = fold_positions(queries, ls0 - ls);
 
+  hm.mark("pow+queries");
   // ---- decommitment: plan device references, gather once, distribute
   {
     StageTimer st(this, log, stream_, C_DECOMMIT);
@@ -1186,6 +1222,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     if (!entries.empty()) {
       GatherEntry* d_e = upload_vec(entries);
       uint32_t* d_o = arena_.alloc_words(out_words);
+      hm.mark("decommit planned");
       launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
       gathered = (const uint32_t*)stage_download(d_o, (size_t)out_words * 4);
       lmn_sync(stream_);
@@ -1234,6 +1271,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       proof.decommitments.push_back(d);
     }
   }
+  hm.mark("decommit done");
   total_guard.reset();
   lmn_sync(stream_);
 

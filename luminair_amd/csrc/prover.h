@@ -89,7 +89,8 @@ class Context {
   TwPtrs itw(int domain_log) const;
   // commit `cols` (coefficients already in place) -> LDE + Merkle
   void lde_and_merkle(DevTree& tree);
-  void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted);
+  void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
+                    DevChannel* ch = nullptr, QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
 
