@@ -60,12 +60,21 @@ inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) { LMN_HIP_CHE
 // Spin on hipStreamQuery instead of blocking in hipStreamSynchronize: the prover synchronises 6
 // times per proof and the blocking wake-up latency (tens of microseconds) would sit on the critical path.
 inline void lmn_sync(lmn_stream_t s) {
-  for (;;) {
+  static const int mode = getenv("LMN_SYNC_MODE") ? atoi(getenv("LMN_SYNC_MODE")) : 0;  // 0 spin, 1 block, 2 hybrid
+  if (mode == 1) {
+    LMN_HIP_CHECK(hipStreamSynchronize(s));
+    return;
+  }
+  for (int it = 0;; ++it) {
     hipError_t e = hipStreamQuery(s);
     if (e == hipSuccess) return;
     if (e != hipErrorNotReady) LMN_HIP_CHECK(e);
+    if (mode == 2 && it > 64) {
+      LMN_HIP_CHECK(hipStreamSynchronize(s));
+      return;
+    }
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+    for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
 #endif
   }
 }
