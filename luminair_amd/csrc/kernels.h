@@ -108,7 +108,7 @@ int logup_scan_num_blocks(int log_size);
 
 // ---- a7: constraint quotients on the eval domain (log_size + 1)
 struct CompositionArgs {
-  int kind;                    // TraceTable kind (0 add, 1 mul, 2 recip, 15 inputs)
+  int kind;                    // TraceTable kind (0 add, 1 mul, 2 recip, 5 sum_reduce, 6 max_reduce, 15 inputs, 16 contiguous)
   int log_size;                // trace log size
   int eval_log;                // eval domain log size
   const uint32_t* main;        // main columns on the eval domain, stride 2^eval_log

@@ -114,6 +114,7 @@ struct FftStagePlan {
   int nst;
   int first[FFT_MAX_STAGES];  // first layer of each stage, ascending
   int R[FFT_MAX_STAGES];      // layers per stage (1..4)
+  int xcd_swizzle;
 };
 
 LMN_HD uint32_t fft_lds_pad(uint32_t e) { return e + (e >> 5); }
@@ -213,7 +214,11 @@ template <bool INV>
 LMN_KERNEL k_fft_staged(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride,
                         uint64_t src_len, FftStagePlan pl, TwPtrs tw, uint32_t scale, int ncols, int cpb) {
   LMN_DYN_SMEM(uint32_t, sm);
-  const uint32_t tile = blockIdx.x;
+  // XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8 XCDs (observed, used
+  // for speed only), so give each XCD a contiguous run of tiles: neighbouring strided tiles share
+  // 128-byte lines and then hit the same L2.
+  uint32_t tile = blockIdx.x;
+  if (pl.xcd_swizzle && (gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint32_t q = tile & ((1u << (pl.lo - pl.cb)) - 1u);
   const uint32_t H = tile >> (pl.lo - pl.cb);
   const uint64_t base = ((uint64_t)H << pl.hi) + ((uint64_t)q << pl.cb);
@@ -305,6 +310,8 @@ static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uin
     pl.hi = p.hi;
     pl.cb = p.cb;
     split_stages(pl);
+    static const int env_xcd = getenv("LMN_FFT_XCD") ? atoi(getenv("LMN_FFT_XCD")) : 1;
+    pl.xcd_swizzle = (env_xcd && p.cb > 0) ? 1 : 0;
     uint32_t tile_elems = 1u << (rbits + p.cb);
     size_t smem = (size_t)4 * (tile_elems + (tile_elems >> 5) + 1);
     // several columns per block when there are plenty of tiles: twiddles stay hot in L1/L2
@@ -474,8 +481,10 @@ LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
   o4[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
-// LDS climb shared by both kernels: `n_here` hashes of this block sit in sh[idx*8..]; levels
-// first..last are produced (level l has lvl_size0 >> (l - first + 1) nodes in total).
+// LDS climb shared by the Merkle kernels: `lvl_size` hashes of this block sit in sh[idx*8..]; levels
+// first..last are produced, one lane per parent.  (A 4-lane cooperative, DPP-rotated Blake2s was
+// tried for the narrow levels: no faster — one lane already interleaves the four independent G
+// functions of each half-round, so a level costs ~1 us of issue plus two barriers either way.)
 template <int BLOCK>
 LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, int last, uint32_t lvl_size,
                             uint32_t cur[8]) {
@@ -1030,6 +1039,33 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     logup_constraints<2>(ca, a, rm, rv, ri, s, E);
+  } else if (KIND == 5 || KIND == 6 || KIND == 16) {
+    // SumReduce (14 cols) / MaxReduce (15) / Contiguous (11): shared id/idx prefix, 2 relations
+    const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
+    const uint32_t n_node = LMN_COL(4), n_in = LMN_COL(5), n_idx = LMN_COL(6);
+    const uint32_t inp = LMN_COL(7), out = LMN_COL(8);
+    constexpr int mo = KIND == 5 ? 12 : (KIND == 6 ? 13 : 9);
+    const uint32_t m0 = LMN_COL(mo), m1 = LMN_COL(mo + 1);
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    if (KIND == 5) {
+      const uint32_t acc = LMN_COL(9), next_acc = LMN_COL(10), ils = LMN_COL(11);
+      ca.add_m(m_mul(ils, m_sub(ils, 1u)));
+      ca.add_m(m_sub(next_acc, m_add(acc, inp)));
+      ca.add_m(m_mul(m_sub(out, next_acc), ils));
+    } else if (KIND == 6) {
+      const uint32_t mx = LMN_COL(9), next_mx = LMN_COL(10), ils = LMN_COL(11), im = LMN_COL(12);
+      ca.add_m(m_mul(ils, m_sub(ils, 1u)));
+      ca.add_m(m_mul(im, m_sub(im, 1u)));
+      ca.add_m(m_mul(im, m_sub(next_mx, inp)));
+      ca.add_m(m_mul(m_sub(1u, im), m_sub(next_mx, mx)));
+      ca.add_m(m_mul(m_sub(out, next_mx), ils));
+    }
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
+    logup_constraints<2>(ca, a, rm, rv, ri, s, E);
   } else {
     const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
     const uint32_t val = LMN_COL(5), mult = LMN_COL(6);
@@ -1062,7 +1098,10 @@ void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
     case 0: LMN_LAUNCH(k_composition<0>, g, b, 0, s, a); break;
     case 1: LMN_LAUNCH(k_composition<1>, g, b, 0, s, a); break;
     case 2: LMN_LAUNCH(k_composition<2>, g, b, 0, s, a); break;
+    case 5: LMN_LAUNCH(k_composition<5>, g, b, 0, s, a); break;
+    case 6: LMN_LAUNCH(k_composition<6>, g, b, 0, s, a); break;
     case 15: LMN_LAUNCH(k_composition<15>, g, b, 0, s, a); break;
+    case 16: LMN_LAUNCH(k_composition<16>, g, b, 0, s, a); break;
     default: throw LmnError(-100, "composition: unsupported component kind");
   }
 }

@@ -19,6 +19,10 @@ static const ComponentSpec kSpecs[] = {
     {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7},
     {LMN_KIND_RECIP, 13, 3, 2, {11, 12, 0}, {7, 8, 0}, {1, 0, 0}, 5},
     {LMN_KIND_INPUTS, 7, 2, 1, {6, 0, 0}, {5, 0, 0}, {0, 0, 0}, 3},
+    // constraint forms fully visible in the reference (no numerair helper):
+    {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13, 0}, {7, 8, 0}, {1, 0, 0}, 7},   // sum_reduce/component.rs:36-110
+    {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14, 0}, {7, 8, 0}, {1, 0, 0}, 9},   // max_reduce/component.rs
+    {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10, 0}, {7, 8, 0}, {1, 0, 0}, 4},    // contiguous/component.rs
 };
 const ComponentSpec* component_spec(int kind) {
   for (auto& s : kSpecs)
@@ -422,11 +426,30 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
     out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
     out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
-  } else {
+  } else if (kind == LMN_KIND_INPUTS) {
     QM31 is_last = c[2], not_last = one_minus(is_last);
     out.push_back(q_mul(is_last, qsub1(is_last)));
     out.push_back(q_mul(not_last, q_sub(c[3], c[0])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[4], c[1]))));
+  } else {  // SumReduce / MaxReduce / Contiguous share the id/idx prefix (columns 0..6)
+    QM31 is_last = c[3], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    if (kind == LMN_KIND_SUM_REDUCE) {
+      QM31 ils = c[11];
+      out.push_back(q_mul(ils, qsub1(ils)));
+      out.push_back(q_sub(c[10], q_add(c[9], c[7])));
+      out.push_back(q_mul(q_sub(c[8], c[10]), ils));
+    } else if (kind == LMN_KIND_MAX_REDUCE) {
+      QM31 ils = c[11], im = c[12];
+      out.push_back(q_mul(ils, qsub1(ils)));
+      out.push_back(q_mul(im, qsub1(im)));
+      out.push_back(q_mul(im, q_sub(c[10], c[7])));
+      out.push_back(q_mul(one_minus(im), q_sub(c[10], c[9])));
+      out.push_back(q_mul(q_sub(c[8], c[10]), ils));
+    }
+    out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
   }
   return out;
 }

@@ -15,6 +15,7 @@ import numpy as np
 P = (1 << 31) - 1
 SCALE = 1 << 12
 KIND_ADD, KIND_MUL, KIND_RECIP, KIND_INPUTS = 0, 1, 2, 15
+KIND_SUM_REDUCE, KIND_MAX_REDUCE, KIND_CONTIGUOUS = 5, 6, 16
 
 
 def to_m31(v: np.ndarray) -> np.ndarray:
@@ -73,6 +74,74 @@ def inputs_rows(vals, node, multiplicity) -> np.ndarray:
     last = (idx == n - 1).astype(np.int64)
     cols = [np.full(n, node), idx, last, np.full(n, node), idx + 1, to_m31(vals), np.full(n, multiplicity % P)]
     return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def _reduce_common(x, node, input_id):
+    """x: (n_out, dim) int64.  One row per INPUT element, idx = output index (prim.rs:1486-1510)."""
+    n_out, dim = x.shape
+    idx = np.repeat(np.arange(n_out, dtype=np.int64), dim)
+    last = (idx == n_out - 1).astype(np.int64)
+    step_last = np.tile((np.arange(dim) == dim - 1).astype(np.int64), n_out)
+    n = n_out * dim
+    head = [np.full(n, node), np.full(n, input_id), idx, last, np.full(n, node), np.full(n, input_id), idx + 1]
+    return head, step_last
+
+
+def sum_reduce_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndarray:
+    """`LuminairSumReduce::process_trace` (crates/graph/src/op/prim.rs:1514-1565)."""
+    x = np.asarray(x, np.int64)
+    head, step_last = _reduce_common(x, node, input_id)
+    next_acc = np.cumsum(x, axis=1)
+    acc = next_acc - x
+    out = (next_acc * (np.arange(x.shape[1]) == x.shape[1] - 1)).reshape(-1)
+    cols = head + [to_m31(x.reshape(-1)), to_m31(out), to_m31(acc.reshape(-1)), to_m31(next_acc.reshape(-1)),
+                   step_last, np.full(x.size, input_mult % P), (out_mult * step_last) % P]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def max_reduce_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndarray:
+    """`LuminairMaxReduce::process_trace` (crates/graph/src/op/prim.rs:1591-1734): running max starts at
+    the first element; is_max marks rows whose input becomes the new running max."""
+    x = np.asarray(x, np.int64)
+    head, step_last = _reduce_common(x, node, input_id)
+    n_out, dim = x.shape
+    next_max = np.maximum.accumulate(x, axis=1)
+    mx = np.concatenate([x[:, :1], next_max[:, :-1]], axis=1)     # max_val before this step
+    is_max = (x > mx).astype(np.int64)       # strict, as in prim.rs:1638-1642
+    out = (next_max * (np.arange(dim) == dim - 1)).reshape(-1)
+    cols = head + [to_m31(x.reshape(-1)), to_m31(out), to_m31(mx.reshape(-1)), to_m31(next_max.reshape(-1)),
+                   step_last, is_max.reshape(-1), np.full(x.size, input_mult % P), (out_mult * step_last) % P]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def contiguous_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndarray:
+    """`LuminairContiguous::process_trace` (crates/graph/src/op/prim.rs:229-301): out = input."""
+    x = np.asarray(x, np.int64).reshape(-1)
+    n = len(x)
+    idx = np.arange(n, dtype=np.int64)
+    cols = [np.full(n, node), np.full(n, input_id), idx, (idx == n - 1).astype(np.int64), np.full(n, node),
+            np.full(n, input_id), idx + 1, to_m31(x), to_m31(x), np.full(n, input_mult % P), np.full(n, out_mult % P)]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def linear_layer(n_out: int, dim: int, seed: int = 42, with_max: bool = False) -> List[Tuple[int, np.ndarray]]:
+    """y = sum_k(x[k] * w[j][k]) + b[j] — the Mul + SumReduce + Add lowering of a linear layer
+    (BASELINE config 5's building block), KAT-era multiplicities (initializers consumed with mult 0):
+    Mul (node 3) yields each product once, SumReduce (node 4) consumes them and yields y' once,
+    Add (node 5) consumes y' [optionally MaxReduce (node 6) consumes the Add outputs]."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 2048, size=(n_out, dim))
+    w = rng.integers(0, 2048, size=(n_out, dim))
+    b = rng.integers(-2048, 2048, size=n_out)
+    prod = (x * w) >> 12
+    y1 = prod.sum(axis=1)
+    y = y1 + b
+    tabs = [(KIND_ADD, add_rows(y1, b, node=5, lhs_id=4, rhs_id=9, mults=(-1, 0, 1 if with_max else 0))),
+            (KIND_MUL, mul_rows(x.reshape(-1), w.reshape(-1), node=3, lhs_id=7, rhs_id=8, mults=(0, 0, 1))),
+            (KIND_SUM_REDUCE, sum_reduce_rows(prod, node=4, input_id=3, input_mult=-1, out_mult=1))]
+    if with_max:
+        tabs.append((KIND_MAX_REDUCE, max_reduce_rows(y.reshape(1, -1), node=6, input_id=5, input_mult=-1, out_mult=0)))
+    return tabs
 
 
 def config2_add_only(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:

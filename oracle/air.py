@@ -5,6 +5,10 @@ Row layouts, padding rows, constraint order and logup relations restate
   Mul    `crates/air/src/components/mul/{table.rs:19-36, component.rs:40-126, witness.rs:18-165}`
   Recip  `crates/air/src/components/recip/{table.rs:20-54, component.rs:38-107}`
   Inputs `crates/air/src/components/inputs/{table.rs:20-44, components.rs:37-85}`
+  SumReduce  `crates/air/src/components/sum_reduce/{table.rs:39-56,173-186, component.rs:36-110}`
+  MaxReduce  `crates/air/src/components/max_reduce/{table.rs:39-57,178-192, component.rs}`
+  Contiguous `crates/air/src/components/contiguous/{table.rs:36-50,162-172, component.rs}`
+(the last three use no numerair helper: their constraint forms are fully visible in the reference)
 `eval_fixed_{add,mul,recip}` live in numerair@11d1d26 (un-vendored).  KAT evidence (SURVEY.md §2.1,
 A.7) pins: eval_fixed_add = 1 constraint `out-(lhs+rhs)`; eval_fixed_mul = 2 constraint slots, the
 first `lhs*rhs-(out*scale+rem)`, the second contributing zero whenever rem == 0 — restated here as
@@ -120,6 +124,30 @@ def _inputs_local(c):
     return [is_last * (is_last - 1), not_last * (n_node - node), not_last * (n_idx - idx - 1)]
 
 
+def _sum_reduce_local(c):
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, inp, out, acc, next_acc, is_last_step, _im, _om) = c
+    cons = [is_last * (is_last - 1), is_last_step * (is_last_step - 1), next_acc - (acc + inp),
+            (out - next_acc) * is_last_step]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+    return cons
+
+
+def _max_reduce_local(c):
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, inp, out, mx, next_mx, is_last_step, is_max, _im, _om) = c
+    cons = [is_last * (is_last - 1), is_last_step * (is_last_step - 1), is_max * (is_max - 1),
+            is_max * (next_mx - inp), (1 - is_max) * (next_mx - mx), (out - next_mx) * is_last_step]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+    return cons
+
+
+def _contiguous_local(c):
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, _inp, _out, _im, _om) = c
+    not_last = 1 - is_last
+    return [is_last * (is_last - 1)] + _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+
+
 def _pad(n, is_last_col):
     p = [0] * n
     p[is_last_col] = 1
@@ -135,7 +163,14 @@ RECIP = Component("recip", KIND_RECIP, 13, _pad(13, 3), _recip_local,
 INPUTS = Component("inputs", KIND_INPUTS, 7, _pad(7, 2), _inputs_local,
                    ((6, (5, 0)),))
 
-COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS)}
+SUM_REDUCE = Component("sum_reduce", KIND_SUM_REDUCE, 14, _pad(14, 3), _sum_reduce_local,
+                       ((12, (7, 1)), (13, (8, 0))))
+MAX_REDUCE = Component("max_reduce", KIND_MAX_REDUCE, 15, _pad(15, 3), _max_reduce_local,
+                       ((13, (7, 1)), (14, (8, 0))))
+CONTIGUOUS = Component("contiguous", KIND_CONTIGUOUS, 11, _pad(11, 3), _contiguous_local,
+                       ((9, (7, 1)), (10, (8, 0))))
+
+COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS, SUM_REDUCE, MAX_REDUCE, CONTIGUOUS)}
 
 
 def pad_table(comp: Component, rows: np.ndarray) -> np.ndarray:

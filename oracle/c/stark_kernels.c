@@ -212,7 +212,7 @@ void orc_logup_prefix(u32* col4, long n, const int64_t* order, const u32 shift[4
 
 /* ---------------------------------------------------------------------------------------------
  * Constraint quotients of one component on its eval domain (Appendix A.7).
- * kind: 0 Add, 1 Mul, 2 Recip, 15 Inputs.  main: n_cols columns of E words; inter: 4*n_rel columns;
+ * kind: 0 Add, 1 Mul, 2 Recip, 5 SumReduce, 6 MaxReduce, 15 Inputs, 16 Contiguous.  main: n_cols columns of E words; inter: 4*n_rel columns;
  * prev_idx[s] = storage index of the previous trace row of s; coeff: alpha powers (QM31) in
  * constraint order; zinv[s]: 1/Z per row; out: 4 x E (+= when accumulate).
  * ------------------------------------------------------------------------------------------- */
@@ -238,11 +238,30 @@ static int local_constraints(int kind, const u32* c, u32* out) {
     out[k++] = mmul(nl, msub(c[4], c[0]));
     out[k++] = mmul(nl, msub(c[5], c[1]));
     out[k++] = mmul(nl, msub(msub(c[6], c[2]), 1));
-  } else {
+  } else if (kind == 15) {
     u32 is_last = c[2], nl = msub(1, is_last);
     out[k++] = mmul(is_last, msub(is_last, 1));
     out[k++] = mmul(nl, msub(c[3], c[0]));
     out[k++] = mmul(nl, msub(msub(c[4], c[1]), 1));
+  } else { /* 5 SumReduce, 6 MaxReduce, 16 Contiguous: shared id/idx prefix, columns 0..6 */
+    u32 is_last = c[3], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    if (kind == 5) {
+      u32 ils = c[11];
+      out[k++] = mmul(ils, msub(ils, 1));
+      out[k++] = msub(c[10], madd(c[9], c[7]));
+      out[k++] = mmul(msub(c[8], c[10]), ils);
+    } else if (kind == 6) {
+      u32 ils = c[11], im = c[12];
+      out[k++] = mmul(ils, msub(ils, 1));
+      out[k++] = mmul(im, msub(im, 1));
+      out[k++] = mmul(im, msub(c[10], c[7]));
+      out[k++] = mmul(msub(1, im), msub(c[10], c[9]));
+      out[k++] = mmul(msub(c[8], c[10]), ils);
+    }
+    out[k++] = mmul(nl, msub(c[4], c[0]));
+    out[k++] = mmul(nl, msub(c[5], c[1]));
+    out[k++] = mmul(nl, msub(msub(c[6], c[2]), 1));
   }
   return k;
 }

@@ -38,6 +38,8 @@ def test_gpu_reproduces_reference_kat(gpu_prover, kat_bytes):
     ("recip-only", [syn.chain_graph(257, 10)[2]]),
     ("pow2-plus-one", syn.config2_add_only((1 << 10) + 1, 11)),
     ("pow2-minus-one", syn.config2_add_only((1 << 11) - 1, 12)),
+    ("linear-layer", syn.linear_layer(64, 100, 13)),
+    ("linear-layer+max", syn.linear_layer(33, 50, 14, True)),
 ])
 def test_gpu_proof_equals_oracle_proof(gpu_prover, name, tabs):
     got = _gpu_bytes(gpu_prover, tabs)
@@ -69,6 +71,14 @@ def test_gpu_config3_mixed_2_20_total_rows_equals_c_oracle_bytes(gpu_prover, c_o
     from oracle.proof import to_bincode
     from oracle.prover import prove
     tabs = syn.config3_mixed(19, 18, 18, 8)
+    assert _gpu_bytes(gpu_prover, tabs) == to_bincode(prove(tabs, kernels=c_oracle))
+
+
+def test_gpu_linear_layer_2_19_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
+    """BASELINE config 5's building block (Mul + SumReduce + Add) at 2 x 2^18 + 2^9 rows, byte-for-byte."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.linear_layer(512, 512, 21)
     assert _gpu_bytes(gpu_prover, tabs) == to_bincode(prove(tabs, kernels=c_oracle))
 
 

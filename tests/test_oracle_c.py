@@ -24,6 +24,8 @@ def test_c_oracle_reproduces_kat(ck, kat_bytes):
     ("mixed-sizes", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])], ProtocolVariant.KAT),
     ("add-2^13", syn.config2_add_only(1 << 13, 6), ProtocolVariant.KAT),
     ("2b-inputs", syn.config2_graph_faithful(200, 7), ProtocolVariant.PINNED),
+    ("linear-layer", syn.linear_layer(8, 16, 1), ProtocolVariant.KAT),
+    ("linear-layer+max", syn.linear_layer(20, 7, 2, True), ProtocolVariant.KAT),
 ])
 def test_c_oracle_equals_numpy_oracle(ck, name, tabs, variant):
     a = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=variant))

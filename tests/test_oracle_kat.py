@@ -161,3 +161,23 @@ def test_oracle_pinned_variant_proves_and_verifies():
     verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.PINNED)
     with pytest.raises(Exception):
         verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.KAT)   # different transcript encodings
+
+
+def test_oracle_linear_layer_components_verify():
+    """Mul + SumReduce + Add (+ MaxReduce) — the linear-layer lowering of BASELINE config 5; the
+    SumReduce / MaxReduce / Contiguous constraint forms are fully visible in the reference."""
+    for tabs in (syn.linear_layer(8, 16, 1), syn.linear_layer(20, 7, 2, True)):
+        proof = prove([(k, r.astype(np.uint64)) for k, r in tabs])
+        verify(from_bincode(to_bincode(proof), 8))
+    tabs = [(0, syn.add_rows([5, 6, 7], [1, 2, 3], node=2, lhs_id=0, rhs_id=1, mults=(0, 0, 1))),
+            (16, syn.contiguous_rows([6, 8, 10], node=3, input_id=2, input_mult=-1, out_mult=0))]
+    proof = prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED)
+    verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.PINNED)
+    # a wrong running sum must be caught by the AIR
+    from oracle.prover import ProvingError
+    bad = syn.linear_layer(8, 16, 1)
+    rows = bad[2][1].copy()
+    rows[5, 10] = (int(rows[5, 10]) + 1) % P     # next_acc != acc + input
+    with pytest.raises(ProvingError):
+        prove([(bad[0][0], bad[0][1].astype(np.uint64)), (bad[1][0], bad[1][1].astype(np.uint64)),
+               (bad[2][0], rows.astype(np.uint64))])
