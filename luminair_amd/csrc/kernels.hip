@@ -128,6 +128,7 @@ LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_
     const int L = first_layer + r;
     const uint32_t* __restrict__ t = tw.l[L];
     const uint32_t hb = (H << (hi - L - 1)) + (mhigh << (R - 1 - r));
+    LMN_ASSUME(hb < (1u << 28));  // lets the compiler use 32-bit offsets from the uniform table pointer
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
       if (j & (1 << r)) continue;
@@ -153,14 +154,18 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
   const uint32_t tile_elems = 1u << (hi - lo + cb);
   const uint32_t ngroups = tile_elems >> R;
   const uint32_t cmask = (1u << cb) - 1u;
+  // 32-bit offsets from the (block-uniform) tile base keep the address arithmetic off the 64-bit path
+  const uint32_t* __restrict__ tsrc = scol + base;
+  uint32_t* __restrict__ tdst = col + base;
+  const uint64_t span = src_len > base ? src_len - base : 0;
+  const uint32_t lim = span > 0x10000000ull ? 0x10000000u : (uint32_t)span;  // readable words from tsrc
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const uint32_t e0 = ((g >> p) << (p + R)) | (g & ((1u << p) - 1u));
     uint32_t v[1 << R];
     if (from_global) {
       if (p == 0 && cb == 0 && R >= 2) {
-        const uint64_t gi = base + e0;
-        if (gi < src_len) {
-          const uint4* q = reinterpret_cast<const uint4*>(scol + gi);
+        if (e0 < lim) {
+          const uint4* q = reinterpret_cast<const uint4*>(tsrc + e0);
 #pragma unroll
           for (int k = 0; k < (1 << R) / 4; ++k) {
             uint4 x = q[k];
@@ -177,8 +182,9 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) {
           const uint32_t e = e0 + ((uint32_t)j << p);
-          const uint64_t gi = base + ((uint64_t)(e >> cb) << lo) + (e & cmask);
-          v[j] = gi < src_len ? scol[gi] : 0u;
+          const uint32_t off = ((e >> cb) << lo) + (e & cmask);
+          LMN_ASSUME(off < 0x10000000u);
+          v[j] = off < lim ? tsrc[off] : 0u;
         }
       }
     } else {
@@ -193,14 +199,16 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
         for (int j = 0; j < (1 << R); ++j) v[j] = m_mul(v[j], scale);
       }
       if (p == 0 && cb == 0 && R >= 2) {
-        uint4* q = reinterpret_cast<uint4*>(col + base + e0);
+        uint4* q = reinterpret_cast<uint4*>(tdst + e0);
 #pragma unroll
         for (int k = 0; k < (1 << R) / 4; ++k) q[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
       } else {
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) {
           const uint32_t e = e0 + ((uint32_t)j << p);
-          col[base + ((uint64_t)(e >> cb) << lo) + (e & cmask)] = v[j];
+          const uint32_t off = ((e >> cb) << lo) + (e & cmask);
+          LMN_ASSUME(off < 0x10000000u);
+          tdst[off] = v[j];
         }
       }
     } else {

@@ -21,6 +21,7 @@
 #define LMN_SHARED __shared__
 typedef hipStream_t lmn_stream_t;
 #define lmn_shfl_xor(v, mask) __shfl_xor((v), (mask), 64)
+#define LMN_ASSUME(x) __builtin_assume(x)
 
 struct LmnError : std::runtime_error {
   int code;
@@ -122,6 +123,7 @@ void lmn_emu_syncthreads();
 #define __syncthreads() lmn_emu_syncthreads()
 #define LMN_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(lmn_emu_dyn_smem)
 typedef int lmn_stream_t;
+#define LMN_ASSUME(x) ((void)0)
 extern unsigned lmn_emu_shfl_scratch[1024];
 inline unsigned lmn_shfl_xor(unsigned v, int mask) {  // all lanes of the block must call it together
   lmn_emu_shfl_scratch[threadIdx.x] = v;
