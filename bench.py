@@ -180,12 +180,12 @@ def main(argv=None):
         pass
     fams = {
         "k_fft_staged": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"], ["k_fft_staged<false>", "k_fft_staged<true>"]),
-        "k_merkle_fused": (tm["merkle_ms"], tm["merkle_bytes"], tm["merkle_launches"],
-                           ["k_merkle_fused", "k_merkle_small", "k_fri_tail"]),
+        "k_merkle_fused": (tm["merkle_fused_ms"], tm["merkle_fused_bytes"], tm["merkle_fused_launches"],
+                           ["k_merkle_fused"]),
     }
     alu = {
         "k_fft_staged": (tm["fft_butterflies"], BUTTERFLY_PEAK_G, "G butterflies/s"),
-        "k_merkle_fused": (tm["merkle_compressions"], BLAKE2S_PEAK_GCOMP, "G Blake2s compressions/s"),
+        "k_merkle_fused": (tm["merkle_fused_compressions"], BLAKE2S_PEAK_GCOMP, "G Blake2s compressions/s"),
     }
 
     def roof(name):

@@ -98,6 +98,10 @@ typedef struct lmn_timings {
   uint32_t fft_launches, merkle_launches;
   uint64_t fft_butterflies;      /* M31 butterflies (1 mul + 1 add + 1 sub) executed by those FFT launches */
   uint64_t merkle_compressions;  /* Blake2s compression-function calls executed by the Merkle launches */
+  /* the k_merkle_fused launches alone (the dominant kernel; excludes k_merkle_small / k_fri_tail) */
+  float merkle_fused_ms;
+  uint32_t merkle_fused_launches;
+  uint64_t merkle_fused_bytes, merkle_fused_compressions;
 } lmn_timings;
 
 const char* lmn_strerror(int code);

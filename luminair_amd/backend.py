@@ -41,7 +41,9 @@ class LmnTimings(C.Structure):
         "transpose_ms", "main_commit_ms", "logup_ms", "interaction_commit_ms", "composition_ms",
         "composition_commit_ms", "oods_ms", "quotients_ms", "fri_ms", "decommit_ms", "fft_ms", "merkle_ms")] + [
         ("fft_bytes", C.c_uint64), ("merkle_bytes", C.c_uint64), ("fft_launches", C.c_uint32),
-        ("merkle_launches", C.c_uint32), ("fft_butterflies", C.c_uint64), ("merkle_compressions", C.c_uint64)]
+        ("merkle_launches", C.c_uint32), ("fft_butterflies", C.c_uint64), ("merkle_compressions", C.c_uint64),
+        ("merkle_fused_ms", C.c_float), ("merkle_fused_launches", C.c_uint32), ("merkle_fused_bytes", C.c_uint64),
+        ("merkle_fused_compressions", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

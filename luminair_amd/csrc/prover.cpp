@@ -79,7 +79,7 @@ static EventLog* g_log(Context* c);
 
 enum Cat {
   C_TOTAL = 0, C_TRANSPOSE, C_MAIN_COMMIT, C_LOGUP, C_INTER_COMMIT, C_COMPOSITION, C_COMP_COMMIT, C_OODS, C_QUOT,
-  C_FRI, C_DECOMMIT, C_FFT, C_MERKLE, C_N
+  C_FRI, C_DECOMMIT, C_FFT, C_MERKLE, C_MERKLE_FUSED, C_N
 };
 
 struct StageTimer {
@@ -344,7 +344,16 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
         if (const char* e = getenv("LMN_MERKLE_SUB")) sub = std::min(std::min(atoi(e), nfused), MERKLE_MAX_SUB);
         nfused = std::min(nfused, sub + 8);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
+        StageTimer tf(this, g_log(this), stream_, C_MERKLE_FUSED);
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_);
+        timings.merkle_fused_launches++;
+        uint64_t words = (prev ? 16 : 0) + lc.size();
+        timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
+        timings.merkle_fused_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
+        for (int l = 1; l <= nfused; ++l) {
+          timings.merkle_fused_bytes += ((uint64_t)1 << (level - l)) * 96ull;
+          timings.merkle_fused_compressions += (uint64_t)1 << (level - l);
+        }
       }
       timings.merkle_launches++;
       timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
@@ -540,9 +549,9 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair
     size_t start = pos;
     while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
     bool have_prev = log < m.max_log;
-    std::vector<uint32_t> colq;
+    static const std::vector<uint32_t> kNone;
     auto it = queries.find(log);
-    if (it != queries.end()) colq = it->second;
+    const std::vector<uint32_t>& colq = it != queries.end() ? it->second : kNone;
     size_t pi = 0, ci = 0;
     std::vector<uint32_t> total;
     while (pi < last.size() || ci < colq.size()) {
@@ -1195,13 +1204,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
     };
     std::vector<Plan> plans;  // [first, inner..., tree0..3]
+    plans.reserve(inner.size() + 5);
     {
       Plan p;
       std::map<int, std::vector<uint32_t>> dec;
       for (auto& q : quots) plan_fri_witness(q.vals, 1ull << q.log, pos_by_log[q.log], dec[q.log], p.fri_wit);
       std::vector<Ref> dummy;
       plan_merkle_decommit(first_merkle, first_cols, dec, dummy, p.hash_wit, p.col_wit);
-      plans.push_back(p);
+      plans.push_back(std::move(p));
     }
     std::vector<uint32_t> lq = fold_positions(queries, 1);
     for (auto& fl : inner) {
@@ -1212,22 +1222,24 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       for (int k = 0; k < 4; ++k) lc.push_back({fl.vals + ((uint64_t)k << fl.log), fl.log});
       std::vector<Ref> dummy;
       plan_merkle_decommit(fl.merkle, lc, dec, dummy, p.hash_wit, p.col_wit);
-      plans.push_back(p);
+      plans.push_back(std::move(p));
       lq = fold_positions(lq, 1);
     }
     for (auto* t : trees) {
       Plan p;
       std::vector<std::pair<const uint32_t*, int>> sorted;
       std::map<int, std::vector<uint32_t>> qmap;
+      sorted.reserve(t->cols.size());
       for (auto& c : t->cols) {
         sorted.push_back({c.lde, c.log_size + lb});
-        qmap[c.log_size + lb] = pos_by_log[c.log_size + lb];
+        if (!qmap.count(c.log_size + lb)) qmap[c.log_size + lb] = pos_by_log[c.log_size + lb];
       }
       std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
       plan_merkle_decommit(t->merkle, sorted, qmap, p.queried, p.hash_wit, p.col_wit);
-      plans.push_back(p);
+      plans.push_back(std::move(p));
     }
     std::vector<GatherEntry> entries;
+    entries.reserve(8192);
     uint32_t out_words = 0;
     auto add_refs = [&](const std::vector<Ref>& refs) {
       for (auto& r : refs) {
@@ -1314,6 +1326,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   timings.decommit_ms = acc[C_DECOMMIT];
   timings.fft_ms = acc[C_FFT];
   timings.merkle_ms = acc[C_MERKLE];
+  timings.merkle_fused_ms = acc[C_MERKLE_FUSED];
   return proof_to_bincode(proof);
 }
 
