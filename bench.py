@@ -147,7 +147,7 @@ def main(argv=None):
 
     def barrier():
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     def device_sync():
         drain()
