@@ -16,6 +16,7 @@ P = (1 << 31) - 1
 SCALE = 1 << 12
 KIND_ADD, KIND_MUL, KIND_RECIP, KIND_INPUTS = 0, 1, 2, 15
 KIND_SUM_REDUCE, KIND_MAX_REDUCE, KIND_CONTIGUOUS = 5, 6, 16
+KIND_LESS_THAN, KIND_RANGE_CHECK_LOOKUP = 13, 14
 
 
 def to_m31(v: np.ndarray) -> np.ndarray:
@@ -122,6 +123,46 @@ def contiguous_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndar
     cols = [np.full(n, node), np.full(n, input_id), idx, (idx == n - 1).astype(np.int64), np.full(n, node),
             np.full(n, input_id), idx + 1, to_m31(x), to_m31(x), np.full(n, input_mult % P), np.full(n, out_mult % P)]
     return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def less_than_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(-1, -1, 0)):
+    """`LuminairLessThan::process_trace` (crates/graph/src/op/prim.rs:1203-1295): out = 1.0 if lhs < rhs,
+    diff = rhs - lhs (+ 2^31-1 when borrow), split into four 8-bit limbs that are range-checked.
+    Returns (rows, limb multiplicities[256])."""
+    lhs, rhs = np.asarray(lhs, np.int64), np.asarray(rhs, np.int64)
+    n = len(lhs)
+    lt = lhs < rhs
+    out = np.where(lt, SCALE, 0)
+    borrow = np.where(lt, 0, 1)
+    diff = rhs - lhs + borrow * P
+    limbs = [(diff >> (8 * k)) & 0xFF for k in range(4)]
+    cols = _ids(n, node, lhs_id, rhs_id) + [to_m31(lhs), to_m31(rhs), to_m31(out), diff, borrow] + limbs
+    cols += [np.full(n, m % P) for m in mults] + [np.ones(n, dtype=np.int64)]
+    rows = np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+    counts = np.zeros(256, dtype=np.int64)
+    for l in limbs:
+        counts += np.bincount(l, minlength=256)
+    return rows, counts
+
+
+def range_check_lookup_rows(multiplicities) -> np.ndarray:
+    """`RangeCheckLookup::add_multiplicities_to_table`: one row per LUT entry (256 for the 8-bit check)."""
+    return np.asarray(multiplicities, dtype=np.int64).reshape(-1, 1).astype(np.uint32)
+
+
+def less_than_graph(n: int, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
+    """c = a + b; d = (c < t) with fresh inputs a, b, t (PINNED variant): Add, LessThan, its
+    RangeCheckLookup LUT component and the Inputs table, logup sums cancelling."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-2048, 2048, size=n)
+    b = rng.integers(-2048, 2048, size=n)
+    t = rng.integers(-4096, 4096, size=n)
+    c = a + b
+    add = add_rows(a, b, node=3, lhs_id=0, rhs_id=1, mults=(-1, -1, 1))
+    lt, counts = less_than_rows(c, t, node=4, lhs_id=3, rhs_id=2, mults=(-1, -1, 0))
+    inp = np.concatenate([inputs_rows(a, 0, 1), inputs_rows(b, 1, 1), inputs_rows(t, 2, 1)])
+    return [(KIND_ADD, add), (KIND_LESS_THAN, lt), (KIND_RANGE_CHECK_LOOKUP, range_check_lookup_rows(counts)),
+            (KIND_INPUTS, inp)]
 
 
 def linear_layer(n_out: int, dim: int, seed: int = 42, with_max: bool = False) -> List[Tuple[int, np.ndarray]]:

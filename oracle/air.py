@@ -20,8 +20,8 @@ scalar `QM31` (OODS point, verifier side).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Callable, List, Sequence, Tuple
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -69,6 +69,22 @@ N_KINDS = 17
 N_KINDS_KAT = 8
 
 
+ELEMS_NODE, ELEMS_RANGE_CHECK = 0, 1   # relation!(NodeElements, 2) / relation!(RangeCheckLookupElements, 1)
+
+
+@dataclass(frozen=True)
+class Rel:
+    """One `add_to_relation` entry: multiplicity column, value column, optional tensor-id column
+    (None for width-1 relations), the element set it is combined with, numerator sign, and
+    whether `val` indexes the component's preprocessed columns instead of its main columns."""
+    mult: int
+    val: int
+    id: Optional[int] = None
+    elems: int = ELEMS_NODE
+    neg: bool = False
+    pre: bool = False
+
+
 @dataclass
 class Component:
     name: str
@@ -76,7 +92,11 @@ class Component:
     n_cols: int
     padding: Tuple[int, ...]
     local: Callable[[Sequence], List]            # cols -> list of constraint values
-    relations: Tuple[Tuple[int, Tuple[int, int]], ...]  # (mult_col, (value_col, id_col))
+    relations: Tuple                             # Rel entries (legacy form (mult,(val,id)) is converted)
+    pre_cols: Tuple[Tuple[str, int], ...] = ()   # preprocessed columns used: (id, log_size)
+
+    def __post_init__(self):
+        self.relations = tuple(r if isinstance(r, Rel) else Rel(r[0], r[1][0], r[1][1]) for r in self.relations)
 
     @property
     def n_local(self):
@@ -170,7 +190,46 @@ MAX_REDUCE = Component("max_reduce", KIND_MAX_REDUCE, 15, _pad(15, 3), _max_redu
 CONTIGUOUS = Component("contiguous", KIND_CONTIGUOUS, 11, _pad(11, 3), _contiguous_local,
                        ((9, (7, 1)), (10, (8, 0))))
 
-COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS, SUM_REDUCE, MAX_REDUCE, CONTIGUOUS)}
+
+
+def _less_than_local(c):
+    """`crates/air/src/components/less_than/component.rs:48-185`."""
+    (node, lhs_id, rhs_id, idx, is_last, n_node, n_lhs, n_rhs, n_idx, lhs, rhs, out, diff, borrow,
+     l0, l1, l2, l3, _lm, _rm, _om, _dm) = c
+    cons = [is_last * (is_last - 1), borrow * (borrow - 1), out - (1 - borrow) * FP_SCALE,
+            lhs + diff - rhs - borrow * P_MINUS_1_AS_2POW31M1,
+            diff - (l3 * (1 << 24) + l2 * (1 << 16) + l1 * (1 << 8) + l0)]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_lhs, lhs_id), (n_rhs, rhs_id)], n_idx, idx)
+    return cons
+
+
+# TWO_POW_31_MINUS_1 (crates/air/src/lib.rs:26) as a field constant: 2^31-1 == P == 0 in M31; the
+# reference builds it with from_u32_unchecked, i.e. the non-canonical representative of zero.
+P_MINUS_1_AS_2POW31M1 = 0
+
+_LT_PAD = [0] * 22
+_LT_PAD[4], _LT_PAD[10], _LT_PAD[11], _LT_PAD[12], _LT_PAD[14] = 1, 1, FP_SCALE, 1, 1   # less_than/table.rs:47-72
+LESS_THAN = Component("less_than", KIND_LESS_THAN, 22, tuple(_LT_PAD), _less_than_local,
+                      (Rel(18, 9, 1), Rel(19, 10, 2), Rel(20, 11, 0),
+                       Rel(21, 14, None, ELEMS_RANGE_CHECK), Rel(21, 15, None, ELEMS_RANGE_CHECK),
+                       Rel(21, 16, None, ELEMS_RANGE_CHECK), Rel(21, 17, None, ELEMS_RANGE_CHECK)))
+# lookups/range_check/component.rs: one multiplicity column + the preprocessed 8-bit enumeration
+RANGE_CHECK_LOG = 8
+RANGE_CHECK_COL_ID = "range_check_8_column_0"
+RANGE_CHECK_LOOKUP = Component("range_check_lookup", KIND_RANGE_CHECK_LOOKUP, 1, (0,), lambda c: [],
+                               (Rel(0, 0, None, ELEMS_RANGE_CHECK, neg=True, pre=True),),
+                               pre_cols=((RANGE_CHECK_COL_ID, RANGE_CHECK_LOG),))
+
+COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS, SUM_REDUCE, MAX_REDUCE, CONTIGUOUS, LESS_THAN,
+                                  RANGE_CHECK_LOOKUP)}
+
+
+def preprocessed_column(col_id: str, log_size: int) -> np.ndarray:
+    """`RangeCheckPreProcessed::gen_column` (crates/air/src/preprocessed.rs:289-296): row r holds r."""
+    if col_id == RANGE_CHECK_COL_ID:
+        return np.arange(1 << log_size, dtype=U64)
+    raise ValueError("unknown preprocessed column " + col_id)
 
 
 def pad_table(comp: Component, rows: np.ndarray) -> np.ndarray:

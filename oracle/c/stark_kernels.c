@@ -173,9 +173,9 @@ void orc_blake2s_rows(const u32* words, long n, int w, u32* out) {
  * cols: k relations x (val, id, mult) pointers, each n words.  out: k secure columns as 4k base
  * columns of n words (running sums, NOT yet prefix-summed); claimed = sum over rows of S_{k-1}.
  * ------------------------------------------------------------------------------------------- */
-void orc_logup_columns(const u32* const* val, const u32* const* id, const u32* const* mult, int k, long n,
-                       const u32 z[4], const u32 alpha[4], u32* out, u32 claimed[4]) {
-  const qm Z = {z[0], z[1], z[2], z[3]}, A = {alpha[0], alpha[1], alpha[2], alpha[3]};
+void orc_logup_columns(const u32* const* val, const u32* const* id /* entries may be NULL */,
+                       const u32* const* mult, int k, long n, const u32* zs /* 4 per relation */,
+                       const u32* alphas /* 4 per relation */, const int* neg, u32* out, u32 claimed[4]) {
   u64 acc[4] = {0, 0, 0, 0};
 #pragma omp parallel
   {
@@ -184,8 +184,14 @@ void orc_logup_columns(const u32* const* val, const u32* const* id, const u32* c
     for (long r = 0; r < n; ++r) {
       qm S = QZERO;
       for (int j = 0; j < k; ++j) {
-        qm den = qsub(qadd(qfromm(val[j][r]), qmulm(A, id[j][r])), Z);
-        S = qadd(S, qmulm(qinv(den), mult[j][r]));
+        const qm Z = {zs[4 * j], zs[4 * j + 1], zs[4 * j + 2], zs[4 * j + 3]};
+        const qm A = {alphas[4 * j], alphas[4 * j + 1], alphas[4 * j + 2], alphas[4 * j + 3]};
+        qm den = qfromm(val[j][r]);
+        if (id[j]) den = qadd(den, qmulm(A, id[j][r]));
+        den = qsub(den, Z);
+        u32 m = mult[j][r];
+        if (neg[j]) m = mneg(m);
+        S = qadd(S, qmulm(qinv(den), m));
         u32* o = out + (long)(4 * j) * n + r;
         o[0] = S.a; o[n] = S.b; o[2 * n] = S.c; o[3 * n] = S.d;
       }
@@ -212,7 +218,9 @@ void orc_logup_prefix(u32* col4, long n, const int64_t* order, const u32 shift[4
 
 /* ---------------------------------------------------------------------------------------------
  * Constraint quotients of one component on its eval domain (Appendix A.7).
- * kind: 0 Add, 1 Mul, 2 Recip, 5 SumReduce, 6 MaxReduce, 15 Inputs, 16 Contiguous.  main: n_cols columns of E words; inter: 4*n_rel columns;
+ * kind: 0 Add, 1 Mul, 2 Recip, 5 SumReduce, 6 MaxReduce, 13 LessThan, 14 RangeCheckLookup, 15 Inputs,
+ * 16 Contiguous.  Relations are given by eval-domain column pointers (value, optional id, multiplicity)
+ * with their element set (z, alpha) and numerator sign.  main: n_cols columns of E words; inter: 4*n_rel columns;
  * prev_idx[s] = storage index of the previous trace row of s; coeff: alpha powers (QM31) in
  * constraint order; zinv[s]: 1/Z per row; out: 4 x E (+= when accumulate).
  * ------------------------------------------------------------------------------------------- */
@@ -243,6 +251,22 @@ static int local_constraints(int kind, const u32* c, u32* out) {
     out[k++] = mmul(is_last, msub(is_last, 1));
     out[k++] = mmul(nl, msub(c[3], c[0]));
     out[k++] = mmul(nl, msub(msub(c[4], c[1]), 1));
+  } else if (kind == 14) {
+    /* RangeCheckLookup: no local constraints */
+  } else if (kind == 13) { /* LessThan, less_than/component.rs:48-185 */
+    u32 is_last = c[4], nl = msub(1, is_last), borrow = c[13];
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    out[k++] = mmul(borrow, msub(borrow, 1));
+    out[k++] = msub(c[11], mmul(msub(1, borrow), 4096));
+    out[k++] = msub(madd(c[9], c[12]), c[10]); /* borrow * (2^31-1) == 0 in M31 */
+    {
+      u32 rec = madd(madd(mmul(c[17], 1u << 24), mmul(c[16], 1u << 16)), madd(mmul(c[15], 1u << 8), c[14]));
+      out[k++] = msub(c[12], rec);
+    }
+    out[k++] = mmul(nl, msub(c[5], c[0]));
+    out[k++] = mmul(nl, msub(c[6], c[1]));
+    out[k++] = mmul(nl, msub(c[7], c[2]));
+    out[k++] = mmul(nl, msub(msub(c[8], c[3]), 1));
   } else { /* 5 SumReduce, 6 MaxReduce, 16 Contiguous: shared id/idx prefix, columns 0..6 */
     u32 is_last = c[3], nl = msub(1, is_last);
     out[k++] = mmul(is_last, msub(is_last, 1));
@@ -266,11 +290,10 @@ static int local_constraints(int kind, const u32* c, u32* out) {
   return k;
 }
 
-void orc_composition(int kind, int n_cols, int n_rel, const int* rel_mult, const int* rel_val, const int* rel_id,
-                     const u32* main, const u32* inter, long E, const int64_t* prev_idx, const u32 z[4],
-                     const u32 alpha[4], const u32 shift[4], const u32* coeff /* 4 words each */,
-                     const u32* zinv, u32* out, int accumulate) {
-  const qm Z = {z[0], z[1], z[2], z[3]}, A = {alpha[0], alpha[1], alpha[2], alpha[3]};
+void orc_composition(int kind, int n_cols, int n_rel, const u32* const* rel_val, const u32* const* rel_id,
+                     const u32* const* rel_mult, const u32* rel_z, const u32* rel_alpha, const int* rel_neg,
+                     const u32* main, const u32* inter, long E, const int64_t* prev_idx, const u32 shift[4],
+                     const u32* coeff /* 4 words each */, const u32* zinv, u32* out, int accumulate) {
   const qm SH = {shift[0], shift[1], shift[2], shift[3]};
 #pragma omp parallel for schedule(static)
   for (long s = 0; s < E; ++s) {
@@ -286,8 +309,14 @@ void orc_composition(int kind, int n_cols, int n_rel, const int* rel_mult, const
     qm prev = QZERO;
     for (int j = 0; j < n_rel; ++j, ++k) {
       const u32* b = inter + (long)(4 * j) * E;
+      const qm Z = {rel_z[4 * j], rel_z[4 * j + 1], rel_z[4 * j + 2], rel_z[4 * j + 3]};
+      const qm A = {rel_alpha[4 * j], rel_alpha[4 * j + 1], rel_alpha[4 * j + 2], rel_alpha[4 * j + 3]};
       qm cur = {b[s], b[E + s], b[2 * E + s], b[3 * E + s]};
-      qm den = qsub(qadd(qfromm(c[rel_val[j]]), qmulm(A, c[rel_id[j]])), Z);
+      qm den = qfromm(rel_val[j][s]);
+      if (rel_id[j]) den = qadd(den, qmulm(A, rel_id[j][s]));
+      den = qsub(den, Z);
+      u32 m = rel_mult[j][s];
+      if (rel_neg[j]) m = mneg(m);
       qm diff;
       if (j < n_rel - 1) {
         diff = qsub(cur, prev);
@@ -296,7 +325,7 @@ void orc_composition(int kind, int n_cols, int n_rel, const int* rel_mult, const
         qm pr = {b[ps], b[E + ps], b[2 * E + ps], b[3 * E + ps]};
         diff = qadd(qsub(qsub(cur, pr), prev), SH);
       }
-      qm cons = qsub(qmul(diff, den), qfromm(c[rel_mult[j]]));
+      qm cons = qsub(qmul(diff, den), qfromm(m));
       qm cf = {coeff[4 * k], coeff[4 * k + 1], coeff[4 * k + 2], coeff[4 * k + 3]};
       acc = qadd(acc, qmul(cons, cf));
       prev = cur;

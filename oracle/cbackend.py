@@ -135,17 +135,27 @@ class CKernels:
             self._tw[key] = (np.ascontiguousarray(xs, dtype=U32), np.ascontiguousarray(ys, dtype=U32))
         return self._tw[key]
 
-    def gen_interaction_trace(self, comp, cols, z, alpha):
+    def _rel_args(self, comp, main2d, pre_list, elems):
+        """ctypes argument arrays for the relations of `comp` over the given column arrays."""
+        k = len(comp.relations)
+        PK = C.c_void_p * k
+        keep = [np.ascontiguousarray(p, dtype=U32) for p in pre_list]
+        val = PK(*[(keep[r.val] if r.pre else main2d[r.val]).ctypes.data for r in comp.relations])
+        idp = PK(*[(main2d[r.id].ctypes.data if r.id is not None else None) for r in comp.relations])
+        mult = PK(*[main2d[r.mult].ctypes.data for r in comp.relations])
+        zs = np.array([elems[r.elems][0].v for r in comp.relations], dtype=U32).reshape(-1)
+        als = np.array([elems[r.elems][1].v for r in comp.relations], dtype=U32).reshape(-1)
+        neg = (C.c_int * k)(*[1 if r.neg else 0 for r in comp.relations])
+        return k, val, idp, mult, zs, als, neg, keep
+
+    def gen_interaction_trace(self, comp, cols, elems, pre_cols=()):
         cols = np.ascontiguousarray(cols, dtype=U32)
         n = cols.shape[1]
-        k = len(comp.relations)
-        P3 = C.c_void_p * k
-        val = P3(*[cols[vc].ctypes.data for (_, (vc, _)) in comp.relations])
-        idp = P3(*[cols[ic].ctypes.data for (_, (_, ic)) in comp.relations])
-        mult = P3(*[cols[mc].ctypes.data for (mc, _) in comp.relations])
+        k, val, idp, mult, zs, als, neg, keep = self._rel_args(comp, cols, pre_cols, elems)
         out = np.empty((4 * k, n), dtype=U32)
         claimed = (C.c_uint32 * 4)()
-        self.lib.orc_logup_columns(val, idp, mult, C.c_int(k), C.c_long(n), _q4(z), _q4(alpha), _ptr(out), claimed)
+        self.lib.orc_logup_columns(val, idp, mult, C.c_int(k), C.c_long(n), _ptr(zs), _ptr(als), neg, _ptr(out),
+                                   claimed)
         cl = QM31(*claimed)
         shift = cl / QM31(n % P)
         order = np.ascontiguousarray(coset_order_storage_indices(n.bit_length() - 1), dtype=np.int64)
@@ -153,7 +163,7 @@ class CKernels:
         self.lib.orc_logup_prefix(_ptr(last), C.c_long(n), _ptr(order), _q4(shift))
         return [out[i] for i in range(4 * k)], cl
 
-    def composition(self, instances, tree1, tree2, z, alpha_rel, powers, n_total):
+    def composition(self, instances, tree0, tree1, tree2, elems, powers, n_total):
         sub = {}
         k0 = 0
         for ci in instances:
@@ -165,23 +175,20 @@ class CKernels:
             k0 += nc
             main_e = self._evaluate(np.stack([np.asarray(tree1.coeffs[i], dtype=U32) for i in range(*ci.main_span)]), e)
             inter_e = self._evaluate(np.stack([np.asarray(tree2.coeffs[i], dtype=U32) for i in range(*ci.inter_span)]), e)
+            pre_e = [self._evaluate(np.asarray(tree0.coeffs[i], dtype=U32).reshape(1, -1), e)[0] for i in ci.pre_idx]
             prev = np.ascontiguousarray(prev_row_indices(ci.log_size, e), dtype=np.int64)
             zkey = ("zinv", e, ci.log_size)
             if zkey not in self._tw:
                 xs, _ = self._domain(e)
                 self._tw[zkey] = self._inv(coset_vanishing_x(xs.astype(np.uint64), ci.log_size))
             zinv = self._tw[zkey]
-            nrel = len(comp.relations)
-            I = C.c_int * nrel
-            rm = I(*[mc for (mc, _) in comp.relations])
-            rv = I(*[vc for (_, (vc, _)) in comp.relations])
-            ri = I(*[ic for (_, (_, ic)) in comp.relations])
+            nrel, val, idp, mult, zs, als, neg, keep = self._rel_args(comp, main_e, pre_e, elems)
             shift = ci.claimed_sum / QM31((1 << ci.log_size) % P)
             first = e not in sub
             if first:
                 sub[e] = np.zeros((4, E), dtype=U32)
-            self.lib.orc_composition(C.c_int(comp.kind), C.c_int(comp.n_cols), C.c_int(nrel), rm, rv, ri, _ptr(main_e),
-                                     _ptr(inter_e), C.c_long(E), _ptr(prev), _q4(z), _q4(alpha_rel), _q4(shift),
+            self.lib.orc_composition(C.c_int(comp.kind), C.c_int(comp.n_cols), C.c_int(nrel), val, idp, mult, _ptr(zs),
+                                     _ptr(als), neg, _ptr(main_e), _ptr(inter_e), C.c_long(E), _ptr(prev), _q4(shift),
                                      _ptr(cp), _ptr(zinv), _ptr(sub[e]), C.c_int(0 if first else 1))
         cur = None
         for e in sorted(sub):

@@ -57,21 +57,39 @@ def commit_evals(cols: Sequence[np.ndarray], log_blowup: int, K=None) -> Committ
 
 
 # ----------------------------------------------------------------------------- logup
-def combine(z: QM31, alpha: QM31, v0: np.ndarray, v1: np.ndarray) -> np.ndarray:
-    """`Relation::combine` for the width-2 NodeElements relation: v0 + alpha*v1 - z (A.6)."""
-    return q_sub(q_add(q_from_m(v0), q_mul_m(q_const(alpha, v1.shape), v1)), q_const(z, v0.shape))
+def combine(z: QM31, alpha: QM31, v0: np.ndarray, v1: Optional[np.ndarray]) -> np.ndarray:
+    """`Relation::combine`: sum_i alpha^i * v_i - z (A.6); width 2 (NodeElements: value, tensor id)
+    or width 1 (RangeCheckLookupElements: value only, v1 = None)."""
+    acc = q_from_m(v0)
+    if v1 is not None:
+        acc = q_add(acc, q_mul_m(q_const(alpha, v1.shape), v1))
+    return q_sub(acc, q_const(z, v0.shape))
 
 
-def gen_interaction_trace(comp: Component, main_cols: np.ndarray, z: QM31, alpha: QM31):
+def rel_operands(rel, main_cols, pre_cols):
+    """(value vector, id vector or None, numerator vector) of one relation entry."""
+    val = pre_cols[rel.val] if rel.pre else main_cols[rel.val]
+    idv = main_cols[rel.id] if rel.id is not None else None
+    mult = main_cols[rel.mult]
+    if rel.neg:
+        mult = (U64(P) - np.asarray(mult, dtype=U64)) % U64(P)
+    return val, idv, mult
+
+
+def gen_interaction_trace(comp: Component, main_cols: np.ndarray, elems, pre_cols=()):
     """-> (list of 4k base columns, claimed_sum).  Restates `write_interaction_trace`
-    (`add/witness.rs:126-167`) + stwo `LogupTraceGenerator::{write_frac,finalize_col,finalize_last}`."""
+    (`add/witness.rs:126-167`) + stwo `LogupTraceGenerator::{write_frac,finalize_col,finalize_last}`.
+    elems[i] = (z, alpha) of relation element set i; pre_cols = the component's preprocessed columns
+    on the trace domain."""
     n = main_cols.shape[1]
     log_size = n.bit_length() - 1
     S = np.zeros((n, 4), dtype=U64)
     ext_cols = []
-    for (mult_col, (vc, ic)) in comp.relations:
-        den = combine(z, alpha, main_cols[vc], main_cols[ic])
-        frac = q_mul_m(q_inv(den), main_cols[mult_col])
+    for rel in comp.relations:
+        z, alpha = elems[rel.elems]
+        val, idv, mult = rel_operands(rel, main_cols, pre_cols)
+        den = combine(z, alpha, val, idv)
+        frac = q_mul_m(q_inv(den), mult)
         S = q_add(S, frac)
         ext_cols.append(S)
     last = ext_cols[-1]
@@ -98,6 +116,7 @@ class ComponentInstance:
     main_span: Tuple[int, int]    # [start, end) in tree 1
     inter_span: Tuple[int, int]   # [start, end) in tree 2
     claimed_sum: QM31
+    pre_idx: Tuple[int, ...] = ()  # tree-0 column indices of the component's preprocessed columns
 
 
 def prev_row_indices(log_size: int, eval_log: int) -> np.ndarray:
@@ -112,7 +131,7 @@ def prev_row_indices(log_size: int, eval_log: int) -> np.ndarray:
 
 
 def eval_component_constraints_on_domain(ci: ComponentInstance, main_e: np.ndarray, inter_e: np.ndarray,
-                                         z: QM31, alpha_rel: QM31, coeff_powers: List[QM31], eval_log: int):
+                                         elems, coeff_powers: List[QM31], eval_log: int, pre_e=()):
     """Σ_k c_k * coeff_powers[k] / Z on the eval domain -> (E, 4) array."""
     comp = ci.comp
     E = 1 << eval_log
@@ -126,10 +145,12 @@ def eval_component_constraints_on_domain(ci: ComponentInstance, main_e: np.ndarr
     n_rel = len(comp.relations)
     prev = np.zeros((E, 4), dtype=U64)
     shift = ci.claimed_sum / QM31((1 << ci.log_size) % P)
-    for j, (mult_col, (vc, ic)) in enumerate(comp.relations):
+    for j, rel in enumerate(comp.relations):
         cur = np.stack([inter_e[4 * j + t] for t in range(4)], axis=-1)
-        den = combine(z, alpha_rel, main_e[vc], main_e[ic])
-        num = q_from_m(main_e[mult_col])
+        z, alpha_rel = elems[rel.elems]
+        val, idv, mult = rel_operands(rel, main_e, pre_e)
+        den = combine(z, alpha_rel, val, idv)
+        num = q_from_m(mult)
         if j < n_rel - 1:
             diff = q_sub(cur, prev)
         else:
@@ -275,10 +296,10 @@ class NumpyKernels:
     def merkle(self, cols):
         return MerkleTree(cols)
 
-    def gen_interaction_trace(self, comp, cols, z, alpha):
-        return gen_interaction_trace(comp, cols, z, alpha)
+    def gen_interaction_trace(self, comp, cols, elems, pre_cols=()):
+        return gen_interaction_trace(comp, cols, elems, pre_cols)
 
-    def composition(self, instances, tree1, tree2, z, alpha_rel, powers, n_total):
+    def composition(self, instances, tree0, tree1, tree2, elems, powers, n_total):
         sub: Dict[int, np.ndarray] = {}
         k0 = 0
         for ci in instances:
@@ -288,7 +309,8 @@ class NumpyKernels:
             k0 += nc
             main_e = np.stack([evaluate(tree1.coeffs[i], e) for i in range(*ci.main_span)])
             inter_e = np.stack([evaluate(tree2.coeffs[i], e) for i in range(*ci.inter_span)])
-            val = eval_component_constraints_on_domain(ci, main_e, inter_e, z, alpha_rel, cp, e)
+            pre_e = [evaluate(tree0.coeffs[i], e) for i in ci.pre_idx]
+            val = eval_component_constraints_on_domain(ci, main_e, inter_e, elems, cp, e, pre_e)
             sub[e] = q_add(sub[e], val) if e in sub else val
         cur = None  # coefficient form, (4, 2^e)
         for e in sorted(sub):
@@ -359,8 +381,17 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     n_slots = claim_slots(variant)
     lb = config.log_blowup
 
-    # PHASE 0: preprocessed trace (no LUT components in the oracle's scope -> empty tree)
-    tree0 = CommittedTree([], lb, K)
+    # PHASE 0: preprocessed trace (prover.rs:54-59): the LUT columns the present components use,
+    # sorted by log size descending (PreProcessedTrace::new); empty for LUT-free graphs
+    pre_ids: List[Tuple[str, int]] = []
+    for kind, _ in tables:
+        if kind in COMPONENTS:
+            for pc in COMPONENTS[kind].pre_cols:
+                if pc not in pre_ids:
+                    pre_ids.append(pc)
+    pre_ids.sort(key=lambda pc: -pc[1])
+    pre_evals = [air.preprocessed_column(cid, ls) for cid, ls in pre_ids]
+    tree0 = commit_evals(pre_evals, lb, K) if pre_evals else CommittedTree([], lb, K)
     channel.mix_root(tree0.root())
     tr.digests["root0"] = channel.digest
 
@@ -398,9 +429,10 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
 
     # PHASE 2: interaction trace, prover.rs:186-298
     z, alpha_rel = channel.draw_felts(2)          # NodeElements (relation!(NodeElements, 2))
+    # LookupElements::draw (lookups/mod.rs:44-51): KAT era 1 LUT relation; HEAD: sin, exp2, log2, range_check
     n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
-    for _ in range(n_lut_rel):                    # LookupElements::draw — advances n_sent only
-        channel.draw_felts(2)
+    lut_draws = [channel.draw_felts(2) for _ in range(n_lut_rel)]
+    elems = [(z, alpha_rel), tuple(lut_draws[3]) if n_lut_rel == 4 else None]
     tr.z, tr.alpha_rel = z, alpha_rel
     inter_cols: List[np.ndarray] = []
     iclaim: List[Optional[QM31]] = [None] * n_slots
@@ -410,11 +442,14 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         if claim[kind] is None:
             continue
         comp, cols = seen[kind]
-        base_cols, claimed = K.gen_interaction_trace(comp, cols, z, alpha_rel)
+        if any(r.elems == air.ELEMS_RANGE_CHECK for r in comp.relations) and elems[1] is None:
+            raise ProvingError("component needs RangeCheckLookupElements (PINNED variant only)")
+        pre_idx = tuple(pre_ids.index(pc) for pc in comp.pre_cols)
+        base_cols, claimed = K.gen_interaction_trace(comp, cols, elems, [pre_evals[i] for i in pre_idx])
         iclaim[kind] = claimed
         # TraceLocationAllocator hands out spans in component (struct) order
         instances.append(ComponentInstance(comp, claim[kind], (main_off, main_off + comp.n_cols),
-                                           (len(inter_cols), len(inter_cols) + len(base_cols)), claimed))
+                                           (len(inter_cols), len(inter_cols) + len(base_cols)), claimed, pre_idx))
         main_off += comp.n_cols
         inter_cols.extend(base_cols)
     for kind in range(n_slots):
@@ -433,7 +468,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     for _ in range(n_total - 1):
         powers.append(powers[-1] * comp_alpha)
     # composition: per eval-domain size accumulation (DomainEvaluationAccumulator)
-    comp_coeffs = K.composition(instances, tree1, tree2, z, alpha_rel, powers, n_total)
+    comp_coeffs = K.composition(instances, tree0, tree1, tree2, elems, powers, n_total)
     tree3 = CommittedTree(comp_coeffs, lb, K)
     channel.mix_root(tree3.root())
     tr.digests["root3"] = channel.digest
@@ -449,8 +484,8 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     tr.oods_point = oods
 
     # mask points: offset 0 everywhere, [-1, 0] on the last logup column of each component
-    sample_points: List[List[List[Tuple[QM31, QM31]]]] = [[], [None] * len(main_cols), [None] * len(inter_cols),
-                                                          [[oods]] * 4]
+    sample_points: List[List[List[Tuple[QM31, QM31]]]] = [[[oods]] * len(pre_ids), [None] * len(main_cols),
+                                                          [None] * len(inter_cols), [[oods]] * 4]
     for ci in instances:
         for i in range(*ci.main_span):
             sample_points[1][i] = [oods]
@@ -475,7 +510,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     # sanity: composition OODS eval must match the constraints at the sampled values
     from .verifier import eval_composition_at_point
     lhs = QM31.from_partial_evals([sampled_values[3][k][0] for k in range(4)])
-    rhs = eval_composition_at_point(instances, sampled_values, oods, z, alpha_rel, comp_alpha)
+    rhs = eval_composition_at_point(instances, sampled_values, oods, elems, comp_alpha)
     if lhs != rhs:
         raise ProvingError("ProverError(ConstraintsNotSatisfied)")
 

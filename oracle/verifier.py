@@ -25,7 +25,7 @@ class VerificationError(Exception):
     pass
 
 
-def eval_composition_at_point(instances, sampled_values, oods, z: QM31, alpha_rel: QM31, comp_alpha: QM31) -> QM31:
+def eval_composition_at_point(instances, sampled_values, oods, elems, comp_alpha: QM31) -> QM31:
     """Σ_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values (A.7)."""
     acc = ZERO
     for ci in instances:
@@ -35,10 +35,14 @@ def eval_composition_at_point(instances, sampled_values, oods, z: QM31, alpha_re
         n_rel = len(comp.relations)
         prev = ZERO
         shift = ci.claimed_sum / QM31((1 << ci.log_size) % P)
-        for j, (mult_col, (vc, ic)) in enumerate(comp.relations):
+        pre = [sampled_values[0][i][0] for i in ci.pre_idx]
+        for j, rel in enumerate(comp.relations):
             cols = [sampled_values[2][ci.inter_span[0] + 4 * j + t] for t in range(4)]
-            den = main[vc] + alpha_rel * main[ic] - z
-            num = main[mult_col]
+            z, alpha_rel = elems[rel.elems]
+            den = (pre[rel.val] if rel.pre else main[rel.val]) - z
+            if rel.id is not None:
+                den = den + alpha_rel * main[rel.id]
+            num = -main[rel.mult] if rel.neg else main[rel.mult]
             if j < n_rel - 1:
                 cur = QM31.from_partial_evals([c[0] for c in cols])
                 diff = cur - prev
@@ -57,8 +61,21 @@ def eval_composition_at_point(instances, sampled_values, oods, z: QM31, alpha_re
     return acc
 
 
+def _preprocessed_ids(claim):
+    """Tree-0 layout implied by the claim: the LUT columns of the present components, log size desc."""
+    pre_ids = []
+    for kind, ls in enumerate(claim):
+        if ls is not None:
+            for pc in COMPONENTS[kind].pre_cols:
+                if pc not in pre_ids:
+                    pre_ids.append(pc)
+    pre_ids.sort(key=lambda pc: -pc[1])
+    return pre_ids
+
+
 def _instances_from_claim(claim, iclaim):
     from .prover import ComponentInstance
+    pre_ids = _preprocessed_ids(claim)
     inst = []
     m_off = i_off = 0
     for kind, ls in enumerate(claim):
@@ -66,7 +83,8 @@ def _instances_from_claim(claim, iclaim):
             continue
         comp = COMPONENTS[kind]
         ni = 4 * len(comp.relations)
-        inst.append(ComponentInstance(comp, ls, (m_off, m_off + comp.n_cols), (i_off, i_off + ni), iclaim[kind]))
+        inst.append(ComponentInstance(comp, ls, (m_off, m_off + comp.n_cols), (i_off, i_off + ni), iclaim[kind],
+                                      tuple(pre_ids.index(pc) for pc in comp.pre_cols)))
         m_off += comp.n_cols
         i_off += ni
     return inst
@@ -89,6 +107,9 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
             channel.mix_u64(ls)
     channel.mix_root(s.commitments[1])
     z, alpha_rel = channel.draw_felts(2)
+    n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
+    lut_draws = [channel.draw_felts(2) for _ in range(n_lut_rel)]
+    elems = [(z, alpha_rel), tuple(lut_draws[3]) if n_lut_rel == 4 else None]
     # log_sum_valid (verifier.rs:97-99)
     tot = ZERO
     for c in proof.interaction_claim:
@@ -113,9 +134,10 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
         main_sizes += [ci.log_size] * ci.comp.n_cols
         inter_sizes += [ci.log_size] * (4 * len(ci.comp.relations))
     comp_log = max(ci.log_size for ci in inst) + 1
-    tree_sizes = [[], main_sizes, inter_sizes, [comp_log] * 4]
+    pre_ids = _preprocessed_ids(proof.claim)
+    tree_sizes = [[ls for _, ls in pre_ids], main_sizes, inter_sizes, [comp_log] * 4]
     # sample points
-    pts = [[], [[oods]] * len(main_sizes), [], [[oods]] * 4]
+    pts = [[[oods]] * len(pre_ids), [[oods]] * len(main_sizes), [], [[oods]] * 4]
     for ci in inst:
         step = qp_from_m(point_of_index(-subgroup_gen_index(ci.log_size) % ORDER))
         prev_pt = qp_add(oods, step)
@@ -127,7 +149,7 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
             raise VerificationError("sampled values shape")
     # OODS composition identity
     lhs = QM31.from_partial_evals([sv[3][k][0] for k in range(4)])
-    rhs = eval_composition_at_point(inst, sv, oods, z, alpha_rel, comp_alpha)
+    rhs = eval_composition_at_point(inst, sv, oods, elems, comp_alpha)
     if lhs != rhs:
         raise VerificationError("OodsNotMatching")
     channel.mix_felts([v for ts in sv for col in ts for v in col])
