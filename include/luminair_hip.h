@@ -78,10 +78,12 @@ typedef struct lmn_table {
   const uint32_t* rows; /* n_rows * n_columns(kind) words */
 } lmn_table;
 
-/* CircuitSettings (crates/air/src/settings.rs): only LUT-free graphs are in scope, so the
- * settings carry just the flag that all lookups are None. */
+/* CircuitSettings (crates/air/src/settings.rs): `lookups.{sin,exp2,log2}` must be None; the 8-bit
+ * range-check LUT (`lookups.range_check`, crates/graph/src/graph.rs:142-146) is supported and is
+ * implied by the presence of a RangeCheckLookup table. */
+#define LMN_LOOKUP_RANGE_CHECK 8u
 typedef struct lmn_settings {
-  uint32_t has_lookups; /* must be 0 */
+  uint32_t has_lookups; /* 0 or LMN_LOOKUP_RANGE_CHECK */
 } lmn_settings;
 
 typedef struct lmn_ctx lmn_ctx;

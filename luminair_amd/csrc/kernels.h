@@ -14,8 +14,11 @@ struct TwPtrs {
 };
 
 // ---- a3: AoS rows -> padded SoA columns (write_trace / pack_values)
+struct PadRow {
+  uint32_t v[32];  // the component's padding row (e.g. add/table.rs:40-58)
+};
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
-                          int is_last_col, lmn_stream_t s);
+                          const PadRow& pad, lmn_stream_t s);
 
 // ---- a4: circle FFT passes.  data = ncols columns of 2^log_n words at stride col_stride.
 // dst may equal src (in place).  launch_fft zero-extends src (2^log_src words) to 2^log_n (LDE).
@@ -86,12 +89,14 @@ void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n
                    lmn_stream_t s);
 
 // ---- a6: logup
+constexpr int LOGUP_MAX_REL = 7;
 struct LogupArgs {
-  int k;                       // number of relations (1..3)
-  const uint32_t* val[3];      // value column
-  const uint32_t* id[3];       // tensor-id column
-  const uint32_t* mult[3];     // multiplicity column
-  QM31 z, alpha;
+  int k;                       // number of relations (1..7)
+  const uint32_t* val[LOGUP_MAX_REL];   // value column
+  const uint32_t* id[LOGUP_MAX_REL];    // tensor-id column, nullptr for width-1 relations
+  const uint32_t* mult[LOGUP_MAX_REL];  // multiplicity column
+  int neg[LOGUP_MAX_REL];      // numerator is -mult
+  QM31 z[LOGUP_MAX_REL], alpha[LOGUP_MAX_REL];  // element set of each relation
   uint32_t* inter;             // interaction eval columns (4k columns, stride n)
   QM31* last_tmp;              // S_{k-1} per row (AoS), n entries
   uint32_t* partials;          // per-block partial sums, 4 words each
@@ -116,7 +121,9 @@ struct CompositionArgs {
   uint32_t* out;               // 4 coordinate columns, stride 2^eval_log
   int accumulate;              // out += instead of out =
   int zero_slot;               // 1: Mul's second eval_fixed_mul slot contributes zero (KAT form)
-  QM31 z, alpha;
+  QM31 z, alpha;               // NodeElements
+  QM31 z2, alpha2;             // RangeCheckLookupElements (LessThan, RangeCheckLookup)
+  const uint32_t* pre;         // preprocessed column on the eval domain (RangeCheckLookup)
   const QM31* claimed_shift;   // device: [claimed, shift]
   QM31 coeff[16];              // alpha^(N-1-k) for this component's constraints, in order
   uint32_t zinv[2];            // 1/Z for rows with (s >> log_size) == 0 / 1

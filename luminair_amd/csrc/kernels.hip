@@ -16,7 +16,7 @@ static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b -
 // =============================================================================================
 constexpr int TR_ROWS = 64;
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
-                           uint32_t* __restrict__ cols, int is_last_col) {
+                           uint32_t* __restrict__ cols, PadRow pad) {
   LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
   const int stride = ncols + 1;
   const uint64_t row0 = (uint64_t)blockIdx.x * TR_ROWS;
@@ -28,7 +28,7 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
     if (gr < n_rows)
       v = rows[gr * (uint64_t)ncols + c];
     else
-      v = (c == is_last_col) ? 1u : 0u;
+      v = pad.v[c];
     tile[r * stride + c] = v;
   }
   __syncthreads();
@@ -39,11 +39,12 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
 }
 
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
-                          int is_last_col, lmn_stream_t s) {
+                          const PadRow& pad, lmn_stream_t s) {
   uint64_t size = 1ull << log_size;
   unsigned grid = cdiv(size, TR_ROWS);
   size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
-  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, is_last_col);
+  if (ncols > 32) throw LmnError(-100, "transpose: too many columns");
+  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad);
 }
 
 // =============================================================================================
@@ -777,7 +778,9 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
     QM31 den[K], pre[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      QM31 d = q_sub(q_add_m(q_mul_m(a.alpha, a.id[j][r]), a.val[j][r]), a.z);
+      QM31 d = q_from_m(a.val[j][r]);
+      if (a.id[j]) d = q_add(d, q_mul_m(a.alpha[j], a.id[j][r]));
+      d = q_sub(d, a.z[j]);
       den[j] = d;
       pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
     }
@@ -790,7 +793,9 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      S = q_add(S, q_mul_m(invs[j], a.mult[j][r]));
+      uint32_t mlt = a.mult[j][r];
+      if (a.neg[j]) mlt = m_neg(mlt);
+      S = q_add(S, q_mul_m(invs[j], mlt));
       if (j < K - 1) {
         uint32_t* o = a.inter + (uint64_t)(4 * j) * a.n + r;
         o[0] = S.a;
@@ -820,6 +825,7 @@ void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s) {
     case 1: LMN_LAUNCH(k_logup_fracs<1>, g, b, 0, s, a); break;
     case 2: LMN_LAUNCH(k_logup_fracs<2>, g, b, 0, s, a); break;
     case 3: LMN_LAUNCH(k_logup_fracs<3>, g, b, 0, s, a); break;
+    case 7: LMN_LAUNCH(k_logup_fracs<7>, g, b, 0, s, a); break;
     default: throw LmnError(-100, "logup: unsupported relation count");
   }
 }
@@ -981,15 +987,17 @@ LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint3
 }
 
 // logup constraints for NREL relations; values are passed by value (no indexed private arrays:
-// those get promoted to LDS and cost occupancy)
+// those get promoted to LDS and cost occupancy).  rc[j] != 0: relation j uses the width-1
+// RangeCheckLookupElements (z2) instead of NodeElements (z, alpha); neg: numerator is -mult.
 template <int NREL>
 LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t (&mult)[NREL],
-                             const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], uint32_t s, uint64_t E) {
+                             const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], const bool (&rc)[NREL], bool neg,
+                             uint32_t s, uint64_t E) {
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
     QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * E, E, s);
-    QM31 den = q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
+    QM31 den = rc[j] ? q_sub(q_from_m(val[j]), a.z2) : q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
     QM31 diff;
     if (j < NREL - 1) {
       diff = q_sub(cur, prev);
@@ -998,7 +1006,7 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32
       QM31 pr = load_secure(a.inter + (uint64_t)(4 * j) * E, E, ps);
       diff = q_add(q_sub(q_sub(cur, pr), prev), a.claimed_shift[1]);
     }
-    ca.add_q(q_sub_m(q_mul(diff, den), mult[j]));
+    ca.add_q(q_sub_m(q_mul(diff, den), neg ? m_neg(mult[j]) : mult[j]));
     prev = cur;
   }
 }
@@ -1033,7 +1041,8 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
-    logup_constraints<3>(ca, a, rm, rv, ri, s, E);
+    const bool rc[3] = {false, false, false};
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 2) {
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
     const uint32_t n_node = LMN_COL(4), n_in = LMN_COL(5), n_idx = LMN_COL(6);
@@ -1046,7 +1055,35 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
-    logup_constraints<2>(ca, a, rm, rv, ri, s, E);
+    const bool rc[2] = {false, false};
+    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
+  } else if (KIND == 13) {
+    // LessThan (22 cols; less_than/component.rs:48-185): 9 local constraints, 3 node relations +
+    // 4 range-check relations on the 8-bit limbs of diff
+    const uint32_t node = LMN_COL(0), lhs_id = LMN_COL(1), rhs_id = LMN_COL(2), idx = LMN_COL(3), is_last = LMN_COL(4);
+    const uint32_t n_node = LMN_COL(5), n_lhs = LMN_COL(6), n_rhs = LMN_COL(7), n_idx = LMN_COL(8);
+    const uint32_t lhs = LMN_COL(9), rhs = LMN_COL(10), out = LMN_COL(11), diff = LMN_COL(12), borrow = LMN_COL(13);
+    const uint32_t l0 = LMN_COL(14), l1 = LMN_COL(15), l2 = LMN_COL(16), l3 = LMN_COL(17);
+    const uint32_t m0 = LMN_COL(18), m1 = LMN_COL(19), m2 = LMN_COL(20), md = LMN_COL(21);
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    ca.add_m(m_mul(borrow, m_sub(borrow, 1u)));
+    ca.add_m(m_sub(out, m_mul(m_sub(1u, borrow), 4096u)));
+    ca.add_m(m_sub(m_add(lhs, diff), rhs));  // - borrow * (2^31 - 1), which is 0 in M31
+    ca.add_m(m_sub(diff, m_add(m_add(m_mul(l3, 1u << 24), m_mul(l2, 1u << 16)), m_add(m_mul(l1, 1u << 8), l0))));
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_lhs, lhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[7] = {m0, m1, m2, md, md, md, md}, rv[7] = {lhs, rhs, out, l0, l1, l2, l3};
+    const uint32_t ri[7] = {lhs_id, rhs_id, node, 0u, 0u, 0u, 0u};
+    const bool rc[7] = {false, false, false, true, true, true, true};
+    logup_constraints<7>(ca, a, rm, rv, ri, rc, false, s, E);
+  } else if (KIND == 14) {
+    // RangeCheckLookup: multiplicity column + preprocessed LUT column, relation (-multiplicity, [lut])
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[s]}, ri[1] = {0u};
+    const bool rc[1] = {true};
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, E);
   } else if (KIND == 5 || KIND == 6 || KIND == 16) {
     // SumReduce (14 cols) / MaxReduce (15) / Contiguous (11): shared id/idx prefix, 2 relations
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -1073,7 +1110,8 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
-    logup_constraints<2>(ca, a, rm, rv, ri, s, E);
+    const bool rc[2] = {false, false};
+    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
   } else {
     const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
     const uint32_t val = LMN_COL(5), mult = LMN_COL(6);
@@ -1082,7 +1120,8 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_node, node)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[1] = {mult}, rv[1] = {val}, ri[1] = {node};
-    logup_constraints<1>(ca, a, rm, rv, ri, s, E);
+    const bool rc[1] = {false};
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, E);
   }
 #undef LMN_COL
   QM31 r = q_mul_m(ca.acc, a.zinv[(s >> a.log_size) & 1u]);
@@ -1108,6 +1147,8 @@ void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
     case 2: LMN_LAUNCH(k_composition<2>, g, b, 0, s, a); break;
     case 5: LMN_LAUNCH(k_composition<5>, g, b, 0, s, a); break;
     case 6: LMN_LAUNCH(k_composition<6>, g, b, 0, s, a); break;
+    case 13: LMN_LAUNCH(k_composition<13>, g, b, 0, s, a); break;
+    case 14: LMN_LAUNCH(k_composition<14>, g, b, 0, s, a); break;
     case 15: LMN_LAUNCH(k_composition<15>, g, b, 0, s, a); break;
     case 16: LMN_LAUNCH(k_composition<16>, g, b, 0, s, a); break;
     default: throw LmnError(-100, "composition: unsupported component kind");

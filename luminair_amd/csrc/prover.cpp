@@ -15,14 +15,20 @@ namespace lmn {
 // ------------------------------------------------------------------------------------ components
 // Column layouts / relation wiring: crates/air/src/components/{add,mul,recip,inputs}/{table,component}.rs
 static const ComponentSpec kSpecs[] = {
-    {LMN_KIND_ADD, 15, 4, 3, {12, 13, 14}, {9, 10, 11}, {1, 2, 0}, 6},
-    {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7},
-    {LMN_KIND_RECIP, 13, 3, 2, {11, 12, 0}, {7, 8, 0}, {1, 0, 0}, 5},
-    {LMN_KIND_INPUTS, 7, 2, 1, {6, 0, 0}, {5, 0, 0}, {0, 0, 0}, 3},
+    // kind, n_cols, is_last, n_rel, rel_mult, rel_val, rel_id, n_local, rel_elems, rel_neg, rel_pre, n_pre, n_pad, pad_col, pad_val
+    {LMN_KIND_ADD, 15, 4, 3, {12, 13, 14}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    {LMN_KIND_RECIP, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    {LMN_KIND_INPUTS, 7, 2, 1, {6}, {5}, {0}, 3, {0}, {0}, {0}, 0, 0, {0}, {0}},
     // constraint forms fully visible in the reference (no numerair helper):
-    {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13, 0}, {7, 8, 0}, {1, 0, 0}, 7},   // sum_reduce/component.rs:36-110
-    {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14, 0}, {7, 8, 0}, {1, 0, 0}, 9},   // max_reduce/component.rs
-    {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10, 0}, {7, 8, 0}, {1, 0, 0}, 4},    // contiguous/component.rs
+    {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13}, {7, 8}, {1, 0}, 7, {0}, {0}, {0}, 0, 0, {0}, {0}},   // sum_reduce/component.rs:36-110
+    {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14}, {7, 8}, {1, 0}, 9, {0}, {0}, {0}, 0, 0, {0}, {0}},   // max_reduce/component.rs
+    {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10}, {7, 8}, {1, 0}, 4, {0}, {0}, {0}, 0, 0, {0}, {0}},    // contiguous/component.rs
+    // less_than/component.rs:48-185; padding row less_than/table.rs:47-72 (rhs=1, out=4096, diff=1, limb0=1)
+    {LMN_KIND_LESS_THAN, 22, 4, 7, {18, 19, 20, 21, 21, 21, 21}, {9, 10, 11, 14, 15, 16, 17}, {1, 2, 0, -1, -1, -1, -1}, 9,
+     {0, 0, 0, 1, 1, 1, 1}, {0}, {0}, 0, 4, {10, 11, 12, 14}, {1u, 4096u, 1u, 1u}},
+    // lookups/range_check/component.rs: (-multiplicity, [range_check_8_column_0])
+    {LMN_KIND_RANGE_CHECK_LOOKUP, 1, -1, 1, {0}, {0}, {-1}, 0, {1}, {1}, {1}, 1, 0, {0}, {0}},
 };
 const ComponentSpec* component_spec(int kind) {
   for (auto& s : kSpecs)
@@ -407,6 +413,7 @@ struct Instance {
   QM31 claimed;
   const QM31* d_claimed_shift;  // device [claimed, shift]
   uint32_t* trace_evals;        // device, n_cols x 2^log_size
+  int pre_idx = -1;             // tree-0 column index of the component's preprocessed column (if any)
 };
 
 static QM31 qsub1(QM31 a) { return q_sub_m(a, 1u); }
@@ -435,6 +442,20 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
     out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
     out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
+  } else if (kind == LMN_KIND_RANGE_CHECK_LOOKUP) {
+    // no local constraints
+  } else if (kind == LMN_KIND_LESS_THAN) {
+    QM31 is_last = c[4], not_last = one_minus(is_last), borrow = c[13];
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    out.push_back(q_mul(borrow, qsub1(borrow)));
+    out.push_back(q_sub(c[11], q_mul_m(one_minus(borrow), 4096u)));
+    out.push_back(q_sub(q_add(c[9], c[12]), c[10]));  // - borrow * (2^31 - 1) == 0 in M31
+    out.push_back(q_sub(c[12], q_add(q_add(q_mul_m(c[17], 1u << 24), q_mul_m(c[16], 1u << 16)),
+                                     q_add(q_mul_m(c[15], 1u << 8), c[14]))));
+    out.push_back(q_mul(not_last, q_sub(c[5], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[6], c[1])));
+    out.push_back(q_mul(not_last, q_sub(c[7], c[2])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[8], c[3]))));
   } else if (kind == LMN_KIND_INPUTS) {
     QM31 is_last = c[2], not_last = one_minus(is_last);
     out.push_back(q_mul(is_last, qsub1(is_last)));
@@ -465,7 +486,7 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
 
 static QM31 eval_composition_at_point(const std::vector<Instance>& inst,
                                       const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, QM31 z,
-                                      QM31 alpha_rel, QM31 comp_alpha) {
+                                      QM31 alpha_rel, QM31 z_rc, QM31 comp_alpha) {
   QM31 acc = q_zero();
   for (auto& ci : inst) {
     const ComponentSpec* sp = ci.spec;
@@ -476,8 +497,9 @@ static QM31 eval_composition_at_point(const std::vector<Instance>& inst,
     QM31 shift = q_mul_m(ci.claimed, m_inv((uint32_t)((1ull << ci.log_size) % P31)));
     for (int j = 0; j < sp->n_rel; ++j) {
       const auto* cols = &sv[2][ci.inter_start + 4 * j];
-      QM31 den = q_sub(q_add(main[sp->rel_val[j]], q_mul(alpha_rel, main[sp->rel_id[j]])), z);
-      QM31 num = main[sp->rel_mult[j]];
+      QM31 val = sp->rel_pre[j] ? sv[0][ci.pre_idx][0] : main[sp->rel_val[j]];
+      QM31 den = sp->rel_elems[j] ? q_sub(val, z_rc) : q_sub(q_add(val, q_mul(alpha_rel, main[sp->rel_id[j]])), z);
+      QM31 num = sp->rel_neg[j] ? q_neg(main[sp->rel_mult[j]]) : main[sp->rel_mult[j]];
       QM31 cur, diff;
       if (j < sp->n_rel - 1) {
         cur = q_from_partial_evals(cols[0][0], cols[1][0], cols[2][0], cols[3][0]);
@@ -626,7 +648,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   if (!tables || n_tables == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "no trace tables");
-  if (settings && settings->has_lookups) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "lookup tables are out of scope");
+  if (settings && (settings->has_lookups & ~LMN_LOOKUP_RANGE_CHECK))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only the range-check lookup table is in scope");
   const int lb = (int)cfg.log_blowup;
   const int n_slots = cfg.protocol_variant == LMN_VARIANT_KAT ? 8 : 17;
   HostMarks hm;
@@ -693,9 +716,29 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   StageTimer* total_timer = new StageTimer(this, log, stream_, C_TOTAL);
   std::unique_ptr<StageTimer> total_guard(total_timer);
 
-  // ---- PHASE 0: preprocessed trace — empty tree, root = blake2s("") (prover.rs:54-59)
+  // ---- PHASE 0: preprocessed trace (prover.rs:54-59): empty tree (root = blake2s("")) unless a LUT
+  // component is present; the only LUT in scope is the 8-bit range check (preprocessed.rs:289-296:
+  // row r of `range_check_8_column_0` holds r)
   DevTree tree0;
-  build_merkle(tree0.merkle, {});
+  bool has_range_check = false;
+  for (auto& ti : infos) has_range_check = has_range_check || ti.spec->kind == LMN_KIND_RANGE_CHECK_LOOKUP;
+  if (settings && (settings->has_lookups & LMN_LOOKUP_RANGE_CHECK) && !has_range_check)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "settings announce a range-check LUT but the pie has no RangeCheckLookup table");
+  uint32_t* d_rc_evals = nullptr;
+  constexpr int RC_LOG = 8;
+  if (has_range_check) {
+    std::vector<uint32_t> lut(1u << RC_LOG);
+    for (uint32_t r = 0; r < lut.size(); ++r) lut[r] = r;
+    d_rc_evals = upload_vec(lut);
+    uint32_t* coeffs = arena_.alloc_words(lut.size());
+    launch_ifft(coeffs, lut.size(), d_rc_evals, lut.size(), 1, RC_LOG, itw(RC_LOG), stream_);
+    tree0.cols.push_back({RC_LOG, coeffs, nullptr});
+    lde_and_merkle(tree0);
+    lmn_sync(stream_);
+    tree0.merkle.finish_root();
+  } else {
+    build_merkle(tree0.merkle, {});
+  }
   channel.mix_root(tree0.merkle.root);
 
   // ---- PHASE 1: main trace (prover.rs:70-179)
@@ -712,11 +755,15 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       }
       uint64_t n = 1ull << ti.log_size;
       uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * n);
-      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, ti.spec->is_last_col, stream_);
+      PadRow pad{};
+      if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
+      for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
+      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, pad, stream_);
       Instance ci{};
       ci.spec = ti.spec;
       ci.log_size = ti.log_size;
       ci.trace_evals = evals;
+      ci.pre_idx = ti.spec->n_pre ? 0 : -1;
       inst.push_back(ci);
       proof.claim[ti.spec->kind] = ti.log_size;
     }
@@ -749,7 +796,15 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // ---- PHASE 2: interaction trace (prover.rs:186-298)
   std::vector<QM31> rel = channel.draw_felts(2);  // NodeElements: z, alpha
   const QM31 z = rel[0], alpha_rel = rel[1];
-  for (int k = 0; k < (cfg.protocol_variant == LMN_VARIANT_KAT ? 1 : 4); ++k) channel.draw_felts(2);  // LookupElements
+  // LookupElements::draw (lookups/mod.rs:44-51): KAT era one LUT relation; HEAD: sin, exp2, log2, range_check
+  QM31 z_rc = q_zero(), alpha_rc = q_zero();
+  for (int k = 0; k < (cfg.protocol_variant == LMN_VARIANT_KAT ? 1 : 4); ++k) {
+    std::vector<QM31> d = channel.draw_felts(2);
+    if (k == 3) {
+      z_rc = d[0];
+      alpha_rc = d[1];
+    }
+  }
   DevTree tree2;
   {
     StageTimer st(this, log, stream_, C_LOGUP);
@@ -762,12 +817,17 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       LogupArgs a{};
       a.k = sp->n_rel;
       for (int j = 0; j < sp->n_rel; ++j) {
-        a.val[j] = ci.trace_evals + (uint64_t)sp->rel_val[j] * n;
-        a.id[j] = ci.trace_evals + (uint64_t)sp->rel_id[j] * n;
+        if (sp->rel_elems[j] && cfg.protocol_variant == LMN_VARIANT_KAT)
+          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "range-check relations need the PINNED protocol variant");
+        if (sp->rel_pre[j] && (uint64_t)(1u << RC_LOG) != n)
+          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "RangeCheckLookup table must have exactly 256 rows");
+        a.val[j] = sp->rel_pre[j] ? d_rc_evals : ci.trace_evals + (uint64_t)sp->rel_val[j] * n;
+        a.id[j] = sp->rel_id[j] >= 0 ? ci.trace_evals + (uint64_t)sp->rel_id[j] * n : nullptr;
         a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * n;
+        a.neg[j] = sp->rel_neg[j];
+        a.z[j] = sp->rel_elems[j] ? z_rc : z;
+        a.alpha[j] = sp->rel_elems[j] ? alpha_rc : alpha_rel;
       }
-      a.z = z;
-      a.alpha = alpha_rel;
       a.inter = ievals;
       a.last_tmp = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
       int nb = logup_num_blocks((uint32_t)n);
@@ -838,6 +898,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       a.accumulate = first ? 0 : 1;
       a.z = z;
       a.alpha = alpha_rel;
+      a.z2 = z_rc;
+      a.alpha2 = alpha_rc;
+      a.pre = ci.pre_idx >= 0 ? tree0.cols[ci.pre_idx].lde : nullptr;
       a.claimed_shift = ci.d_claimed_shift;
       int nc = ci.spec->n_local + ci.spec->n_rel;
       for (int k = 0; k < nc; ++k) a.coeff[k] = powers[n_total - 1 - (k0 + k)];
@@ -902,6 +965,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   }
   // sample point indices per tree/column, in sampled_values order
   std::vector<std::vector<std::vector<int>>> spoints(4);
+  spoints[0].assign(tree0.cols.size(), {0});
   spoints[1].assign(tree1.cols.size(), {0});
   spoints[2].assign(tree2.cols.size(), {0});
   spoints[3].assign(4, {0});
@@ -913,12 +977,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   {
     StageTimer st(this, log, stream_, C_OODS);
     std::vector<EvalJob> jobs;
-    for (int t = 1; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
       for (size_t c = 0; c < trees[t]->cols.size(); ++c)
         for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p});
     std::vector<QM31> vals = eval_at_points(jobs, points, comp_log);
     size_t k = 0;
-    for (int t = 1; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t) {
       sampled[t].resize(trees[t]->cols.size());
       for (size_t c = 0; c < trees[t]->cols.size(); ++c)
         for (size_t p = 0; p < spoints[t][c].size(); ++p) sampled[t][c].push_back(vals[k++]);
@@ -935,7 +999,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
   {
     QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
-    QM31 rhs = eval_composition_at_point(inst, sampled, oods, z, alpha_rel, comp_alpha);
+    QM31 rhs = eval_composition_at_point(inst, sampled, oods, z, alpha_rel, z_rc, comp_alpha);
     if (!q_eq(lhs, rhs)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
   }
 
@@ -947,7 +1011,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     std::vector<std::pair<int, QM31>> samples;  // (point index, value)
   };
   std::vector<FlatCol> flat;
-  for (int t = 1; t < 4; ++t)
+  for (int t = 0; t < 4; ++t)
     for (size_t c = 0; c < trees[t]->cols.size(); ++c) {
       FlatCol f{trees[t]->cols[c].lde, trees[t]->cols[c].log_size + lb, {}};
       for (size_t p = 0; p < spoints[t][c].size(); ++p) f.samples.push_back({spoints[t][c][p], sampled[t][c][p]});

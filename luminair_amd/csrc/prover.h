@@ -11,13 +11,21 @@
 
 namespace lmn {
 
+constexpr int MAX_REL = 7;
 struct ComponentSpec {
   int kind;
   int n_cols;
   int is_last_col;
   int n_rel;
-  int rel_mult[3], rel_val[3], rel_id[3];
-  int n_local;  // number of local constraints (including zero slots)
+  int rel_mult[MAX_REL], rel_val[MAX_REL], rel_id[MAX_REL];  // rel_id < 0: width-1 relation (value only)
+  int n_local;                // number of local constraints (including zero slots)
+  int rel_elems[MAX_REL];     // 0 NodeElements, 1 RangeCheckLookupElements
+  int rel_neg[MAX_REL];       // numerator is -mult
+  int rel_pre[MAX_REL];       // rel_val indexes the component's preprocessed columns
+  int n_pre;                  // preprocessed (tree 0) columns used: only the 8-bit range-check column so far
+  int n_pad;                  // extra non-zero padding cells besides is_last_col = 1
+  int pad_col[4];
+  uint32_t pad_val[4];
 };
 const ComponentSpec* component_spec(int kind);
 

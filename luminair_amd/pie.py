@@ -32,7 +32,8 @@ class TraceTableKind(IntEnum):
 
 # column counts of the components on the hot path (N_TRACE_COLUMNS in each witness.rs)
 N_COLUMNS = {TraceTableKind.Add: 15, TraceTableKind.Mul: 16, TraceTableKind.Recip: 13, TraceTableKind.Inputs: 7,
-             TraceTableKind.SumReduce: 14, TraceTableKind.MaxReduce: 15, TraceTableKind.Contiguous: 11}
+             TraceTableKind.SumReduce: 14, TraceTableKind.MaxReduce: 15, TraceTableKind.Contiguous: 11,
+             TraceTableKind.LessThan: 22, TraceTableKind.RangeCheckLookup: 1}
 
 
 class LuminairError(Exception):

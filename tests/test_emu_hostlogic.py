@@ -95,6 +95,11 @@ def test_emu_pinned_variant_with_inputs_component(root):
     got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
     want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED))
     assert got == want
+    # LessThan + RangeCheckLookup: preprocessed tree 0, width-1 relations with their own element set
+    tabs2 = syn.less_than_graph(40, 5)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs2])
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs2], variant=ProtocolVariant.PINNED))
+    assert got == want
     # the KAT-variant context has no claim slot for kind 15
     kat_ctx = backend.Context(0, None, lib)
     with pytest.raises(backend.LuminairBackendError) as e:

@@ -206,6 +206,7 @@ def _oracle_bytes_pinned(tabs):
     ("2b-100", syn.config2_graph_faithful(100, 3)),
     ("2b-2^12", syn.config2_graph_faithful(1 << 12, 4)),
     ("add-only-pinned", syn.config2_add_only(300, 5)),
+    ("less-than+range-check-lut", syn.less_than_graph(1000, 6)),
 ])
 def test_gpu_pinned_variant_equals_oracle(gpu_prover_pinned, name, tabs):
     got = _gpu_bytes(gpu_prover_pinned, tabs)
@@ -220,3 +221,13 @@ def test_gpu_config2b_full_size_verifies(gpu_prover_pinned):
     p = from_bincode(_gpu_bytes(gpu_prover_pinned, syn.config2_graph_faithful(1 << 20, 42)), 17)
     assert p.claim[0] == 20 and p.claim[15] == 21
     verify(p, ProtocolVariant.PINNED)
+
+
+def test_gpu_less_than_2_18_rows_equals_c_oracle_bytes(gpu_prover_pinned, c_oracle):
+    """Add + LessThan (7 logup relations, range-check LUT in tree 0) + Inputs at 2^18 rows, byte-for-byte."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.less_than_graph(1 << 18, 9)
+    want = to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=c_oracle))
+    assert _gpu_bytes(gpu_prover_pinned, tabs) == want

@@ -181,3 +181,32 @@ def test_oracle_linear_layer_components_verify():
     with pytest.raises(ProvingError):
         prove([(bad[0][0], bad[0][1].astype(np.uint64)), (bad[1][0], bad[1][1].astype(np.uint64)),
                (bad[2][0], rows.astype(np.uint64))])
+
+
+def test_oracle_less_than_with_range_check_lut():
+    """LessThan + RangeCheckLookup (PINNED variant): tree 0 holds the preprocessed 8-bit LUT column,
+    the four limb relations use RangeCheckLookupElements, logup sums cancel."""
+    from oracle.prover import ProvingError
+    tabs = syn.less_than_graph(100, 3)
+    proof = prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED)
+    assert [c for c in proof.claim if c is not None] == [7, 7, 8, 9]
+    assert [len(t) for t in proof.proof.sampled_values] == [1, 15 + 22 + 1 + 7, 12 + 28 + 4 + 4, 4]
+    assert proof.proof.commitments[0] != hashlib.blake2s(b"").digest()
+    verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.PINNED)
+    # a limb outside its recomposition is caught by the AIR
+    rows = tabs[1][1].copy()
+    rows[3, 14] = (int(rows[3, 14]) + 1) % P
+    with pytest.raises(ProvingError):
+        prove([(tabs[0][0], tabs[0][1].astype(np.uint64)), (13, rows.astype(np.uint64)),
+               (tabs[2][0], tabs[2][1].astype(np.uint64)), (tabs[3][0], tabs[3][1].astype(np.uint64))],
+              variant=ProtocolVariant.PINNED)
+    # wrong LUT multiplicities prove fine but fail the verifier's logup check
+    bad = tabs[2][1].copy()
+    bad[7, 0] += 1
+    p2 = prove([(tabs[0][0], tabs[0][1].astype(np.uint64)), (tabs[1][0], tabs[1][1].astype(np.uint64)),
+                (14, bad.astype(np.uint64)), (tabs[3][0], tabs[3][1].astype(np.uint64))], variant=ProtocolVariant.PINNED)
+    with pytest.raises(VerificationError, match="InvalidLogUp"):
+        verify(p2, ProtocolVariant.PINNED)
+    # range-check relations need the HEAD relation draws
+    with pytest.raises(ProvingError):
+        prove([(k, r.astype(np.uint64)) for k, r in tabs[:2]], variant=ProtocolVariant.KAT)
