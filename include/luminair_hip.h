@@ -30,6 +30,8 @@ extern "C" {
 #define LMN_ERR_INVALID_ARGUMENT (-6)     /* malformed table / unsupported component / config     */
 #define LMN_ERR_OUT_OF_MEMORY (-7)
 #define LMN_ERR_NO_DEVICE (-8)            /* no HIP device: the library never falls back to CPU   */
+#define LMN_ERR_VERIFICATION (-9)         /* StwoVerifierError (verify only)                      */
+#define LMN_ERR_INVALID_LOGUP (-10)       /* InvalidLogUp: claimed sums do not cancel (verify)    */
 #define LMN_ERR_INTERNAL (-100)
 
 /* TraceTable kinds, in `enum TraceTable` order (crates/air/src/pie.rs:31-66). */
@@ -120,6 +122,12 @@ int lmn_prove(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_
               uint8_t** proof_bincode, size_t* proof_len);
 void lmn_free(void* p);
 int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out);
+
+/* Replaces `verify(proof, settings)` (/root/reference/crates/verifiers/rust/src/verifier.rs:21-143).
+ * Host-only (the reference verifier is CPU code too); needs no context and no GPU.  Returns LMN_OK,
+ * LMN_ERR_INVALID_LOGUP, LMN_ERR_VERIFICATION or LMN_ERR_SERIALIZATION; the message of the last
+ * failure on this thread is available through lmn_last_error(NULL). */
+int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant);
 
 /* Device residency helpers for callers that keep trace tables in HBM. */
 int lmn_upload(lmn_ctx* ctx, const void* host, size_t bytes, void** device_out);

@@ -19,6 +19,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libluminair_hip.so")
 LMN_OK = 0
 ERR_EMPTY_TRACE, ERR_MAIN_TRACE, ERR_INTERACTION_TRACE, ERR_CONSTRAINTS = -1, -2, -3, -4
 ERR_SERIALIZATION, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_INTERNAL = -5, -6, -7, -8, -100
+ERR_VERIFICATION, ERR_INVALID_LOGUP = -9, -10
 VARIANT_KAT, VARIANT_PINNED = 0, 1
 TABLE_ROWS_ON_DEVICE = 1
 
@@ -50,7 +51,7 @@ class LmnTimings(C.Structure):
 
 
 EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
-           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_upload", "lmn_device_free",
+           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest"]
 
@@ -85,6 +86,7 @@ class Library:
         lib.lmn_get_timings.argtypes = [C.c_void_p, C.POINTER(LmnTimings)]
         lib.lmn_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lmn_verify.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.c_uint32]
         lib.lmn_op_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.lmn_op_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.lmn_op_merkle_root.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32,
@@ -99,6 +101,13 @@ class Library:
 
     def kind_columns(self, kind: int) -> int:
         return int(self.lib.lmn_kind_columns(kind))
+
+    def verify(self, proof: bytes, variant: int = VARIANT_KAT) -> None:
+        """`verify(proof, settings)` on the host; raises LuminairBackendError on rejection."""
+        rc = self.lib.lmn_verify(proof, len(proof), None, variant)
+        if rc != LMN_OK:
+            msg = self.lib.lmn_last_error(None).decode() or self.lib.lmn_strerror(rc).decode()
+            raise LuminairBackendError(rc, msg)
 
 
 _default_library: Optional[Library] = None

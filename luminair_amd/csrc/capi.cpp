@@ -21,7 +21,7 @@ int guard(lmn_ctx* ctx, F&& f) {
   } catch (const LmnError& e) {
     if (ctx) ctx->last_error = e.what();
     int c = e.code;
-    return (c == -100 || (c <= -1 && c >= -8)) ? c : LMN_ERR_INTERNAL;
+    return (c == -100 || (c <= -1 && c >= -10)) ? c : LMN_ERR_INTERNAL;
   } catch (const std::bad_alloc&) {
     if (ctx) ctx->last_error = "host allocation failed";
     return LMN_ERR_OUT_OF_MEMORY;
@@ -46,6 +46,8 @@ const char* lmn_strerror(int code) {
     case LMN_ERR_INVALID_ARGUMENT: return "invalid argument";
     case LMN_ERR_OUT_OF_MEMORY: return "out of memory";
     case LMN_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+    case LMN_ERR_VERIFICATION: return "StwoVerifierError";
+    case LMN_ERR_INVALID_LOGUP: return "InvalidLogUp";
     default: return "internal error";
   }
 }
@@ -111,6 +113,15 @@ int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out) {
   if (!ctx || !out) return LMN_ERR_INVALID_ARGUMENT;
   *out = ctx->impl->timings;
   return LMN_OK;
+}
+
+int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant) {
+  if (!proof_bincode) return LMN_ERR_INVALID_ARGUMENT;
+  if (settings && (settings->has_lookups & ~LMN_LOOKUP_RANGE_CHECK)) return LMN_ERR_INVALID_ARGUMENT;
+  lmn_ctx tmp{nullptr, {}};
+  int rc = guard(&tmp, [&] { lmn::verify_proof(proof_bincode, proof_len, protocol_variant); });
+  g_create_error = tmp.last_error;
+  return rc;
 }
 
 int lmn_upload(lmn_ctx* ctx, const void* host, size_t bytes, void** device_out) {

@@ -39,6 +39,22 @@ inline uint32_t bit_reverse(uint32_t i, int bits) {
   return r;
 }
 
+// point of CanonicCoset(log).circle_domain() stored at index s (bit-reversed order)
+inline Pt domain_point(int log, uint32_t s) {
+  uint32_t idx = bit_reverse(s, log);
+  uint32_t half = 1u << (log - 1);
+  uint32_t init = 1u << (30 - log);
+  uint32_t step = log >= 2 ? (1u << (32 - log)) : 0u;
+  if (idx < half) return pt_of_index(init + idx * step);
+  Pt p = pt_of_index(init + (idx - half) * step);
+  return {p.x, m_neg(p.y)};
+}
+// x-coordinate of LineDomain(Coset::half_odds(log)) at bit-reversed index i (FRI line layers)
+inline uint32_t line_domain_x(int log, uint32_t i) {
+  uint32_t init = 1u << (31 - (log + 2)), step = log >= 1 ? (1u << (31 - log)) : 0u;
+  return pt_of_index(init + bit_reverse(i, log) * step).x;
+}
+
 struct QPt {
   QM31 x, y;
 };

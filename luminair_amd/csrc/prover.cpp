@@ -266,17 +266,6 @@ TwPtrs Context::itw(int m) const {
   return t;
 }
 
-// point of CanonicCoset(log).circle_domain() stored at index s (bit-reversed order)
-static Pt domain_point(int log, uint32_t s) {
-  uint32_t idx = bit_reverse(s, log);
-  uint32_t half = 1u << (log - 1);
-  uint32_t init = 1u << (30 - log);
-  uint32_t step = log >= 2 ? (1u << (32 - log)) : 0u;
-  if (idx < half) return pt_of_index(init + idx * step);
-  Pt p = pt_of_index(init + (idx - half) * step);
-  return {p.x, m_neg(p.y)};
-}
-
 // ------------------------------------------------------------------------------------ timed launches
 void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size,
                                  uint32_t* out) {
@@ -406,16 +395,6 @@ void Context::lde_and_merkle(DevTree& tree) {
 }
 
 // ------------------------------------------------------------------------------------ host-side AIR at a point
-struct Instance {
-  const ComponentSpec* spec;
-  int log_size;
-  int main_start, inter_start;  // column offsets inside trees 1 / 2
-  QM31 claimed;
-  const QM31* d_claimed_shift;  // device [claimed, shift]
-  uint32_t* trace_evals;        // device, n_cols x 2^log_size
-  int pre_idx = -1;             // tree-0 column index of the component's preprocessed column (if any)
-};
-
 static QM31 qsub1(QM31 a) { return q_sub_m(a, 1u); }
 static QM31 one_minus(QM31 a) { return q_sub(q_one(), a); }
 
@@ -484,7 +463,7 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
   return out;
 }
 
-static QM31 eval_composition_at_point(const std::vector<Instance>& inst,
+QM31 eval_composition_at_point(const std::vector<Instance>& inst,
                                       const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, QM31 z,
                                       QM31 alpha_rel, QM31 z_rc, QM31 comp_alpha) {
   QM31 acc = q_zero();

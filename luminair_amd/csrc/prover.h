@@ -29,6 +29,22 @@ struct ComponentSpec {
 };
 const ComponentSpec* component_spec(int kind);
 
+// one component of a proof: shared by the prover and the host-side verifier
+struct Instance {
+  const ComponentSpec* spec;
+  int log_size;
+  int main_start, inter_start;  // column offsets inside trees 1 / 2
+  QM31 claimed;
+  const QM31* d_claimed_shift = nullptr;  // device [claimed, shift] (prover only)
+  uint32_t* trace_evals = nullptr;        // device, n_cols x 2^log_size (prover only)
+  int pre_idx = -1;             // tree-0 column index of the component's preprocessed column (if any)
+};
+// sum_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values
+QM31 eval_composition_at_point(const std::vector<Instance>& inst, const std::vector<std::vector<std::vector<QM31>>>& sv,
+                               QPt oods, QM31 z, QM31 alpha_rel, QM31 z_rc, QM31 comp_alpha);
+// verify(proof, settings): crates/verifiers/rust/src/verifier.rs:21-143 (host only, no GPU work)
+void verify_proof(const uint8_t* data, size_t len, uint32_t protocol_variant);
+
 // bump allocator over one device slab; reset per proof
 class Arena {
  public:

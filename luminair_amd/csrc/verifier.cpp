@@ -1,0 +1,548 @@
+// verify(proof, settings): host-side replacement for
+// /root/reference/crates/verifiers/rust/src/verifier.rs:21-143 (replay the three commitments, check
+// the logup sum `crates/air/src/utils.rs:29-57`, then stwo::core::verifier::verify) — SURVEY.md §8f-2.
+// Pure host code (the reference verifier is CPU code too); no GPU work, no oracle dependency.
+#include <algorithm>
+#include <set>
+
+#include "prover.h"
+
+namespace lmn {
+
+namespace {
+
+constexpr int ERR_VERIFY = LMN_ERR_VERIFICATION;
+[[noreturn]] void fail(const std::string& what) { throw LmnError(ERR_VERIFY, "StwoVerifierError: " + what); }
+
+// ---- bincode reader
+struct Reader {
+  const uint8_t* p;
+  size_t n, o = 0;
+  void need(size_t k) {
+    if (o + k > n) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: truncated proof");
+  }
+  uint8_t u8() {
+    need(1);
+    return p[o++];
+  }
+  uint32_t u32() {
+    need(4);
+    uint32_t v = (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24);
+    o += 4;
+    return v;
+  }
+  uint64_t u64() {
+    uint64_t lo = u32(), hi = u32();
+    return lo | (hi << 32);
+  }
+  size_t len(size_t elem_bytes) {
+    uint64_t l = u64();
+    if (elem_bytes && l > (n - o) / elem_bytes + 1) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: bad length");
+    return (size_t)l;
+  }
+  QM31 q() { return QM31{u32(), u32(), u32(), u32()}; }
+  Hash32 hash() {
+    Hash32 h;
+    for (int i = 0; i < 8; ++i) h.w[i] = u32();
+    return h;
+  }
+  Decommitment decommit() {
+    Decommitment d;
+    size_t nh = len(32);
+    for (size_t i = 0; i < nh; ++i) d.hash_witness.push_back(hash());
+    size_t nc = len(4);
+    for (size_t i = 0; i < nc; ++i) d.column_witness.push_back(u32());
+    return d;
+  }
+  FriLayerProof layer() {
+    FriLayerProof l;
+    size_t nw = len(16);
+    for (size_t i = 0; i < nw; ++i) l.fri_witness.push_back(q());
+    l.decommitment = decommit();
+    l.commitment = hash();
+    return l;
+  }
+};
+
+Proof parse_proof(const uint8_t* data, size_t n, int n_slots) {
+  Reader r{data, n};
+  Proof p;
+  for (int i = 0; i < n_slots; ++i) p.claim.push_back(r.u8() ? (int)r.u32() : -1);
+  for (int i = 0; i < n_slots; ++i) {
+    bool some = r.u8() != 0;
+    p.interaction_claim.push_back({some, some ? r.q() : q_zero()});
+  }
+  p.pow_bits = r.u32();
+  p.log_blowup = r.u32();
+  p.log_last_layer = r.u32();
+  p.n_queries = r.u64();
+  size_t nc = r.len(32);
+  for (size_t i = 0; i < nc; ++i) p.commitments.push_back(r.hash());
+  size_t nt = r.len(8);
+  for (size_t t = 0; t < nt; ++t) {
+    std::vector<std::vector<QM31>> tree;
+    size_t ncol = r.len(8);
+    for (size_t c = 0; c < ncol; ++c) {
+      std::vector<QM31> col;
+      size_t np = r.len(16);
+      for (size_t k = 0; k < np; ++k) col.push_back(r.q());
+      tree.push_back(col);
+    }
+    p.sampled_values.push_back(tree);
+  }
+  size_t nd = r.len(16);
+  for (size_t i = 0; i < nd; ++i) p.decommitments.push_back(r.decommit());
+  size_t nq = r.len(8);
+  for (size_t t = 0; t < nq; ++t) {
+    std::vector<uint32_t> v;
+    size_t k = r.len(4);
+    for (size_t i = 0; i < k; ++i) v.push_back(r.u32());
+    p.queried_values.push_back(v);
+  }
+  p.proof_of_work = r.u64();
+  p.first_layer = r.layer();
+  size_t ni = r.len(40);
+  for (size_t i = 0; i < ni; ++i) p.inner_layers.push_back(r.layer());
+  size_t nl = r.len(16);
+  for (size_t i = 0; i < nl; ++i) p.last_layer_coeffs.push_back(r.q());
+  p.last_layer_log_size = r.u32();
+  if (r.o != n) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: trailing bytes");
+  return p;
+}
+
+// ---- MerkleVerifier::verify
+bool merkle_verify(const Hash32& root, std::vector<int> col_logs, const std::map<int, std::vector<uint32_t>>& queries,
+                   const std::vector<uint32_t>& queried, const Decommitment& d) {
+  std::sort(col_logs.begin(), col_logs.end(), std::greater<int>());
+  if (col_logs.empty()) {
+    Hash32 e = b2_hash_words(nullptr, 0);
+    return memcmp(e.w, root.w, 32) == 0 && queried.empty() && d.hash_witness.empty() && d.column_witness.empty();
+  }
+  const int max_log = col_logs[0];
+  std::map<int, int> ncols;
+  for (int l : col_logs) ncols[l]++;
+  size_t qi = 0, hi = 0, ci = 0;
+  std::vector<std::pair<uint32_t, Hash32>> last;
+  static const std::vector<uint32_t> none;
+  for (int log = max_log; log >= 0; --log) {
+    int nc = ncols.count(log) ? ncols[log] : 0;
+    auto it = queries.find(log);
+    const std::vector<uint32_t>& cq = it != queries.end() ? it->second : none;
+    size_t pi = 0, cqi = 0;
+    std::vector<std::pair<uint32_t, Hash32>> total;
+    while (pi < last.size() || cqi < cq.size()) {
+      uint32_t node;
+      if (pi < last.size() && cqi < cq.size())
+        node = std::min(last[pi].first / 2, cq[cqi]);
+      else if (pi < last.size())
+        node = last[pi].first / 2;
+      else
+        node = cq[cqi];
+      std::vector<uint32_t> words;
+      if (log < max_log) {
+        Hash32 l, r;
+        if (pi < last.size() && last[pi].first == 2 * node)
+          l = last[pi++].second;
+        else if (hi < d.hash_witness.size())
+          l = d.hash_witness[hi++];
+        else
+          return false;
+        if (pi < last.size() && last[pi].first == 2 * node + 1)
+          r = last[pi++].second;
+        else if (hi < d.hash_witness.size())
+          r = d.hash_witness[hi++];
+        else
+          return false;
+        words.insert(words.end(), l.w, l.w + 8);
+        words.insert(words.end(), r.w, r.w + 8);
+      }
+      bool is_q = cqi < cq.size() && cq[cqi] == node;
+      if (is_q) ++cqi;
+      for (int k = 0; k < nc; ++k) {
+        if (is_q) {
+          if (qi >= queried.size()) return false;
+          words.push_back(queried[qi++]);
+        } else {
+          if (ci >= d.column_witness.size()) return false;
+          words.push_back(d.column_witness[ci++]);
+        }
+      }
+      total.push_back({node, b2_hash_words(words.data(), words.size())});
+    }
+    last.swap(total);
+  }
+  if (qi != queried.size() || hi != d.hash_witness.size() || ci != d.column_witness.size()) return false;
+  return last.size() == 1 && memcmp(last[0].second.w, root.w, 32) == 0;
+}
+
+std::vector<uint32_t> fold_pos(const std::vector<uint32_t>& p, int n) {
+  std::vector<uint32_t> out;
+  for (auto v : p) {
+    uint32_t q = v >> n;
+    if (out.empty() || out.back() != q) out.push_back(q);
+  }
+  return out;
+}
+
+// sibling pairs of a sparse evaluation: queried values come from `known`, the rest from the witness
+bool rebuild_pairs(const std::vector<uint32_t>& qpos, const std::map<uint32_t, QM31>& known,
+                   const std::vector<QM31>& witness, size_t& wi, std::vector<uint32_t>& dec_pos,
+                   std::map<uint32_t, QM31>& vals) {
+  size_t i = 0;
+  while (i < qpos.size()) {
+    uint32_t start = (qpos[i] >> 1) << 1;
+    std::set<uint32_t> subset;
+    while (i < qpos.size() && ((qpos[i] >> 1) << 1) == start) subset.insert(qpos[i++]);
+    for (uint32_t pos = start; pos < start + 2; ++pos) {
+      dec_pos.push_back(pos);
+      if (subset.count(pos)) {
+        auto it = known.find(pos);
+        if (it == known.end()) return false;
+        vals[pos] = it->second;
+      } else {
+        if (wi >= witness.size()) return false;
+        vals[pos] = witness[wi++];
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
+  if (variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  const int n_slots = variant == LMN_VARIANT_KAT ? 8 : 17;
+  Proof p = parse_proof(data, len, n_slots);
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 0\n", 0);
+  const int lb = (int)p.log_blowup;
+  if (lb != 1) fail("unsupported blow-up");
+  if (p.commitments.size() != 4 || p.sampled_values.size() != 4 || p.decommitments.size() != 4 ||
+      p.queried_values.size() != 4)
+    fail("expected 4 commitment trees");
+  if (p.n_queries == 0 || p.n_queries > 1024 || p.log_last_layer > 10) fail("bad PCS config");
+
+  // components in struct order; tree layouts implied by the claim (Claim::log_sizes, components/mod.rs:164-170)
+  std::vector<Instance> inst;
+  int m_off = 0, i_off = 0;
+  bool has_rc = false;
+  for (int kind = 0; kind < n_slots; ++kind) {
+    if (p.claim[kind] < 0) continue;
+    const ComponentSpec* sp = component_spec(kind);
+    if (!sp) fail("claim names a component outside the backend's scope");
+    if (p.claim[kind] < 4 || p.claim[kind] > 26) fail("bad log_size");
+    if (!p.interaction_claim[kind].first) fail("missing interaction claim");
+    Instance ci{};
+    ci.spec = sp;
+    ci.log_size = p.claim[kind];
+    ci.main_start = m_off;
+    ci.inter_start = i_off;
+    ci.claimed = p.interaction_claim[kind].second;
+    ci.pre_idx = sp->n_pre ? 0 : -1;
+    has_rc = has_rc || sp->n_pre;
+    m_off += sp->n_cols;
+    i_off += 4 * sp->n_rel;
+    inst.push_back(ci);
+  }
+  if (inst.empty()) fail("empty claim");
+  for (int kind = 0; kind < n_slots; ++kind)
+    if (p.claim[kind] < 0 && p.interaction_claim[kind].first) fail("interaction claim without claim");
+  std::vector<std::vector<int>> tree_logs(4);
+  if (has_rc) tree_logs[0].push_back(8);
+  int max_log = 0;
+  for (auto& ci : inst) {
+    for (int c = 0; c < ci.spec->n_cols; ++c) tree_logs[1].push_back(ci.log_size);
+    for (int c = 0; c < 4 * ci.spec->n_rel; ++c) tree_logs[2].push_back(ci.log_size);
+    max_log = std::max(max_log, ci.log_size);
+  }
+  for (int k = 0; k < 4; ++k) tree_logs[3].push_back(max_log + 1);
+
+  // ---- transcript replay (verifier.rs:61-106)
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 1\n", 1);
+  Channel ch(variant);
+  ch.mix_root(p.commitments[0]);
+  for (int kind = 0; kind < n_slots; ++kind)
+    if (p.claim[kind] >= 0) ch.mix_u64((uint64_t)p.claim[kind]);
+  ch.mix_root(p.commitments[1]);
+  std::vector<QM31> rel = ch.draw_felts(2);
+  QM31 z_rc = q_zero();
+  for (int k = 0; k < (variant == LMN_VARIANT_KAT ? 1 : 4); ++k) {
+    std::vector<QM31> d = ch.draw_felts(2);
+    if (k == 3) z_rc = d[0];
+  }
+  if (has_rc && variant == LMN_VARIANT_KAT) fail("range-check components need the PINNED variant");
+  QM31 tot = q_zero();
+  for (auto& ci : inst) tot = q_add(tot, ci.claimed);
+  if (!q_is_zero(tot)) throw LmnError(LMN_ERR_INVALID_LOGUP, "InvalidLogUp");   // log_sum_valid, verifier.rs:97-99
+  for (auto& ci : inst) ch.mix_felts({ci.claimed});
+  ch.mix_root(p.commitments[2]);
+  const QM31 comp_alpha = ch.draw_felt();
+  ch.mix_root(p.commitments[3]);
+  QM31 tt = ch.draw_felt();
+  QM31 t2 = q_sqr(tt);
+  QM31 tinv = q_inv(q_add_m(t2, 1u));
+  QPt oods{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
+
+  // ---- sample points per column
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 2\n", 2);
+  std::vector<std::vector<std::vector<QPt>>> pts(4);
+  for (size_t c = 0; c < tree_logs[0].size(); ++c) pts[0].push_back({oods});
+  for (size_t c = 0; c < tree_logs[1].size(); ++c) pts[1].push_back({oods});
+  for (auto& ci : inst) {
+    Pt stp = pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu);
+    QPt prev = qpt_add_m(oods, stp);
+    int ni = 4 * ci.spec->n_rel;
+    for (int c = 0; c < ni; ++c) {
+      if (c >= ni - 4)
+        pts[2].push_back({prev, oods});
+      else
+        pts[2].push_back({oods});
+    }
+  }
+  for (int k = 0; k < 4; ++k) pts[3].push_back({oods});
+  for (int t = 0; t < 4; ++t) {
+    if (p.sampled_values[t].size() != pts[t].size()) fail("sampled values shape");
+    for (size_t c = 0; c < pts[t].size(); ++c)
+      if (p.sampled_values[t][c].size() != pts[t][c].size()) fail("sampled values shape");
+  }
+  // ---- OODS composition identity
+  {
+    auto& s3 = p.sampled_values[3];
+    QM31 lhs = q_from_partial_evals(s3[0][0], s3[1][0], s3[2][0], s3[3][0]);
+    QM31 rhs = eval_composition_at_point(inst, p.sampled_values, oods, rel[0], rel[1], z_rc, comp_alpha);
+    if (!q_eq(lhs, rhs)) fail("OodsNotMatching");
+  }
+  {
+    std::vector<QM31> flat;
+    for (auto& t : p.sampled_values)
+      for (auto& c : t)
+        for (auto& v : c) flat.push_back(v);
+    ch.mix_felts(flat);
+  }
+  const QM31 quot_alpha = ch.draw_felt();
+
+  // ---- FRI commit phase replay
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 3\n", 3);
+  std::set<int, std::greater<int>> size_set;
+  for (auto& t : tree_logs)
+    for (int l : t) size_set.insert(l + lb);
+  std::vector<int> sizes(size_set.begin(), size_set.end());
+  const int top = sizes[0];
+  ch.mix_root(p.first_layer.commitment);
+  std::vector<QM31> alphas{ch.draw_felt()};
+  for (auto& l : p.inner_layers) {
+    ch.mix_root(l.commitment);
+    alphas.push_back(ch.draw_felt());
+  }
+  if ((int)p.inner_layers.size() != top - 1 - ((int)p.log_last_layer + lb)) fail("inner layer count");
+  if (p.last_layer_coeffs.size() != (size_t)1 << p.log_last_layer) fail("last layer degree");
+  ch.mix_felts(p.last_layer_coeffs);
+  {
+    Channel c = ch;
+    c.mix_u64(p.proof_of_work);
+    if (c.trailing_zeros() < p.pow_bits) fail("ProofOfWork");
+  }
+  ch.mix_u64(p.proof_of_work);
+  std::vector<uint32_t> queries;
+  {
+    std::set<uint32_t> qs;
+    uint64_t cnt = 0;
+    const uint32_t mask = (1u << top) - 1u;
+    while (cnt < p.n_queries) {
+      Hash32 r = ch.draw_random_words();
+      for (int i = 0; i < 8 && cnt < p.n_queries; ++i, ++cnt) qs.insert(r.w[i] & mask);
+    }
+    queries.assign(qs.begin(), qs.end());
+  }
+  std::map<int, std::vector<uint32_t>> pos_by_log;
+  for (int ls : sizes) pos_by_log[ls] = fold_pos(queries, top - ls);
+
+  // ---- trace tree decommitments
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 4\n", 4);
+  for (int t = 0; t < 4; ++t) {
+    std::vector<int> logs;
+    std::map<int, std::vector<uint32_t>> qmap;
+    for (int l : tree_logs[t]) {
+      logs.push_back(l + lb);
+      qmap[l + lb] = pos_by_log[l + lb];
+    }
+    if (!merkle_verify(p.commitments[t], logs, qmap, p.queried_values[t], p.decommitments[t]))
+      fail("Merkle tree " + std::to_string(t));
+  }
+
+  // ---- FRI answers: quotient values at the queried positions, per LDE size
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 5\n", 5);
+  struct ColRef {
+    int tree, lde_log;
+    size_t base;   // offset of this size-group inside queried_values[tree]
+    int ncol, j;   // columns of that size in the tree, index of this column among them
+    std::vector<std::pair<int, QM31>> samples;  // (point id, value); point id indexes `all_pts`
+  };
+  std::vector<QPt> all_pts;
+  auto pt_id = [&](const QPt& q) {
+    for (size_t i = 0; i < all_pts.size(); ++i)
+      if (q_eq(all_pts[i].x, q.x) && q_eq(all_pts[i].y, q.y)) return (int)i;
+    all_pts.push_back(q);
+    return (int)all_pts.size() - 1;
+  };
+  std::vector<ColRef> cols;
+  for (int t = 0; t < 4; ++t) {
+    std::map<int, std::pair<size_t, int>, std::greater<int>> group;  // lde log -> (base, ncol)
+    for (int l : tree_logs[t]) group[l + lb].second++;
+    size_t off = 0;
+    for (auto& g : group) {
+      g.second.first = off;
+      off += (size_t)g.second.second * pos_by_log[g.first].size();
+    }
+    std::map<int, int> seen;
+    for (size_t c = 0; c < tree_logs[t].size(); ++c) {
+      int ls = tree_logs[t][c] + lb;
+      ColRef cr{t, ls, group[ls].first, group[ls].second, seen[ls]++, {}};
+      for (size_t k = 0; k < pts[t][c].size(); ++k) cr.samples.push_back({pt_id(pts[t][c][k]), p.sampled_values[t][c][k]});
+      cols.push_back(cr);
+    }
+  }
+  std::map<int, std::map<uint32_t, QM31>> quot_at;
+  for (int ls : sizes) {
+    std::vector<const ColRef*> lc;
+    for (auto& c : cols)
+      if (c.lde_log == ls) lc.push_back(&c);
+    // batches by point, first-appearance order
+    std::vector<int> bpt;
+    std::vector<std::vector<std::pair<int, QM31>>> bcols;
+    for (size_t c = 0; c < lc.size(); ++c)
+      for (auto& sm : lc[c]->samples) {
+        size_t b = 0;
+        while (b < bpt.size() && bpt[b] != sm.first) ++b;
+        if (b == bpt.size()) {
+          bpt.push_back(sm.first);
+          bcols.emplace_back();
+        }
+        bcols[b].push_back({(int)c, sm.second});
+      }
+    const auto& qp = pos_by_log[ls];
+    for (size_t qi = 0; qi < qp.size(); ++qi) {
+      Pt dp = domain_point(ls, qp[qi]);
+      QM31 acc = q_zero();
+      for (size_t b = 0; b < bpt.size(); ++b) {
+        const QPt& pt = all_pts[bpt[b]];
+        QM31 alpha = q_one(), num = q_zero();
+        for (auto& cv : bcols[b]) {
+          alpha = q_mul(alpha, quot_alpha);
+          const ColRef* cr = lc[cv.first];
+          size_t idx = cr->base + qi * (size_t)cr->ncol + (size_t)cr->j;
+          if (idx >= p.queried_values[cr->tree].size()) fail("queried values shape");
+          uint32_t f = p.queried_values[cr->tree][idx];
+          QM31 val = cv.second;
+          QM31 la = q_sub(q_conj(val), val);
+          QM31 lc2 = q_sub(q_conj(pt.y), pt.y);
+          QM31 lbb = q_sub(q_mul(val, lc2), q_mul(la, pt.y));
+          num = q_add(num, q_mul(alpha, q_sub(q_mul_m(lc2, f), q_add(q_mul_m(la, dp.y), lbb))));
+        }
+        CM31 prx{pt.x.a, pt.x.b}, pix{pt.x.c, pt.x.d}, pry{pt.y.a, pt.y.b}, piy{pt.y.c, pt.y.d};
+        CM31 dx{m_sub(prx.a, dp.x), prx.b}, dy{m_sub(pry.a, dp.y), pry.b};
+        CM31 den = c_sub(c_mul(dx, piy), c_mul(dy, pix));
+        if (c_norm(den) == 0) fail("degenerate quotient denominator");
+        acc = q_add(q_mul(acc, q_pow(quot_alpha, bcols[b].size())), q_mul_c(num, c_inv(den)));
+      }
+      quot_at[ls][qp[qi]] = acc;
+    }
+  }
+
+  // ---- FRI first layer: rebuild sibling pairs, Merkle-check, fold circle -> line
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 6\n", 6);
+  std::map<int, std::map<uint32_t, QM31>> first_vals;
+  std::map<int, std::vector<uint32_t>> dec_by_log;
+  {
+    size_t wi = 0;
+    for (int ls : sizes)
+      if (!rebuild_pairs(pos_by_log[ls], quot_at[ls], p.first_layer.fri_witness, wi, dec_by_log[ls], first_vals[ls]))
+        fail("first layer witness");
+    if (wi != p.first_layer.fri_witness.size()) fail("first layer witness too long");
+    std::vector<int> logs;
+    std::vector<uint32_t> qv;
+    for (int ls : sizes) {
+      for (int k = 0; k < 4; ++k) logs.push_back(ls);
+      for (uint32_t pos : dec_by_log[ls]) {
+        QM31 v = first_vals[ls][pos];
+        qv.insert(qv.end(), {v.a, v.b, v.c, v.d});
+      }
+    }
+    if (!merkle_verify(p.first_layer.commitment, logs, dec_by_log, qv, p.first_layer.decommitment))
+      fail("FRI first layer Merkle");
+  }
+  auto fold_circle = [&](const std::map<uint32_t, QM31>& vals, int ls, QM31 alpha) {
+    std::map<uint32_t, QM31> out;
+    for (auto& kv : vals) {
+      if (kv.first & 1u) continue;
+      QM31 a = kv.second, b = vals.at(kv.first + 1);
+      uint32_t y = domain_point(ls, kv.first).y;
+      out[kv.first >> 1] = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), m_inv(y))));
+    }
+    return out;
+  };
+  int layer_log = top - 1;
+  std::map<uint32_t, QM31> cur = fold_circle(first_vals[top], top, alphas[0]);
+  std::vector<int> left(sizes.begin() + 1, sizes.end());
+  std::vector<uint32_t> lq = fold_pos(queries, 1);
+  for (size_t li = 0; li < p.inner_layers.size(); ++li) {
+    const FriLayerProof& l = p.inner_layers[li];
+    std::vector<uint32_t> dpos;
+    std::map<uint32_t, QM31> vals;
+    size_t wi = 0;
+    if (!rebuild_pairs(lq, cur, l.fri_witness, wi, dpos, vals) || wi != l.fri_witness.size())
+      fail("inner layer witness");
+    std::vector<uint32_t> qv;
+    for (uint32_t pos : dpos) {
+      QM31 v = vals[pos];
+      qv.insert(qv.end(), {v.a, v.b, v.c, v.d});
+    }
+    std::map<int, std::vector<uint32_t>> dq;
+    dq[layer_log] = dpos;
+    if (!merkle_verify(l.commitment, {layer_log, layer_log, layer_log, layer_log}, dq, qv, l.decommitment))
+      fail("FRI inner layer " + std::to_string(li) + " Merkle");
+    QM31 alpha = alphas[li + 1];
+    std::map<uint32_t, QM31> nxt;
+    for (uint32_t pos : dpos) {
+      if (pos & 1u) continue;
+      QM31 a = vals[pos], b = vals[pos + 1];
+      uint32_t x = line_domain_x(layer_log, pos);
+      nxt[pos >> 1] = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), m_inv(x))));
+    }
+    layer_log -= 1;
+    lq = fold_pos(lq, 1);
+    for (auto it = left.begin(); it != left.end();) {
+      if (*it - 1 == layer_log) {
+        auto fc = fold_circle(first_vals[*it], *it, alpha);
+        for (auto& kv : nxt) {
+          auto f = fc.find(kv.first);
+          if (f == fc.end()) fail("FRI column positions");
+          kv.second = q_add(q_mul(kv.second, q_mul(alpha, alpha)), f->second);
+        }
+        it = left.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    cur.swap(nxt);
+  }
+  if (!left.empty()) fail("unconsumed FRI columns");
+  // ---- last layer: the polynomial must reproduce the folded values
+  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 7\n", 7);
+  for (auto& kv : cur) {
+    uint32_t x = line_domain_x(layer_log, kv.first);
+    QM31 val = q_zero();
+    for (size_t j = 0; j < p.last_layer_coeffs.size(); ++j) {
+      QM31 term = p.last_layer_coeffs[j];
+      uint32_t xx = x;
+      for (size_t jj = j; jj; jj >>= 1) {
+        if (jj & 1) term = q_mul_m(term, xx);
+        xx = m_sub(m_dbl(m_sqr(xx)), 1u);
+      }
+      val = q_add(val, term);
+    }
+    if (!q_eq(val, kv.second)) fail("FRI last layer");
+  }
+}
+
+}  // namespace lmn

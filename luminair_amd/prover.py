@@ -17,6 +17,8 @@ _ERR_VARIANT = {
     backend.ERR_OUT_OF_MEMORY: "OutOfMemory",
     backend.ERR_NO_DEVICE: "NoDevice",
     backend.ERR_INTERNAL: "Internal",
+    backend.ERR_VERIFICATION: "StwoVerifierError",
+    backend.ERR_INVALID_LOGUP: "InvalidLogUp",
 }
 
 
@@ -57,3 +59,16 @@ def prove(pie: LuminairPie, settings: Optional[CircuitSettings] = None) -> Lumin
     if _default is None:
         _default = Prover(0)
     return _default.prove(pie, settings)
+
+
+def verify(proof: LuminairProof, settings: Optional[CircuitSettings] = None,
+           protocol_variant: int = backend.VARIANT_KAT, library=None) -> None:
+    """Drop-in for the reference's `verify(proof, settings)` (crates/verifiers/rust/src/verifier.rs:21-143):
+    host-side check of a proof's bincode bytes; raises LuminairError(StwoVerifierError | InvalidLogUp | ...)."""
+    if settings is not None and settings.lookups:
+        raise LuminairError("InvalidArgument", "lookup settings are outside the hot-path scope")
+    lib = library or backend.default_library()
+    try:
+        lib.verify(proof.to_bincode() if isinstance(proof, LuminairProof) else bytes(proof), protocol_variant)
+    except backend.LuminairBackendError as e:
+        raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e

@@ -101,6 +101,10 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
         raise VerificationError("empty claim")
     if len(s.commitments) != 4:
         raise VerificationError("expected 4 commitments")
+    if not (0 < s.n_queries <= 1024) or s.log_last_layer > 10 or s.log_blowup != 1:
+        raise VerificationError("bad PCS config")
+    if any(ls is not None and not (4 <= ls <= 26) for ls in proof.claim):
+        raise VerificationError("bad log_size")
     channel.mix_root(s.commitments[0])
     for ls in proof.claim:
         if ls is not None:

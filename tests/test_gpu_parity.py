@@ -231,3 +231,18 @@ def test_gpu_less_than_2_18_rows_equals_c_oracle_bytes(gpu_prover_pinned, c_orac
     tabs = syn.less_than_graph(1 << 18, 9)
     want = to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=c_oracle))
     assert _gpu_bytes(gpu_prover_pinned, tabs) == want
+
+
+def test_gpu_proofs_pass_the_product_verifier(gpu_prover, gpu_prover_pinned, kat_bytes):
+    """prove -> verify round trip through the C ABI only (the reference's own test strategy,
+    crates/graph/src/tests/mod.rs:26-44), plus rejection of a tampered proof."""
+    luminair_amd.verify(luminair_amd.LuminairProof(kat_bytes))
+    proof = gpu_prover.prove(luminair_amd.LuminairPie.from_tables(syn.linear_layer(64, 100, 13)))
+    luminair_amd.verify(proof)
+    from luminair_amd import backend
+    p2 = gpu_prover_pinned.prove(luminair_amd.LuminairPie.from_tables(syn.less_than_graph(1000, 6)))
+    luminair_amd.verify(p2, protocol_variant=backend.VARIANT_PINNED)
+    bad = bytearray(proof.to_bincode())
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.verify(luminair_amd.LuminairProof(bytes(bad)))
