@@ -214,7 +214,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   if (variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
   const int n_slots = variant == LMN_VARIANT_KAT ? 8 : 17;
   Proof p = parse_proof(data, len, n_slots);
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 0\n", 0);
   const int lb = (int)p.log_blowup;
   if (lb != 1) fail("unsupported blow-up");
   if (p.commitments.size() != 4 || p.sampled_values.size() != 4 || p.decommitments.size() != 4 ||
@@ -258,7 +257,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   for (int k = 0; k < 4; ++k) tree_logs[3].push_back(max_log + 1);
 
   // ---- transcript replay (verifier.rs:61-106)
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 1\n", 1);
   Channel ch(variant);
   ch.mix_root(p.commitments[0]);
   for (int kind = 0; kind < n_slots; ++kind)
@@ -284,7 +282,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   QPt oods{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
 
   // ---- sample points per column
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 2\n", 2);
   std::vector<std::vector<std::vector<QPt>>> pts(4);
   for (size_t c = 0; c < tree_logs[0].size(); ++c) pts[0].push_back({oods});
   for (size_t c = 0; c < tree_logs[1].size(); ++c) pts[1].push_back({oods});
@@ -322,7 +319,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   const QM31 quot_alpha = ch.draw_felt();
 
   // ---- FRI commit phase replay
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 3\n", 3);
   std::set<int, std::greater<int>> size_set;
   for (auto& t : tree_logs)
     for (int l : t) size_set.insert(l + lb);
@@ -358,7 +354,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   for (int ls : sizes) pos_by_log[ls] = fold_pos(queries, top - ls);
 
   // ---- trace tree decommitments
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 4\n", 4);
   for (int t = 0; t < 4; ++t) {
     std::vector<int> logs;
     std::map<int, std::vector<uint32_t>> qmap;
@@ -371,7 +366,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   }
 
   // ---- FRI answers: quotient values at the queried positions, per LDE size
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 5\n", 5);
   struct ColRef {
     int tree, lde_log;
     size_t base;   // offset of this size-group inside queried_values[tree]
@@ -450,7 +444,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   }
 
   // ---- FRI first layer: rebuild sibling pairs, Merkle-check, fold circle -> line
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 6\n", 6);
   std::map<int, std::map<uint32_t, QM31>> first_vals;
   std::map<int, std::vector<uint32_t>> dec_by_log;
   {
@@ -528,7 +521,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   }
   if (!left.empty()) fail("unconsumed FRI columns");
   // ---- last layer: the polynomial must reproduce the folded values
-  if (getenv("LMN_VERIFY_TRACE")) fprintf(stderr, "[verify] step 7\n", 7);
   for (auto& kv : cur) {
     uint32_t x = line_domain_x(layer_log, kv.first);
     QM31 val = q_zero();
