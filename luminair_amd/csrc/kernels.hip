@@ -1043,13 +1043,17 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
     const bool rc[3] = {false, false, false};
     logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
-  } else if (KIND == 2) {
+  } else if (KIND == 2 || KIND == 7) {
+    // Recip / Sqrt (13 cols; the eval_fixed_* forms are unpinned natural identities)
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
     const uint32_t n_node = LMN_COL(4), n_in = LMN_COL(5), n_idx = LMN_COL(6);
     const uint32_t inp = LMN_COL(7), out = LMN_COL(8), rem = LMN_COL(9), scale = LMN_COL(10);
     const uint32_t m0 = LMN_COL(11), m1 = LMN_COL(12);
     ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
-    ca.add_m(m_sub(m_sqr(scale), m_add(m_mul(inp, out), rem)));
+    if (KIND == 2)
+      ca.add_m(m_sub(m_sqr(scale), m_add(m_mul(inp, out), rem)));
+    else
+      ca.add_m(m_sub(m_mul(inp, scale), m_add(m_sqr(out), rem)));
     const uint32_t not_last = m_sub(1u, is_last);
     ca.add_m(m_mul(not_last, m_sub(n_node, node)));
     ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
@@ -1057,6 +1061,22 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     const bool rc[2] = {false, false};
     logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
+  } else if (KIND == 8) {
+    // Rem (16 cols): lhs = rhs*quotient + rem (unpinned form); the out relation carries `rem`
+    const uint32_t node = LMN_COL(0), lhs_id = LMN_COL(1), rhs_id = LMN_COL(2), idx = LMN_COL(3), is_last = LMN_COL(4);
+    const uint32_t n_node = LMN_COL(5), n_lhs = LMN_COL(6), n_rhs = LMN_COL(7), n_idx = LMN_COL(8);
+    const uint32_t lhs = LMN_COL(9), rhs = LMN_COL(10), rem = LMN_COL(11), quo = LMN_COL(12);
+    const uint32_t m0 = LMN_COL(13), m1 = LMN_COL(14), m2 = LMN_COL(15);
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    ca.add_m(m_sub(lhs, m_add(m_mul(rhs, quo), rem)));
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_lhs, lhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, rem}, ri[3] = {lhs_id, rhs_id, node};
+    const bool rc[3] = {false, false, false};
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 13) {
     // LessThan (22 cols; less_than/component.rs:48-185): 9 local constraints, 3 node relations +
     // 4 range-check relations on the 8-bit limbs of diff
@@ -1147,6 +1167,8 @@ void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
     case 2: LMN_LAUNCH(k_composition<2>, g, b, 0, s, a); break;
     case 5: LMN_LAUNCH(k_composition<5>, g, b, 0, s, a); break;
     case 6: LMN_LAUNCH(k_composition<6>, g, b, 0, s, a); break;
+    case 7: LMN_LAUNCH(k_composition<7>, g, b, 0, s, a); break;
+    case 8: LMN_LAUNCH(k_composition<8>, g, b, 0, s, a); break;
     case 13: LMN_LAUNCH(k_composition<13>, g, b, 0, s, a); break;
     case 14: LMN_LAUNCH(k_composition<14>, g, b, 0, s, a); break;
     case 15: LMN_LAUNCH(k_composition<15>, g, b, 0, s, a); break;

@@ -24,6 +24,9 @@ static const ComponentSpec kSpecs[] = {
     {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13}, {7, 8}, {1, 0}, 7, {0}, {0}, {0}, 0, 0, {0}, {0}},   // sum_reduce/component.rs:36-110
     {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14}, {7, 8}, {1, 0}, 9, {0}, {0}, {0}, 0, 0, {0}, {0}},   // max_reduce/component.rs
     {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10}, {7, 8}, {1, 0}, 4, {0}, {0}, {0}, 0, 0, {0}, {0}},    // contiguous/component.rs
+    // numerair's eval_fixed_sqrt / eval_fixed_rem are un-vendored: natural fixed-point identities (unpinned)
+    {LMN_KIND_SQRT, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    {LMN_KIND_REM, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, 0, {0}, {0}},
     // less_than/component.rs:48-185; padding row less_than/table.rs:47-72 (rhs=1, out=4096, diff=1, limb0=1)
     {LMN_KIND_LESS_THAN, 22, 4, 7, {18, 19, 20, 21, 21, 21, 21}, {9, 10, 11, 14, 15, 16, 17}, {1, 2, 0, -1, -1, -1, -1}, 9,
      {0, 0, 0, 1, 1, 1, 1}, {0}, {0}, 0, 4, {10, 11, 12, 14}, {1u, 4096u, 1u, 1u}},
@@ -421,6 +424,21 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
     out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
     out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
+  } else if (kind == LMN_KIND_SQRT) {
+    QM31 is_last = c[3], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    out.push_back(q_sub(q_mul(c[7], c[10]), q_add(q_sqr(c[8]), c[9])));
+    out.push_back(q_mul(not_last, q_sub(c[4], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[5], c[1])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[6], c[2]))));
+  } else if (kind == LMN_KIND_REM) {
+    QM31 is_last = c[4], not_last = one_minus(is_last);
+    out.push_back(q_mul(is_last, qsub1(is_last)));
+    out.push_back(q_sub(c[9], q_add(q_mul(c[10], c[12]), c[11])));
+    out.push_back(q_mul(not_last, q_sub(c[5], c[0])));
+    out.push_back(q_mul(not_last, q_sub(c[6], c[1])));
+    out.push_back(q_mul(not_last, q_sub(c[7], c[2])));
+    out.push_back(q_mul(not_last, qsub1(q_sub(c[8], c[3]))));
   } else if (kind == LMN_KIND_RANGE_CHECK_LOOKUP) {
     // no local constraints
   } else if (kind == LMN_KIND_LESS_THAN) {

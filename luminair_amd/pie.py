@@ -33,7 +33,8 @@ class TraceTableKind(IntEnum):
 # column counts of the components on the hot path (N_TRACE_COLUMNS in each witness.rs)
 N_COLUMNS = {TraceTableKind.Add: 15, TraceTableKind.Mul: 16, TraceTableKind.Recip: 13, TraceTableKind.Inputs: 7,
              TraceTableKind.SumReduce: 14, TraceTableKind.MaxReduce: 15, TraceTableKind.Contiguous: 11,
-             TraceTableKind.LessThan: 22, TraceTableKind.RangeCheckLookup: 1}
+             TraceTableKind.LessThan: 22, TraceTableKind.RangeCheckLookup: 1, TraceTableKind.Sqrt: 13,
+             TraceTableKind.Rem: 16}
 
 
 class LuminairError(Exception):

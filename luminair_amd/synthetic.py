@@ -17,6 +17,7 @@ SCALE = 1 << 12
 KIND_ADD, KIND_MUL, KIND_RECIP, KIND_INPUTS = 0, 1, 2, 15
 KIND_SUM_REDUCE, KIND_MAX_REDUCE, KIND_CONTIGUOUS = 5, 6, 16
 KIND_LESS_THAN, KIND_RANGE_CHECK_LOOKUP = 13, 14
+KIND_SQRT, KIND_REM = 7, 8
 
 
 def to_m31(v: np.ndarray) -> np.ndarray:
@@ -123,6 +124,43 @@ def contiguous_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndar
     cols = [np.full(n, node), np.full(n, input_id), idx, (idx == n - 1).astype(np.int64), np.full(n, node),
             np.full(n, input_id), idx + 1, to_m31(x), to_m31(x), np.full(n, input_mult % P), np.full(n, out_mult % P)]
     return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def sqrt_rows(inp, node=2, input_id=0, mults=(0, 0)) -> np.ndarray:
+    """Fixed-point sqrt rows (`crates/graph/src/op/prim.rs:573-660`): out = floor(sqrt(input*scale)),
+    rem = input*scale - out^2 (the natural identity; numerair's exact form is unpinned)."""
+    inp = np.asarray(inp, np.int64)
+    n = len(inp)
+    out = np.floor(np.sqrt((inp * SCALE).astype(np.float64))).astype(np.int64)
+    out = np.where(out * out > inp * SCALE, out - 1, out)
+    out = np.where((out + 1) * (out + 1) <= inp * SCALE, out + 1, out)
+    rem = inp * SCALE - out * out
+    cols = _ids(n, node, input_id) + [to_m31(inp), to_m31(out), to_m31(rem), np.full(n, SCALE)]
+    cols += [np.full(n, m % P) for m in mults]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def rem_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(0, 0, 0)) -> np.ndarray:
+    """Remainder rows (`crates/graph/src/op/prim.rs:1323-1421`): lhs = rhs*quotient + rem, operands > 0;
+    the out relation carries `rem`."""
+    lhs, rhs = np.asarray(lhs, np.int64), np.asarray(rhs, np.int64)
+    n = len(lhs)
+    quo, rem = lhs // rhs, lhs % rhs
+    cols = _ids(n, node, lhs_id, rhs_id) + [to_m31(lhs), to_m31(rhs), to_m31(rem), to_m31(quo)]
+    cols += [np.full(n, m % P) for m in mults]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
+def sqrt_rem_graph(n: int, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
+    """s = sqrt(a); r = s % m with fresh inputs a, m (PINNED variant: Sqrt, Rem, Inputs tables)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(1, 1 << 20, size=n)
+    m = rng.integers(1, 4096, size=n)
+    sq = sqrt_rows(a, node=2, input_id=0, mults=(-1, 1))
+    s_out = sq[:, 8].astype(np.int64)
+    rm = rem_rows(s_out, m, node=3, lhs_id=2, rhs_id=1, mults=(-1, -1, 0))
+    inp = np.concatenate([inputs_rows(a, 0, 1), inputs_rows(m, 1, 1)])
+    return [(KIND_SQRT, sq), (KIND_REM, rm), (KIND_INPUTS, inp)]
 
 
 def less_than_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(-1, -1, 0)):

@@ -168,6 +168,26 @@ def _contiguous_local(c):
     return [is_last * (is_last - 1)] + _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
 
 
+def _sqrt_local(c):
+    """eval_fixed_sqrt(input, out, rem, scale) is in numerair (un-vendored): **unpinned**; restated as
+    the natural fixed-point identity input*scale = out^2 + rem."""
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, inp, out, rem, scale, _im, _om) = c
+    cons = [is_last * (is_last - 1), inp * scale - (out * out + rem)]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+    return cons
+
+
+def _rem_local(c):
+    """eval_fixed_rem(lhs, rhs, quotient, rem) is in numerair (un-vendored): **unpinned**; restated as
+    lhs = rhs*quotient + rem."""
+    (node, lhs_id, rhs_id, idx, is_last, n_node, n_lhs, n_rhs, n_idx, lhs, rhs, rem, quo, _lm, _rm, _om) = c
+    cons = [is_last * (is_last - 1), lhs - (rhs * quo + rem)]
+    not_last = 1 - is_last
+    cons += _transition(not_last, [(n_node, node), (n_lhs, lhs_id), (n_rhs, rhs_id)], n_idx, idx)
+    return cons
+
+
 def _pad(n, is_last_col):
     p = [0] * n
     p[is_last_col] = 1
@@ -221,8 +241,12 @@ RANGE_CHECK_LOOKUP = Component("range_check_lookup", KIND_RANGE_CHECK_LOOKUP, 1,
                                (Rel(0, 0, None, ELEMS_RANGE_CHECK, neg=True, pre=True),),
                                pre_cols=((RANGE_CHECK_COL_ID, RANGE_CHECK_LOG),))
 
+# sqrt/{table.rs:178-190,component.rs}, rem/{table.rs:203-218,component.rs:60-110}: the out relation of Rem carries `rem`
+SQRT = Component("sqrt", KIND_SQRT, 13, _pad(13, 3), _sqrt_local, ((11, (7, 1)), (12, (8, 0))))
+REM = Component("rem", KIND_REM, 16, _pad(16, 4), _rem_local, ((13, (9, 1)), (14, (10, 2)), (15, (11, 0))))
+
 COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS, SUM_REDUCE, MAX_REDUCE, CONTIGUOUS, LESS_THAN,
-                                  RANGE_CHECK_LOOKUP)}
+                                  RANGE_CHECK_LOOKUP, SQRT, REM)}
 
 
 def preprocessed_column(col_id: str, log_size: int) -> np.ndarray:

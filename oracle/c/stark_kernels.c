@@ -251,6 +251,21 @@ static int local_constraints(int kind, const u32* c, u32* out) {
     out[k++] = mmul(is_last, msub(is_last, 1));
     out[k++] = mmul(nl, msub(c[3], c[0]));
     out[k++] = mmul(nl, msub(msub(c[4], c[1]), 1));
+  } else if (kind == 7) { /* Sqrt: eval_fixed_sqrt unpinned, input*scale = out^2 + rem */
+    u32 is_last = c[3], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    out[k++] = msub(mmul(c[7], c[10]), madd(mmul(c[8], c[8]), c[9]));
+    out[k++] = mmul(nl, msub(c[4], c[0]));
+    out[k++] = mmul(nl, msub(c[5], c[1]));
+    out[k++] = mmul(nl, msub(msub(c[6], c[2]), 1));
+  } else if (kind == 8) { /* Rem: eval_fixed_rem unpinned, lhs = rhs*quotient + rem */
+    u32 is_last = c[4], nl = msub(1, is_last);
+    out[k++] = mmul(is_last, msub(is_last, 1));
+    out[k++] = msub(c[9], madd(mmul(c[10], c[12]), c[11]));
+    out[k++] = mmul(nl, msub(c[5], c[0]));
+    out[k++] = mmul(nl, msub(c[6], c[1]));
+    out[k++] = mmul(nl, msub(c[7], c[2]));
+    out[k++] = mmul(nl, msub(msub(c[8], c[3]), 1));
   } else if (kind == 14) {
     /* RangeCheckLookup: no local constraints */
   } else if (kind == 13) { /* LessThan, less_than/component.rs:48-185 */

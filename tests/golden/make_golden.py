@@ -25,6 +25,7 @@ CASES = {
     "linear_layer_20x7_max_seed2/kat": (lambda: syn.linear_layer(20, 7, 2, True), "KAT"),
     "graph_faithful_100_seed3/pinned": (lambda: syn.config2_graph_faithful(100, 3), "PINNED"),
     "less_than_100_seed3/pinned": (lambda: syn.less_than_graph(100, 3), "PINNED"),
+    "sqrt_rem_50_seed4/pinned": (lambda: syn.sqrt_rem_graph(50, 4), "PINNED"),
 }
 
 

@@ -100,6 +100,10 @@ def test_emu_pinned_variant_with_inputs_component(root):
     got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs2])
     want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs2], variant=ProtocolVariant.PINNED))
     assert got == want
+    tabs3 = syn.sqrt_rem_graph(30, 6)     # Sqrt + Rem (numerair forms unpinned, self-consistent)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs3])
+    assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs3], variant=ProtocolVariant.PINNED))
+    lib.verify(got, backend.VARIANT_PINNED)
     # the KAT-variant context has no claim slot for kind 15
     kat_ctx = backend.Context(0, None, lib)
     with pytest.raises(backend.LuminairBackendError) as e:

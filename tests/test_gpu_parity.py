@@ -207,6 +207,7 @@ def _oracle_bytes_pinned(tabs):
     ("2b-2^12", syn.config2_graph_faithful(1 << 12, 4)),
     ("add-only-pinned", syn.config2_add_only(300, 5)),
     ("less-than+range-check-lut", syn.less_than_graph(1000, 6)),
+    ("sqrt+rem", syn.sqrt_rem_graph(3000, 7)),
 ])
 def test_gpu_pinned_variant_equals_oracle(gpu_prover_pinned, name, tabs):
     got = _gpu_bytes(gpu_prover_pinned, tabs)

@@ -27,6 +27,7 @@ def test_c_oracle_reproduces_kat(ck, kat_bytes):
     ("linear-layer", syn.linear_layer(8, 16, 1), ProtocolVariant.KAT),
     ("linear-layer+max", syn.linear_layer(20, 7, 2, True), ProtocolVariant.KAT),
     ("less-than+range-check-lut", syn.less_than_graph(100, 3), ProtocolVariant.PINNED),
+    ("sqrt+rem", syn.sqrt_rem_graph(50, 4), ProtocolVariant.PINNED),
 ])
 def test_c_oracle_equals_numpy_oracle(ck, name, tabs, variant):
     a = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=variant))
