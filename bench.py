@@ -163,9 +163,16 @@ def main(argv=None):
     elapsed = timed_region(step, args.steps, args.warmup, barrier, device_sync)
     agg = aggregate(elapsed, world, args.steps, reduce_max)
     # single-proof latency (one proof alone on the GPU) and the per-kernel timings behind `roofline`
-    t0 = time.perf_counter()
+    lat = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one(0)
+        lat.append(1e3 * (time.perf_counter() - t0))
+    latency_ms = sorted(lat)[1]
+    # one more solo proof with HIP-event profiling switched on: the source of `roofline` and `stage_ms`
+    prover.ctx.set_profiling(True)
     one(0)
-    latency_ms = 1e3 * (time.perf_counter() - t0)
+    prover.ctx.set_profiling(False)
 
     # roofline per kernel family, from HIP events recorded by the library on the prover's own stream
     # around every transform / tree of the solo proof above (lmn_timings).  `traffic` comes from the

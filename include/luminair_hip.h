@@ -121,6 +121,9 @@ void lmn_ctx_destroy(lmn_ctx* ctx);
 int lmn_prove(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_settings* settings,
               uint8_t** proof_bincode, size_t* proof_len);
 void lmn_free(void* p);
+/* Per-stage / per-kernel HIP-event timing is off by default (every event record costs a few
+ * microseconds between dependent kernels); enable it for the proofs whose lmn_timings you want. */
+int lmn_set_profiling(lmn_ctx* ctx, int enabled);
 int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out);
 
 /* Replaces `verify(proof, settings)` (/root/reference/crates/verifiers/rust/src/verifier.rs:21-143).

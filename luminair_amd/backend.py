@@ -51,7 +51,7 @@ class LmnTimings(C.Structure):
 
 
 EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
-           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_upload", "lmn_device_free", "lmn_verify",
+           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest"]
 
@@ -84,6 +84,7 @@ class Library:
                                   C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         lib.lmn_free.argtypes = [C.c_void_p]
         lib.lmn_get_timings.argtypes = [C.c_void_p, C.POINTER(LmnTimings)]
+        lib.lmn_set_profiling.argtypes = [C.c_void_p, C.c_int]
         lib.lmn_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_device_free.argtypes = [C.c_void_p, C.c_void_p]
         lib.lmn_verify.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.c_uint32]
@@ -188,6 +189,9 @@ class Context:
         data = C.string_at(out, out_len.value)
         self.lib.lib.lmn_free(out)
         return data
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.lib.lib.lmn_set_profiling(self.handle, 1 if enabled else 0))
 
     def timings(self) -> dict:
         t = LmnTimings()

@@ -109,6 +109,12 @@ int lmn_prove(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_
 
 void lmn_free(void* p) { free(p); }
 
+int lmn_set_profiling(lmn_ctx* ctx, int enabled) {
+  if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  ctx->impl->profiling = enabled != 0;
+  return LMN_OK;
+}
+
 int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out) {
   if (!ctx || !out) return LMN_ERR_INVALID_ARGUMENT;
   *out = ctx->impl->timings;

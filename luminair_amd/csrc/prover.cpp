@@ -96,12 +96,17 @@ struct StageTimer {
   EventLog* log;
   lmn_stream_t s;
   int cat;
-  lmn_event_t a;
-  StageTimer(Context* c, EventLog* l, lmn_stream_t st, int cat_) : ctx(c), log(l), s(st), cat(cat_) {
+  lmn_event_t a{};
+  bool on;
+  // Event records are not free (each costs a few microseconds between dependent kernels), so they are
+  // only taken when profiling was requested for this context (lmn_set_profiling).
+  StageTimer(Context* c, EventLog* l, lmn_stream_t st, int cat_) : ctx(c), log(l), s(st), cat(cat_), on(c->profiling) {
+    if (!on) return;
     a = log->get();
     lmn_event_record(a, s);
   }
   ~StageTimer() {
+    if (!on) return;
     lmn_event_t b = log->get();
     lmn_event_record(b, s);
     log->spans.push_back({a, b, cat});

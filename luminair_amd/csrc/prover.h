@@ -105,6 +105,7 @@ class Context {
 
   lmn_config cfg;
   lmn_timings timings{};
+  bool profiling = false;  // record HIP events around stages/kernels (lmn_set_profiling)
   std::string last_error;
 
  private:
