@@ -3,7 +3,10 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'transpose' in r['Kernel_Name']][-1]
+starts = [i for i, r in enumerate(rows) if 'transpose' in r['Kernel_Name']]
+# third-from-last proof: the last one in a bench.py run is the solo proof with HIP-event profiling on
+idx, end = (starts[-3], starts[-2]) if len(starts) >= 3 else (starts[-1], len(rows))
+rows = rows[:end]
 t0 = int(rows[idx]['Start_Timestamp'])
 prev_end = t0
 tot = {}
