@@ -113,17 +113,8 @@ struct StageTimer {
   }
 };
 
-// one EventLog per context, stored out-of-line to keep prover.h free of event types
-static std::map<Context*, EventLog*>& logs() {
-  static std::map<Context*, EventLog*> m;
-  return m;
-}
-static EventLog* g_log(Context* c) {
-  auto& m = logs();
-  auto it = m.find(c);
-  if (it == m.end()) it = m.emplace(c, new EventLog()).first;
-  return it->second;
-}
+// one EventLog per context (owned through an opaque pointer to keep prover.h free of event types)
+static EventLog* g_log(Context* c) { return static_cast<EventLog*>(c->event_log); }
 
 // ------------------------------------------------------------------------------------ context
 Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
@@ -138,6 +129,7 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
 #else
   stream_ = 0;
 #endif
+  event_log = new EventLog();
   pin_cap_ = 32u << 20;
   pin_base_ = (char*)lmn_host_alloc_pinned(pin_cap_);
   if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
@@ -153,12 +145,8 @@ Context::~Context() {
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(stream_);
 #endif
-  auto& m = logs();
-  auto it = m.find(this);
-  if (it != m.end()) {
-    delete it->second;
-    m.erase(it);
-  }
+  delete static_cast<EventLog*>(event_log);
+  event_log = nullptr;
   for (void* p : tw_allocs_) lmn_dev_free(p);
   if (pin_base_) lmn_host_free_pinned(pin_base_);
 #ifndef LMN_EMU

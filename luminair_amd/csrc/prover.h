@@ -106,6 +106,7 @@ class Context {
   lmn_config cfg;
   lmn_timings timings{};
   bool profiling = false;  // record HIP events around stages/kernels (lmn_set_profiling)
+  void* event_log = nullptr;  // EventLog (prover.cpp)
   std::string last_error;
 
  private:
