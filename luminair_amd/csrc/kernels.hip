@@ -527,7 +527,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   // older batch, odd lanes for the newer one); after every fourth batch the same with lane^2, etc.
   // Each lane keeps its pending hash per level in private LDS slots (word 8 = node index).
   LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 9 * TPB];  // [level][word][thread]
-  LMN_SHARED uint32_t sh[TPB * 8];
+  uint32_t* sh = stack;  // the climb buffer reuses the stack storage once the batch loop is over
   const uint32_t per = 1u << sub;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
@@ -565,6 +565,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
       stack[(lvl * 9 + 8) * TPB + threadIdx.x] = cur_idx;
     }
   }
+  __syncthreads();  // every lane is done with its stack slots before they are overwritten
   {
     const uint32_t local = cur_idx - blockIdx.x * TPB;  // this block owns level-`sub` nodes [b*TPB, (b+1)*TPB)
 #pragma unroll
