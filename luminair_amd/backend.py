@@ -33,8 +33,15 @@ class LmnTable(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("n_rows", C.c_uint64), ("rows", C.c_void_p)]
 
 
+class LmnLut(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("log_size", C.c_uint32), ("col0", C.c_void_p), ("col1", C.c_void_p)]
+
+
 class LmnSettings(C.Structure):
-    _fields_ = [("has_lookups", C.c_uint32)]
+    _fields_ = [("has_lookups", C.c_uint32), ("n_luts", C.c_uint32), ("luts", C.POINTER(LmnLut))]
+
+
+LUT_KINDS = {"sin": 0, "exp2": 1, "log2": 2}   # LMN_LUT_*
 
 
 class LmnTimings(C.Structure):
@@ -166,8 +173,9 @@ class Context:
         self._check(self.lib.lib.lmn_upload(self.handle, arr.ctypes.data, arr.nbytes, C.byref(out)))
         return DeviceBuffer(self, out.value, arr.nbytes)
 
-    def prove_tables(self, tables: Sequence[Tuple[int, object, int]]) -> bytes:
-        """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer."""
+    def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:
+        """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer;
+        luts: {"sin" | "exp2" | "log2": (col0, col1)} preprocessed LUT columns (uint32, 2^k words each)."""
         n = len(tables)
         arr = (LmnTable * max(n, 1))()
         keep = []
@@ -182,7 +190,16 @@ class Context:
                 keep.append(a)
                 arr[i].flags = 0
                 arr[i].rows = a.ctypes.data
-        settings = LmnSettings(0)
+        luts = luts or {}
+        lut_arr = (LmnLut * max(len(luts), 1))()
+        for i, (name, (c0, c1)) in enumerate(luts.items()):
+            c0 = np.ascontiguousarray(c0, dtype=np.uint32)
+            c1 = np.ascontiguousarray(c1, dtype=np.uint32)
+            if len(c0) != len(c1) or len(c0) & (len(c0) - 1) or len(c0) == 0:
+                raise LuminairBackendError(-2, "LUT columns must have equal power-of-two lengths")
+            keep += [c0, c1]
+            lut_arr[i] = LmnLut(LUT_KINDS[name], len(c0).bit_length() - 1, c0.ctypes.data, c1.ctypes.data)
+        settings = LmnSettings(0, len(luts), lut_arr)
         out = C.POINTER(C.c_uint8)()
         out_len = C.c_size_t()
         self._check(self.lib.lib.lmn_prove(self.handle, arr, n, C.byref(settings), C.byref(out), C.byref(out_len)))

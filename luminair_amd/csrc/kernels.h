@@ -113,7 +113,7 @@ int logup_scan_num_blocks(int log_size);
 
 // ---- a7: constraint quotients on the eval domain (log_size + 1)
 struct CompositionArgs {
-  int kind;                    // TraceTable kind (0 add, 1 mul, 2 recip, 5 sum_reduce, 6 max_reduce, 15 inputs, 16 contiguous)
+  int kind;                    // TraceTable kind (LMN_KIND_*)
   int log_size;                // trace log size
   int eval_log;                // eval domain log size
   const uint32_t* main;        // main columns on the eval domain, stride 2^eval_log
@@ -122,8 +122,9 @@ struct CompositionArgs {
   int accumulate;              // out += instead of out =
   int zero_slot;               // 1: Mul's second eval_fixed_mul slot contributes zero (KAT form)
   QM31 z, alpha;               // NodeElements
-  QM31 z2, alpha2;             // RangeCheckLookupElements (LessThan, RangeCheckLookup)
-  const uint32_t* pre;         // preprocessed column on the eval domain (RangeCheckLookup)
+  QM31 z2, alpha2;             // the component's LUT element set (range check / sin / exp2 / log2)
+  const uint32_t* pre;         // preprocessed columns on the eval domain (lookup components)
+  const uint32_t* pre2;
   const QM31* claimed_shift;   // device: [claimed, shift]
   QM31 coeff[16];              // alpha^(N-1-k) for this component's constraints, in order
   uint32_t zinv[2];            // 1/Z for rows with (s >> log_size) == 0 / 1

@@ -988,17 +988,20 @@ LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint3
 }
 
 // logup constraints for NREL relations; values are passed by value (no indexed private arrays:
-// those get promoted to LDS and cost occupancy).  rc[j] != 0: relation j uses the width-1
-// RangeCheckLookupElements (z2) instead of NodeElements (z, alpha); neg: numerator is -mult.
+// those get promoted to LDS and cost occupancy).  rc[j]: 0 = NodeElements (z, alpha); 1 = width-1
+// LUT relation val - z2 (range check); 2 = width-2 LUT relation val + alpha2*id - z2 (sin/exp2/log2).
+// neg: numerator is -mult.
 template <int NREL>
 LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t (&mult)[NREL],
-                             const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], const bool (&rc)[NREL], bool neg,
+                             const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], const int (&rc)[NREL], bool neg,
                              uint32_t s, uint64_t E) {
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
     QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * E, E, s);
-    QM31 den = rc[j] ? q_sub(q_from_m(val[j]), a.z2) : q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
+    QM31 den = rc[j] == 1   ? q_sub(q_from_m(val[j]), a.z2)
+               : rc[j] == 2 ? q_sub(q_add_m(q_mul_m(a.alpha2, id[j]), val[j]), a.z2)
+                            : q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
     QM31 diff;
     if (j < NREL - 1) {
       diff = q_sub(cur, prev);
@@ -1042,7 +1045,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
-    const bool rc[3] = {false, false, false};
+    const int rc[3] = {0, 0, 0};
     logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 2 || KIND == 7) {
     // Recip / Sqrt (13 cols; the eval_fixed_* forms are unpinned natural identities)
@@ -1060,7 +1063,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
-    const bool rc[2] = {false, false};
+    const int rc[2] = {0, 0};
     logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 8) {
     // Rem (16 cols): lhs = rhs*quotient + rem (unpinned form); the out relation carries `rem`
@@ -1076,7 +1079,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_rhs, rhs_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, rem}, ri[3] = {lhs_id, rhs_id, node};
-    const bool rc[3] = {false, false, false};
+    const int rc[3] = {0, 0, 0};
     logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 13) {
     // LessThan (22 cols; less_than/component.rs:48-185): 9 local constraints, 3 node relations +
@@ -1098,13 +1101,34 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[7] = {m0, m1, m2, md, md, md, md}, rv[7] = {lhs, rhs, out, l0, l1, l2, l3};
     const uint32_t ri[7] = {lhs_id, rhs_id, node, 0u, 0u, 0u, 0u};
-    const bool rc[7] = {false, false, false, true, true, true, true};
+    const int rc[7] = {0, 0, 0, 1, 1, 1, 1};
     logup_constraints<7>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 14) {
     // RangeCheckLookup: multiplicity column + preprocessed LUT column, relation (-multiplicity, [lut])
     const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[s]}, ri[1] = {0u};
-    const bool rc[1] = {true};
+    const int rc[1] = {1};
     logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, E);
+  } else if (KIND == 4) {
+    // SinLookup / Exp2Lookup / Log2Lookup (lookups/sin/component.rs:40-59): multiplicity column + the two
+    // preprocessed LUT columns, relation (-multiplicity, [lut_0, lut_1])
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[s]}, ri[1] = {a.pre2[s]};
+    const int rc[1] = {2};
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, E);
+  } else if (KIND == 3) {
+    // Sin / Exp2 / Log2 (12 cols; sin/component.rs:50-122): the function value is enforced by the LUT
+    // relation (lookup_mult, [input, out]) only
+    const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
+    const uint32_t n_node = LMN_COL(4), n_in = LMN_COL(5), n_idx = LMN_COL(6);
+    const uint32_t inp = LMN_COL(7), out = LMN_COL(8);
+    const uint32_t m0 = LMN_COL(9), m1 = LMN_COL(10), m2 = LMN_COL(11);
+    ca.add_m(m_mul(is_last, m_sub(is_last, 1u)));
+    const uint32_t not_last = m_sub(1u, is_last);
+    ca.add_m(m_mul(not_last, m_sub(n_node, node)));
+    ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
+    ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
+    const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {inp, out, inp}, ri[3] = {in_id, node, out};
+    const int rc[3] = {0, 0, 2};
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
   } else if (KIND == 5 || KIND == 6 || KIND == 16) {
     // SumReduce (14 cols) / MaxReduce (15) / Contiguous (11): shared id/idx prefix, 2 relations
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -1131,7 +1155,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_in, in_id)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
-    const bool rc[2] = {false, false};
+    const int rc[2] = {0, 0};
     logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
   } else {
     const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
@@ -1141,7 +1165,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(n_node, node)));
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[1] = {mult}, rv[1] = {val}, ri[1] = {node};
-    const bool rc[1] = {false};
+    const int rc[1] = {0};
     logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, E);
   }
 #undef LMN_COL
@@ -1166,6 +1190,12 @@ void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
     case 0: LMN_LAUNCH(k_composition<0>, g, b, 0, s, a); break;
     case 1: LMN_LAUNCH(k_composition<1>, g, b, 0, s, a); break;
     case 2: LMN_LAUNCH(k_composition<2>, g, b, 0, s, a); break;
+    case 3:
+    case 9:
+    case 11: LMN_LAUNCH(k_composition<3>, g, b, 0, s, a); break;
+    case 4:
+    case 10:
+    case 12: LMN_LAUNCH(k_composition<4>, g, b, 0, s, a); break;
     case 5: LMN_LAUNCH(k_composition<5>, g, b, 0, s, a); break;
     case 6: LMN_LAUNCH(k_composition<6>, g, b, 0, s, a); break;
     case 7: LMN_LAUNCH(k_composition<7>, g, b, 0, s, a); break;

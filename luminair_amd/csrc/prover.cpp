@@ -15,28 +15,76 @@ namespace lmn {
 // ------------------------------------------------------------------------------------ components
 // Column layouts / relation wiring: crates/air/src/components/{add,mul,recip,inputs}/{table,component}.rs
 static const ComponentSpec kSpecs[] = {
-    // kind, n_cols, is_last, n_rel, rel_mult, rel_val, rel_id, n_local, rel_elems, rel_neg, rel_pre, n_pre, n_pad, pad_col, pad_val
-    {LMN_KIND_ADD, 15, 4, 3, {12, 13, 14}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, 0, {0}, {0}},
-    {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7, {0}, {0}, {0}, 0, 0, {0}, {0}},
-    {LMN_KIND_RECIP, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, 0, {0}, {0}},
-    {LMN_KIND_INPUTS, 7, 2, 1, {6}, {5}, {0}, 3, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    // kind, n_cols, is_last, n_rel, rel_mult, rel_val, rel_id, n_local, rel_elems, rel_neg, rel_pre, n_pre, pre_id, n_pad, pad_col, pad_val
+    {LMN_KIND_ADD, 15, 4, 3, {12, 13, 14}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_MUL, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 7, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_RECIP, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_INPUTS, 7, 2, 1, {6}, {5}, {0}, 3, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
     // constraint forms fully visible in the reference (no numerair helper):
-    {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13}, {7, 8}, {1, 0}, 7, {0}, {0}, {0}, 0, 0, {0}, {0}},   // sum_reduce/component.rs:36-110
-    {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14}, {7, 8}, {1, 0}, 9, {0}, {0}, {0}, 0, 0, {0}, {0}},   // max_reduce/component.rs
-    {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10}, {7, 8}, {1, 0}, 4, {0}, {0}, {0}, 0, 0, {0}, {0}},    // contiguous/component.rs
+    {LMN_KIND_SUM_REDUCE, 14, 3, 2, {12, 13}, {7, 8}, {1, 0}, 7, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},   // sum_reduce/component.rs:36-110
+    {LMN_KIND_MAX_REDUCE, 15, 3, 2, {13, 14}, {7, 8}, {1, 0}, 9, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},   // max_reduce/component.rs
+    {LMN_KIND_CONTIGUOUS, 11, 3, 2, {9, 10}, {7, 8}, {1, 0}, 4, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},    // contiguous/component.rs
     // numerair's eval_fixed_sqrt / eval_fixed_rem are un-vendored: natural fixed-point identities (unpinned)
-    {LMN_KIND_SQRT, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, 0, {0}, {0}},
-    {LMN_KIND_REM, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, 0, {0}, {0}},
+    {LMN_KIND_SQRT, 13, 3, 2, {11, 12}, {7, 8}, {1, 0}, 5, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_REM, 16, 4, 3, {13, 14, 15}, {9, 10, 11}, {1, 2, 0}, 6, {0}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
     // less_than/component.rs:48-185; padding row less_than/table.rs:47-72 (rhs=1, out=4096, diff=1, limb0=1)
     {LMN_KIND_LESS_THAN, 22, 4, 7, {18, 19, 20, 21, 21, 21, 21}, {9, 10, 11, 14, 15, 16, 17}, {1, 2, 0, -1, -1, -1, -1}, 9,
-     {0, 0, 0, 1, 1, 1, 1}, {0}, {0}, 0, 4, {10, 11, 12, 14}, {1u, 4096u, 1u, 1u}},
+     {0, 0, 0, 1, 1, 1, 1}, {0}, {0}, 0, {0, 0}, 4, {10, 11, 12, 14}, {1u, 4096u, 1u, 1u}},
     // lookups/range_check/component.rs: (-multiplicity, [range_check_8_column_0])
-    {LMN_KIND_RANGE_CHECK_LOOKUP, 1, -1, 1, {0}, {0}, {-1}, 0, {1}, {1}, {1}, 1, 0, {0}, {0}},
+    {LMN_KIND_RANGE_CHECK_LOOKUP, 1, -1, 1, {0}, {0}, {-1}, 0, {ELEMS_RANGE_CHECK}, {1}, {1}, 1, {PRE_RANGE_CHECK, 0}, 0, {0}, {0}},
+    // sin/component.rs:50-122 (exp2, log2 alike): node relations on input/out + LUT relation (lookup_mult, [input, out])
+    {LMN_KIND_SIN, 12, 3, 3, {9, 10, 11}, {7, 8, 7}, {1, 0, 8}, 4, {0, 0, ELEMS_SIN}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_EXP2, 12, 3, 3, {9, 10, 11}, {7, 8, 7}, {1, 0, 8}, 4, {0, 0, ELEMS_EXP2}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    {LMN_KIND_LOG2, 12, 3, 3, {9, 10, 11}, {7, 8, 7}, {1, 0, 8}, 4, {0, 0, ELEMS_LOG2}, {0}, {0}, 0, {0, 0}, 0, {0}, {0}},
+    // lookups/sin/component.rs:40-59: (-multiplicity, [lut_0, lut_1]) over the two preprocessed columns
+    {LMN_KIND_SIN_LOOKUP, 1, -1, 1, {0}, {0}, {1}, 0, {ELEMS_SIN}, {1}, {1}, 2, {PRE_SIN0, PRE_SIN0 + 1}, 0, {0}, {0}},
+    {LMN_KIND_EXP2_LOOKUP, 1, -1, 1, {0}, {0}, {1}, 0, {ELEMS_EXP2}, {1}, {1}, 2, {PRE_EXP20, PRE_EXP20 + 1}, 0, {0}, {0}},
+    {LMN_KIND_LOG2_LOOKUP, 1, -1, 1, {0}, {0}, {1}, 0, {ELEMS_LOG2}, {1}, {1}, 2, {PRE_LOG20, PRE_LOG20 + 1}, 0, {0}, {0}},
 };
 const ComponentSpec* component_spec(int kind) {
   for (auto& s : kSpecs)
     if (s.kind == kind) return &s;
   return nullptr;
+}
+
+RelElems draw_relation_elements(Channel& channel, uint32_t protocol_variant) {
+  RelElems e;
+  auto draw = [&](int set) {
+    std::vector<QM31> d = channel.draw_felts(2);
+    if (set >= 0) {
+      e.z[set] = d[0];
+      e.alpha[set] = d[1];
+      e.drawn[set] = true;
+    }
+  };
+  draw(ELEMS_NODE);
+  draw(ELEMS_SIN);  // the KAT era drew a single LUT relation; HEAD: sin, exp2, log2, range_check
+  if (protocol_variant != LMN_VARIANT_KAT) {
+    draw(ELEMS_EXP2);
+    draw(ELEMS_LOG2);
+    draw(ELEMS_RANGE_CHECK);
+  }
+  return e;
+}
+
+std::vector<int> assign_preprocessed(std::vector<Instance>& inst) {
+  int log_of[N_PRE_IDS];
+  for (int& l : log_of) l = -1;
+  for (auto& ci : inst)
+    for (int k = 0; k < ci.spec->n_pre; ++k) log_of[ci.spec->pre_id[k]] = ci.log_size;
+  std::vector<int> order;
+  for (int id = 0; id < N_PRE_IDS; ++id)
+    if (log_of[id] >= 0) order.push_back(id);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_of[a] > log_of[b]; });
+  int pos[N_PRE_IDS];
+  std::vector<int> logs;
+  for (size_t i = 0; i < order.size(); ++i) {
+    pos[order[i]] = (int)i;
+    logs.push_back(log_of[order[i]]);
+  }
+  for (auto& ci : inst)
+    for (int k = 0; k < ci.spec->n_pre; ++k) ci.pre_idx[k] = pos[ci.spec->pre_id[k]];
+  return logs;
 }
 
 // ------------------------------------------------------------------------------------ arena
@@ -432,7 +480,8 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
     out.push_back(q_mul(not_last, q_sub(c[6], c[1])));
     out.push_back(q_mul(not_last, q_sub(c[7], c[2])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[8], c[3]))));
-  } else if (kind == LMN_KIND_RANGE_CHECK_LOOKUP) {
+  } else if (kind == LMN_KIND_RANGE_CHECK_LOOKUP || kind == LMN_KIND_SIN_LOOKUP || kind == LMN_KIND_EXP2_LOOKUP ||
+             kind == LMN_KIND_LOG2_LOOKUP) {
     // no local constraints
   } else if (kind == LMN_KIND_LESS_THAN) {
     QM31 is_last = c[4], not_last = one_minus(is_last), borrow = c[13];
@@ -451,7 +500,7 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
     out.push_back(q_mul(is_last, qsub1(is_last)));
     out.push_back(q_mul(not_last, q_sub(c[3], c[0])));
     out.push_back(q_mul(not_last, qsub1(q_sub(c[4], c[1]))));
-  } else {  // SumReduce / MaxReduce / Contiguous share the id/idx prefix (columns 0..6)
+  } else {  // SumReduce / MaxReduce / Contiguous / Sin / Exp2 / Log2 share the id/idx prefix (columns 0..6)
     QM31 is_last = c[3], not_last = one_minus(is_last);
     out.push_back(q_mul(is_last, qsub1(is_last)));
     if (kind == LMN_KIND_SUM_REDUCE) {
@@ -475,8 +524,8 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
 }
 
 QM31 eval_composition_at_point(const std::vector<Instance>& inst,
-                                      const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, QM31 z,
-                                      QM31 alpha_rel, QM31 z_rc, QM31 comp_alpha) {
+                               const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, const RelElems& elems,
+                               QM31 comp_alpha) {
   QM31 acc = q_zero();
   for (auto& ci : inst) {
     const ComponentSpec* sp = ci.spec;
@@ -487,8 +536,10 @@ QM31 eval_composition_at_point(const std::vector<Instance>& inst,
     QM31 shift = q_mul_m(ci.claimed, m_inv((uint32_t)((1ull << ci.log_size) % P31)));
     for (int j = 0; j < sp->n_rel; ++j) {
       const auto* cols = &sv[2][ci.inter_start + 4 * j];
-      QM31 val = sp->rel_pre[j] ? sv[0][ci.pre_idx][0] : main[sp->rel_val[j]];
-      QM31 den = sp->rel_elems[j] ? q_sub(val, z_rc) : q_sub(q_add(val, q_mul(alpha_rel, main[sp->rel_id[j]])), z);
+      auto cell = [&](int idx) { return sp->rel_pre[j] ? sv[0][ci.pre_idx[idx]][0] : main[idx]; };
+      const int es = sp->rel_elems[j];
+      QM31 den = q_sub(cell(sp->rel_val[j]), elems.z[es]);
+      if (sp->rel_id[j] >= 0) den = q_add(den, q_mul(elems.alpha[es], cell(sp->rel_id[j])));
       QM31 num = sp->rel_neg[j] ? q_neg(main[sp->rel_mult[j]]) : main[sp->rel_mult[j]];
       QM31 cur, diff;
       if (j < sp->n_rel - 1) {
@@ -638,8 +689,6 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   if (!tables || n_tables == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "no trace tables");
-  if (settings && (settings->has_lookups & ~LMN_LOOKUP_RANGE_CHECK))
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only the range-check lookup table is in scope");
   const int lb = (int)cfg.log_blowup;
   const int n_slots = cfg.protocol_variant == LMN_VARIANT_KAT ? 8 : 17;
   HostMarks hm;
@@ -706,37 +755,85 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   StageTimer* total_timer = new StageTimer(this, log, stream_, C_TOTAL);
   std::unique_ptr<StageTimer> total_guard(total_timer);
 
-  // ---- PHASE 0: preprocessed trace (prover.rs:54-59): empty tree (root = blake2s("")) unless a LUT
-  // component is present; the only LUT in scope is the 8-bit range check (preprocessed.rs:289-296:
-  // row r of `range_check_8_column_0` holds r)
+  // ---- PHASE 0: preprocessed trace (prover.rs:54-59): empty tree (root = blake2s("")) unless a lookup
+  // component is present.  Columns in PreProcessedTrace order (preprocessed.rs:157-179: sin, exp2, log2
+  // LUT pairs from the settings, then the 8-bit range check whose row r holds r), stable-sorted by size
+  // descending (PreProcessedTrace::new).
   DevTree tree0;
-  bool has_range_check = false;
-  for (auto& ti : infos) has_range_check = has_range_check || ti.spec->kind == LMN_KIND_RANGE_CHECK_LOOKUP;
-  if (settings && (settings->has_lookups & LMN_LOOKUP_RANGE_CHECK) && !has_range_check)
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "settings announce a range-check LUT but the pie has no RangeCheckLookup table");
-  uint32_t* d_rc_evals = nullptr;
-  constexpr int RC_LOG = 8;
-  if (has_range_check) {
-    std::vector<uint32_t> lut(1u << RC_LOG);
-    for (uint32_t r = 0; r < lut.size(); ++r) lut[r] = r;
-    d_rc_evals = upload_vec(lut);
-    uint32_t* coeffs = arena_.alloc_words(lut.size());
-    launch_ifft(coeffs, lut.size(), d_rc_evals, lut.size(), 1, RC_LOG, itw(RC_LOG), stream_);
-    tree0.cols.push_back({RC_LOG, coeffs, nullptr});
-    lde_and_merkle(tree0);
-    lmn_sync(stream_);
-    tree0.merkle.finish_root();
-  } else {
-    build_merkle(tree0.merkle, {});
+  std::vector<Instance> inst;
+  for (auto& ti : infos) {
+    Instance ci{};
+    ci.spec = ti.spec;
+    ci.log_size = ti.log_size;
+    inst.push_back(ci);
+  }
+  std::vector<uint32_t*> pre_evals;  // tree-0 columns on their trace domain (logup denominators)
+  {
+    uint32_t present = 0;
+    const lmn_lut* lut_of[3] = {nullptr, nullptr, nullptr};
+    for (auto& ti : infos) {
+      if (ti.spec->kind == LMN_KIND_SIN_LOOKUP) present |= LMN_LOOKUP_SIN;
+      if (ti.spec->kind == LMN_KIND_EXP2_LOOKUP) present |= LMN_LOOKUP_EXP2;
+      if (ti.spec->kind == LMN_KIND_LOG2_LOOKUP) present |= LMN_LOOKUP_LOG2;
+      if (ti.spec->kind == LMN_KIND_RANGE_CHECK_LOOKUP) present |= LMN_LOOKUP_RANGE_CHECK;
+    }
+    if (settings && (settings->has_lookups & ~present))
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "settings announce a lookup whose table is not in the pie");
+    if (settings && settings->n_luts) {
+      if (!settings->luts) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null luts pointer");
+      for (uint32_t i = 0; i < settings->n_luts; ++i) {
+        const lmn_lut& l = settings->luts[i];
+        if (l.kind > LMN_LUT_LOG2 || !l.col0 || !l.col1 || lut_of[l.kind])
+          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad or duplicate LUT in settings");
+        lut_of[l.kind] = &l;
+      }
+    }
+    std::vector<int> logs = assign_preprocessed(inst);
+    tree0.cols.resize(logs.size());
+    pre_evals.resize(logs.size(), nullptr);
+    for (auto& ci : inst) {
+      const ComponentSpec* sp = ci.spec;
+      for (int k = 0; k < sp->n_pre; ++k) {
+        const uint64_t n = 1ull << ci.log_size;
+        uint32_t* evals;
+        if (sp->pre_id[k] == PRE_RANGE_CHECK) {
+          if (ci.log_size != 8) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "RangeCheckLookup table must have exactly 256 rows");
+          std::vector<uint32_t> lut(n);
+          for (uint32_t r = 0; r < n; ++r) lut[r] = r;
+          evals = upload_vec(lut);
+        } else {
+          const lmn_lut* l = lut_of[sp->pre_id[k] / 2];
+          if (!l) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "lookup table present but settings carry no LUT columns for it");
+          if ((int)l->log_size != ci.log_size)
+            throw LmnError(LMN_ERR_INVALID_ARGUMENT, "lookup table rows must match the LUT column size");
+          const uint32_t* src = (sp->pre_id[k] & 1) ? l->col1 : l->col0;
+          for (uint64_t r = 0; r < n; ++r)
+            if (src[r] >= P31) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "LUT value is not a canonical M31");
+          evals = arena_.alloc_words(n);
+          lmn_h2d(evals, src, n * 4, stream_);
+        }
+        uint32_t* coeffs = arena_.alloc_words(n);
+        launch_ifft(coeffs, n, evals, n, 1, ci.log_size, itw(ci.log_size), stream_);
+        tree0.cols[ci.pre_idx[k]] = {ci.log_size, coeffs, nullptr};
+        pre_evals[ci.pre_idx[k]] = evals;
+      }
+    }
+    if (!tree0.cols.empty()) {
+      lde_and_merkle(tree0);
+      lmn_sync(stream_);
+      tree0.merkle.finish_root();
+    } else {
+      build_merkle(tree0.merkle, {});
+    }
   }
   channel.mix_root(tree0.merkle.root);
 
   // ---- PHASE 1: main trace (prover.rs:70-179)
   DevTree tree1;
-  std::vector<Instance> inst;
   {
     StageTimer st(this, log, stream_, C_TRANSPOSE);
-    for (auto& ti : infos) {
+    for (size_t t = 0; t < infos.size(); ++t) {
+      auto& ti = infos[t];
       const uint32_t* d_rows = ti.rows;
       if (!ti.on_device) {
         uint32_t* stg = arena_.alloc_words(ti.n_rows * ti.spec->n_cols);
@@ -749,12 +846,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
       for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
       launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, pad, stream_);
-      Instance ci{};
-      ci.spec = ti.spec;
-      ci.log_size = ti.log_size;
-      ci.trace_evals = evals;
-      ci.pre_idx = ti.spec->n_pre ? 0 : -1;
-      inst.push_back(ci);
+      inst[t].trace_evals = evals;
       proof.claim[ti.spec->kind] = ti.log_size;
     }
   }
@@ -784,17 +876,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   }
 
   // ---- PHASE 2: interaction trace (prover.rs:186-298)
-  std::vector<QM31> rel = channel.draw_felts(2);  // NodeElements: z, alpha
-  const QM31 z = rel[0], alpha_rel = rel[1];
-  // LookupElements::draw (lookups/mod.rs:44-51): KAT era one LUT relation; HEAD: sin, exp2, log2, range_check
-  QM31 z_rc = q_zero(), alpha_rc = q_zero();
-  for (int k = 0; k < (cfg.protocol_variant == LMN_VARIANT_KAT ? 1 : 4); ++k) {
-    std::vector<QM31> d = channel.draw_felts(2);
-    if (k == 3) {
-      z_rc = d[0];
-      alpha_rc = d[1];
-    }
-  }
+  const RelElems elems = draw_relation_elements(channel, cfg.protocol_variant);
   DevTree tree2;
   {
     StageTimer st(this, log, stream_, C_LOGUP);
@@ -807,16 +889,18 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       LogupArgs a{};
       a.k = sp->n_rel;
       for (int j = 0; j < sp->n_rel; ++j) {
-        if (sp->rel_elems[j] && cfg.protocol_variant == LMN_VARIANT_KAT)
-          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "range-check relations need the PINNED protocol variant");
-        if (sp->rel_pre[j] && (uint64_t)(1u << RC_LOG) != n)
-          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "RangeCheckLookup table must have exactly 256 rows");
-        a.val[j] = sp->rel_pre[j] ? d_rc_evals : ci.trace_evals + (uint64_t)sp->rel_val[j] * n;
-        a.id[j] = sp->rel_id[j] >= 0 ? ci.trace_evals + (uint64_t)sp->rel_id[j] * n : nullptr;
+        const int es = sp->rel_elems[j];
+        if (!elems.drawn[es])
+          throw LmnError(LMN_ERR_INVALID_ARGUMENT, "component needs relation elements this protocol variant does not draw");
+        auto column = [&](int idx) -> const uint32_t* {
+          return sp->rel_pre[j] ? pre_evals[ci.pre_idx[idx]] : ci.trace_evals + (uint64_t)idx * n;
+        };
+        a.val[j] = column(sp->rel_val[j]);
+        a.id[j] = sp->rel_id[j] >= 0 ? column(sp->rel_id[j]) : nullptr;
         a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * n;
         a.neg[j] = sp->rel_neg[j];
-        a.z[j] = sp->rel_elems[j] ? z_rc : z;
-        a.alpha[j] = sp->rel_elems[j] ? alpha_rc : alpha_rel;
+        a.z[j] = elems.z[es];
+        a.alpha[j] = elems.alpha[es];
       }
       a.inter = ievals;
       a.last_tmp = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
@@ -886,11 +970,15 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       a.inter = tree2.cols[ci.inter_start].lde;
       a.out = sub[e];
       a.accumulate = first ? 0 : 1;
-      a.z = z;
-      a.alpha = alpha_rel;
-      a.z2 = z_rc;
-      a.alpha2 = alpha_rc;
-      a.pre = ci.pre_idx >= 0 ? tree0.cols[ci.pre_idx].lde : nullptr;
+      a.z = elems.z[ELEMS_NODE];
+      a.alpha = elems.alpha[ELEMS_NODE];
+      for (int j = 0; j < ci.spec->n_rel; ++j)
+        if (ci.spec->rel_elems[j] != ELEMS_NODE) {
+          a.z2 = elems.z[ci.spec->rel_elems[j]];
+          a.alpha2 = elems.alpha[ci.spec->rel_elems[j]];
+        }
+      a.pre = ci.pre_idx[0] >= 0 ? tree0.cols[ci.pre_idx[0]].lde : nullptr;
+      a.pre2 = ci.pre_idx[1] >= 0 ? tree0.cols[ci.pre_idx[1]].lde : nullptr;
       a.claimed_shift = ci.d_claimed_shift;
       int nc = ci.spec->n_local + ci.spec->n_rel;
       for (int k = 0; k < nc; ++k) a.coeff[k] = powers[n_total - 1 - (k0 + k)];
@@ -989,7 +1077,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
   {
     QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
-    QM31 rhs = eval_composition_at_point(inst, sampled, oods, z, alpha_rel, z_rc, comp_alpha);
+    QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha);
     if (!q_eq(lhs, rhs)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
   }
 

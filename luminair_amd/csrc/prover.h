@@ -19,15 +19,26 @@ struct ComponentSpec {
   int n_rel;
   int rel_mult[MAX_REL], rel_val[MAX_REL], rel_id[MAX_REL];  // rel_id < 0: width-1 relation (value only)
   int n_local;                // number of local constraints (including zero slots)
-  int rel_elems[MAX_REL];     // 0 NodeElements, 1 RangeCheckLookupElements
+  int rel_elems[MAX_REL];     // ELEMS_*: 0 NodeElements, 1 RangeCheckLookup, 2 SinLookup, 3 Exp2Lookup, 4 Log2Lookup
   int rel_neg[MAX_REL];       // numerator is -mult
-  int rel_pre[MAX_REL];       // rel_val indexes the component's preprocessed columns
-  int n_pre;                  // preprocessed (tree 0) columns used: only the 8-bit range-check column so far
+  int rel_pre[MAX_REL];       // rel_val / rel_id index the component's preprocessed columns
+  int n_pre;                  // preprocessed (tree 0) columns read (0..2)
+  int pre_id[2];              // PRE_*: position in PreProcessedTrace order (preprocessed.rs:157-179)
   int n_pad;                  // extra non-zero padding cells besides is_last_col = 1
   int pad_col[4];
   uint32_t pad_val[4];
 };
 const ComponentSpec* component_spec(int kind);
+enum { ELEMS_NODE = 0, ELEMS_RANGE_CHECK = 1, ELEMS_SIN = 2, ELEMS_EXP2 = 3, ELEMS_LOG2 = 4, N_ELEMS = 5 };
+// tree-0 column order before the stable size sort: sin_lut_0/1, exp2_lut_0/1, log2_lut_0/1, range_check_8
+enum { PRE_SIN0 = 0, PRE_EXP20 = 2, PRE_LOG20 = 4, PRE_RANGE_CHECK = 6, N_PRE_IDS = 7 };
+// relation element sets drawn after the main commitment (components/mod.rs:227-235, lookups/mod.rs:44-51)
+struct RelElems {
+  QM31 z[N_ELEMS], alpha[N_ELEMS];
+  bool drawn[N_ELEMS] = {false, false, false, false, false};
+};
+class Channel;
+RelElems draw_relation_elements(Channel& channel, uint32_t protocol_variant);
 
 // one component of a proof: shared by the prover and the host-side verifier
 struct Instance {
@@ -37,11 +48,14 @@ struct Instance {
   QM31 claimed;
   const QM31* d_claimed_shift = nullptr;  // device [claimed, shift] (prover only)
   uint32_t* trace_evals = nullptr;        // device, n_cols x 2^log_size (prover only)
-  int pre_idx = -1;             // tree-0 column index of the component's preprocessed column (if any)
+  int pre_idx[2] = {-1, -1};    // tree-0 column indices of the component's preprocessed columns
 };
 // sum_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values
 QM31 eval_composition_at_point(const std::vector<Instance>& inst, const std::vector<std::vector<std::vector<QM31>>>& sv,
-                               QPt oods, QM31 z, QM31 alpha_rel, QM31 z_rc, QM31 comp_alpha);
+                               QPt oods, const RelElems& elems, QM31 comp_alpha);
+// tree-0 layout implied by the components present: fills Instance::pre_idx, returns the columns' log
+// sizes in tree order (a LUT column has the log size of its lookup component)
+std::vector<int> assign_preprocessed(std::vector<Instance>& inst);
 // verify(proof, settings): crates/verifiers/rust/src/verifier.rs:21-143 (host only, no GPU work)
 void verify_proof(const uint8_t* data, size_t len, uint32_t protocol_variant);
 

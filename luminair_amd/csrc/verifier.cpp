@@ -224,7 +224,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   // components in struct order; tree layouts implied by the claim (Claim::log_sizes, components/mod.rs:164-170)
   std::vector<Instance> inst;
   int m_off = 0, i_off = 0;
-  bool has_rc = false;
   for (int kind = 0; kind < n_slots; ++kind) {
     if (p.claim[kind] < 0) continue;
     const ComponentSpec* sp = component_spec(kind);
@@ -237,8 +236,6 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
     ci.main_start = m_off;
     ci.inter_start = i_off;
     ci.claimed = p.interaction_claim[kind].second;
-    ci.pre_idx = sp->n_pre ? 0 : -1;
-    has_rc = has_rc || sp->n_pre;
     m_off += sp->n_cols;
     i_off += 4 * sp->n_rel;
     inst.push_back(ci);
@@ -247,7 +244,7 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   for (int kind = 0; kind < n_slots; ++kind)
     if (p.claim[kind] < 0 && p.interaction_claim[kind].first) fail("interaction claim without claim");
   std::vector<std::vector<int>> tree_logs(4);
-  if (has_rc) tree_logs[0].push_back(8);
+  tree_logs[0] = assign_preprocessed(inst);
   int max_log = 0;
   for (auto& ci : inst) {
     for (int c = 0; c < ci.spec->n_cols; ++c) tree_logs[1].push_back(ci.log_size);
@@ -262,13 +259,10 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   for (int kind = 0; kind < n_slots; ++kind)
     if (p.claim[kind] >= 0) ch.mix_u64((uint64_t)p.claim[kind]);
   ch.mix_root(p.commitments[1]);
-  std::vector<QM31> rel = ch.draw_felts(2);
-  QM31 z_rc = q_zero();
-  for (int k = 0; k < (variant == LMN_VARIANT_KAT ? 1 : 4); ++k) {
-    std::vector<QM31> d = ch.draw_felts(2);
-    if (k == 3) z_rc = d[0];
-  }
-  if (has_rc && variant == LMN_VARIANT_KAT) fail("range-check components need the PINNED variant");
+  const RelElems elems = draw_relation_elements(ch, variant);
+  for (auto& ci : inst)
+    for (int j = 0; j < ci.spec->n_rel; ++j)
+      if (!elems.drawn[ci.spec->rel_elems[j]]) fail("component needs relation elements this protocol variant does not draw");
   QM31 tot = q_zero();
   for (auto& ci : inst) tot = q_add(tot, ci.claimed);
   if (!q_is_zero(tot)) throw LmnError(LMN_ERR_INVALID_LOGUP, "InvalidLogUp");   // log_sum_valid, verifier.rs:97-99
@@ -306,7 +300,7 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
   {
     auto& s3 = p.sampled_values[3];
     QM31 lhs = q_from_partial_evals(s3[0][0], s3[1][0], s3[2][0], s3[3][0]);
-    QM31 rhs = eval_composition_at_point(inst, p.sampled_values, oods, rel[0], rel[1], z_rc, comp_alpha);
+    QM31 rhs = eval_composition_at_point(inst, p.sampled_values, oods, elems, comp_alpha);
     if (!q_eq(lhs, rhs)) fail("OodsNotMatching");
   }
   {

@@ -34,7 +34,8 @@ class TraceTableKind(IntEnum):
 N_COLUMNS = {TraceTableKind.Add: 15, TraceTableKind.Mul: 16, TraceTableKind.Recip: 13, TraceTableKind.Inputs: 7,
              TraceTableKind.SumReduce: 14, TraceTableKind.MaxReduce: 15, TraceTableKind.Contiguous: 11,
              TraceTableKind.LessThan: 22, TraceTableKind.RangeCheckLookup: 1, TraceTableKind.Sqrt: 13,
-             TraceTableKind.Rem: 16}
+             TraceTableKind.Rem: 16, TraceTableKind.Sin: 12, TraceTableKind.Exp2: 12, TraceTableKind.Log2: 12,
+             TraceTableKind.SinLookup: 1, TraceTableKind.Exp2Lookup: 1, TraceTableKind.Log2Lookup: 1}
 
 
 class LuminairError(Exception):
@@ -93,12 +94,25 @@ class LuminairPie:
 
 @dataclass
 class CircuitSettings:
-    """`CircuitSettings { lookups }`; LUT-free graphs only (all lookups None)."""
+    """`CircuitSettings { lookups }` (crates/air/src/settings.rs).  `lookups` maps "sin" / "exp2" /
+    "log2" to that LUT's two preprocessed columns (col0 = inputs, col1 = outputs; uint32 M31 words,
+    2^k rows), i.e. what `lookups_to_preprocessed_column` + `gen_column_simd` produce from the
+    reference's layouts; the 8-bit range-check LUT is implied by a RangeCheckLookup table."""
     lookups: Optional[dict] = None
+
+    def lut_columns(self) -> dict:
+        out = {}
+        for name, cols in (self.lookups or {}).items():
+            if name == "range_check":
+                continue
+            if name not in ("sin", "exp2", "log2"):
+                raise LuminairError("InvalidArgument", "unknown lookup " + name)
+            out[name] = cols
+        return out
 
     def to_bincode(self) -> bytes:
         if self.lookups:
-            raise LuminairError("SerializationError", "lookup settings are outside the hot-path scope")
+            raise LuminairError("SerializationError", "LUT layouts (value ranges) are not carried by this mirror")
         return bytes(4)  # four `None` tags: sin, exp2, log2, range_check
 
 

@@ -38,11 +38,10 @@ class Prover:
             raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
 
     def prove(self, pie: LuminairPie, settings: Optional[CircuitSettings] = None) -> LuminairProof:
-        if settings is not None and settings.lookups:
-            raise LuminairError("InvalidArgument", "lookup tables are outside the hot-path scope")
         tables = [(int(t.kind), t.rows, t.n_rows) for t in pie.trace_tables]
+        luts = settings.lut_columns() if settings is not None else None
         try:
-            return LuminairProof(self.ctx.prove_tables(tables))
+            return LuminairProof(self.ctx.prove_tables(tables, luts))
         except backend.LuminairBackendError as e:
             raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
 
@@ -65,8 +64,6 @@ def verify(proof: LuminairProof, settings: Optional[CircuitSettings] = None,
            protocol_variant: int = backend.VARIANT_KAT, library=None) -> None:
     """Drop-in for the reference's `verify(proof, settings)` (crates/verifiers/rust/src/verifier.rs:21-143):
     host-side check of a proof's bincode bytes; raises LuminairError(StwoVerifierError | InvalidLogUp | ...)."""
-    if settings is not None and settings.lookups:
-        raise LuminairError("InvalidArgument", "lookup settings are outside the hot-path scope")
     lib = library or backend.default_library()
     try:
         lib.verify(proof.to_bincode() if isinstance(proof, LuminairProof) else bytes(proof), protocol_variant)

@@ -163,6 +163,61 @@ def sqrt_rem_graph(n: int, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
     return [(KIND_SQRT, sq), (KIND_REM, rm), (KIND_INPUTS, inp)]
 
 
+_LUT_FN = {"sin": np.sin, "exp2": np.exp2, "log2": np.log2}
+_LUT_KINDS = {"sin": (3, 4), "exp2": (9, 10), "log2": (11, 12)}   # (component kind, lookup kind)
+
+
+def make_lut(name: str, lo: int, hi: int):
+    """LUT columns for one value range, the way `SinPreProcessed::gen_column` lays them out
+    (crates/air/src/preprocessed.rs:351-383): the fixed-point values lo..=hi ascending in column 0,
+    round(f(v/scale)*scale) in column 1, zero rows up to the next power of two (at least 16 rows).
+    Returns (col0, col1) as uint32 M31 words."""
+    v = np.arange(lo, hi + 1, dtype=np.int64)
+    out = np.rint(_LUT_FN[name](v / SCALE) * SCALE).astype(np.int64)
+    log = max(4, int(len(v) - 1).bit_length())
+    pad = (1 << log) - len(v)
+    col0 = np.concatenate([to_m31(v), np.zeros(pad, np.int64)]).astype(np.uint32)
+    col1 = np.concatenate([to_m31(out), np.zeros(pad, np.int64)]).astype(np.uint32)
+    return col0, col1
+
+
+def unary_lut_rows(name: str, inp, lo: int, node=2, input_id=0, mults=(0, 0)):
+    """Sin / Exp2 / Log2 rows (`crates/graph/src/op/prim.rs:663-760` and siblings): out = LUT(input),
+    lookup multiplicity 1 per row.  Returns (rows, LUT multiplicities indexed by input - lo)."""
+    inp = np.asarray(inp, np.int64)
+    n = len(inp)
+    out = np.rint(_LUT_FN[name](inp / SCALE) * SCALE).astype(np.int64)
+    cols = _ids(n, node, input_id) + [to_m31(inp), to_m31(out)]
+    cols += [np.full(n, m % P) for m in mults] + [np.ones(n, dtype=np.int64)]
+    rows = np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+    return rows, np.bincount(inp - lo)
+
+
+def lut_lookup_rows(multiplicities, lut_len: int) -> np.ndarray:
+    """`SinLookup` & co. trace table: one multiplicity per LUT row (zero on the LUT's padding rows)."""
+    m = np.zeros(lut_len, dtype=np.int64)
+    m[:len(multiplicities)] = multiplicities
+    return m.reshape(-1, 1).astype(np.uint32)
+
+
+def activation_graph(n: int, seed: int = 42, names=("sin", "exp2", "log2")):
+    """y = f(a) for each LUT function in `names`, each on its own fresh input tensor.  Returns
+    (tables, luts): the trace tables in `gen_trace` order and the LUT columns the settings carry."""
+    rng = np.random.default_rng(seed)
+    ranges = {"sin": (-4 * SCALE, 4 * SCALE), "exp2": (-2 * SCALE, 2 * SCALE), "log2": (1, 4 * SCALE)}
+    tables, luts, inputs = [], {}, []
+    for t, name in enumerate(names):
+        lo, hi = ranges[name]
+        a = rng.integers(lo, hi + 1, size=n)
+        rows, counts = unary_lut_rows(name, a, lo, node=10 + t, input_id=t, mults=(-1, 0))
+        luts[name] = make_lut(name, lo, hi)
+        kind, lookup_kind = _LUT_KINDS[name]
+        tables += [(kind, rows), (lookup_kind, lut_lookup_rows(counts, len(luts[name][0])))]
+        inputs.append(inputs_rows(a, t, 1))
+    tables.append((KIND_INPUTS, np.concatenate(inputs)))
+    return sorted(tables, key=lambda kt: kt[0]), luts
+
+
 def less_than_rows(lhs, rhs, node=2, lhs_id=0, rhs_id=1, mults=(-1, -1, 0)):
     """`LuminairLessThan::process_trace` (crates/graph/src/op/prim.rs:1203-1295): out = 1.0 if lhs < rhs,
     diff = rhs - lhs (+ 2^31-1 when borrow), split into four 8-bit limbs that are range-checked.

@@ -69,14 +69,17 @@ N_KINDS = 17
 N_KINDS_KAT = 8
 
 
-ELEMS_NODE, ELEMS_RANGE_CHECK = 0, 1   # relation!(NodeElements, 2) / relation!(RangeCheckLookupElements, 1)
+# relation element sets; draw order is node, sin, exp2, log2, range_check (components/mod.rs:227-235,
+# lookups/mod.rs:44-51)
+ELEMS_NODE, ELEMS_RANGE_CHECK, ELEMS_SIN, ELEMS_EXP2, ELEMS_LOG2 = 0, 1, 2, 3, 4
 
 
 @dataclass(frozen=True)
 class Rel:
-    """One `add_to_relation` entry: multiplicity column, value column, optional tensor-id column
-    (None for width-1 relations), the element set it is combined with, numerator sign, and
-    whether `val` indexes the component's preprocessed columns instead of its main columns."""
+    """One `add_to_relation` entry: multiplicity column, first value column, optional second value
+    column (tensor id for node relations, LUT output for LUT relations; None for width-1 relations),
+    the element set it is combined with, numerator sign, and whether `val`/`id` index the
+    component's preprocessed columns instead of its main columns."""
     mult: int
     val: int
     id: Optional[int] = None
@@ -93,7 +96,7 @@ class Component:
     padding: Tuple[int, ...]
     local: Callable[[Sequence], List]            # cols -> list of constraint values
     relations: Tuple                             # Rel entries (legacy form (mult,(val,id)) is converted)
-    pre_cols: Tuple[Tuple[str, int], ...] = ()   # preprocessed columns used: (id, log_size)
+    pre_cols: Tuple[str, ...] = ()               # ids of the preprocessed (tree 0) columns it reads
 
     def __post_init__(self):
         self.relations = tuple(r if isinstance(r, Rel) else Rel(r[0], r[1][0], r[1][1]) for r in self.relations)
@@ -239,21 +242,59 @@ RANGE_CHECK_LOG = 8
 RANGE_CHECK_COL_ID = "range_check_8_column_0"
 RANGE_CHECK_LOOKUP = Component("range_check_lookup", KIND_RANGE_CHECK_LOOKUP, 1, (0,), lambda c: [],
                                (Rel(0, 0, None, ELEMS_RANGE_CHECK, neg=True, pre=True),),
-                               pre_cols=((RANGE_CHECK_COL_ID, RANGE_CHECK_LOG),))
+                               pre_cols=(RANGE_CHECK_COL_ID,))
+
+
+def _unary_lut_local(c):
+    """Sin / Exp2 / Log2 (`sin/component.rs:50-122`): only the boolean + transition constraints; the
+    function value is enforced by the LUT relation (lookup_mult, [input, out])."""
+    (node, in_id, idx, is_last, n_node, n_in, n_idx, _inp, _out, _im, _om, _lm) = c
+    not_last = 1 - is_last
+    return [is_last * (is_last - 1)] + _transition(not_last, [(n_node, node), (n_in, in_id)], n_idx, idx)
+
+
+def _unary_lut(name, kind, elems):
+    return Component(name, kind, 12, _pad(12, 3), _unary_lut_local,
+                     (Rel(9, 7, 1), Rel(10, 8, 0), Rel(11, 7, 8, elems)))
+
+
+def _lut_lookup(name, kind, elems, prefix):
+    """`lookups/sin/component.rs:40-59`: multiplicity column + two preprocessed LUT columns,
+    relation (-multiplicity, [lut_0, lut_1])."""
+    return Component(name, kind, 1, (0,), lambda c: [], (Rel(0, 0, 1, elems, neg=True, pre=True),),
+                     pre_cols=(prefix + "_lut_0", prefix + "_lut_1"))
+
+
+SIN = _unary_lut("sin", KIND_SIN, ELEMS_SIN)
+EXP2 = _unary_lut("exp2", KIND_EXP2, ELEMS_EXP2)
+LOG2 = _unary_lut("log2", KIND_LOG2, ELEMS_LOG2)
+SIN_LOOKUP = _lut_lookup("sin_lookup", KIND_SIN_LOOKUP, ELEMS_SIN, "sin")
+EXP2_LOOKUP = _lut_lookup("exp2_lookup", KIND_EXP2_LOOKUP, ELEMS_EXP2, "exp2")
+LOG2_LOOKUP = _lut_lookup("log2_lookup", KIND_LOG2_LOOKUP, ELEMS_LOG2, "log2")
+# tree-0 column order before the size sort (lookups_to_preprocessed_column, preprocessed.rs:157-179)
+PREPROCESSED_ORDER = ("sin_lut_0", "sin_lut_1", "exp2_lut_0", "exp2_lut_1", "log2_lut_0", "log2_lut_1",
+                      RANGE_CHECK_COL_ID)
 
 # sqrt/{table.rs:178-190,component.rs}, rem/{table.rs:203-218,component.rs:60-110}: the out relation of Rem carries `rem`
 SQRT = Component("sqrt", KIND_SQRT, 13, _pad(13, 3), _sqrt_local, ((11, (7, 1)), (12, (8, 0))))
 REM = Component("rem", KIND_REM, 16, _pad(16, 4), _rem_local, ((13, (9, 1)), (14, (10, 2)), (15, (11, 0))))
 
 COMPONENTS = {c.kind: c for c in (ADD, MUL, RECIP, INPUTS, SUM_REDUCE, MAX_REDUCE, CONTIGUOUS, LESS_THAN,
-                                  RANGE_CHECK_LOOKUP, SQRT, REM)}
+                                  RANGE_CHECK_LOOKUP, SQRT, REM, SIN, EXP2, LOG2, SIN_LOOKUP, EXP2_LOOKUP,
+                                  LOG2_LOOKUP)}
 
 
-def preprocessed_column(col_id: str, log_size: int) -> np.ndarray:
-    """`RangeCheckPreProcessed::gen_column` (crates/air/src/preprocessed.rs:289-296): row r holds r."""
+def preprocessed_column(col_id: str, luts) -> np.ndarray:
+    """Tree-0 column by id.  The range-check column is `RangeCheckPreProcessed::gen_column`
+    (crates/air/src/preprocessed.rs:289-296: row r holds r); the sin/exp2/log2 LUT columns
+    (`:351-383,434-466,517-549`, generated with f64 math on the reference's host side) are inputs:
+    `luts` maps "sin"/"exp2"/"log2" to (col0, col1) arrays."""
     if col_id == RANGE_CHECK_COL_ID:
-        return np.arange(1 << log_size, dtype=U64)
-    raise ValueError("unknown preprocessed column " + col_id)
+        return np.arange(1 << RANGE_CHECK_LOG, dtype=U64)
+    name, _, idx = col_id.rpartition("_lut_")
+    if luts and name in luts:
+        return np.asarray(luts[name][int(idx)], dtype=U64)
+    raise ValueError("missing preprocessed column " + col_id)
 
 
 def pad_table(comp: Component, rows: np.ndarray) -> np.ndarray:

@@ -218,8 +218,7 @@ void orc_logup_prefix(u32* col4, long n, const int64_t* order, const u32 shift[4
 
 /* ---------------------------------------------------------------------------------------------
  * Constraint quotients of one component on its eval domain (Appendix A.7).
- * kind: 0 Add, 1 Mul, 2 Recip, 5 SumReduce, 6 MaxReduce, 13 LessThan, 14 RangeCheckLookup, 15 Inputs,
- * 16 Contiguous.  Relations are given by eval-domain column pointers (value, optional id, multiplicity)
+ * kind: TraceTable variant index (all 17).  Relations are given by eval-domain column pointers (value, optional id, multiplicity)
  * with their element set (z, alpha) and numerator sign.  main: n_cols columns of E words; inter: 4*n_rel columns;
  * prev_idx[s] = storage index of the previous trace row of s; coeff: alpha powers (QM31) in
  * constraint order; zinv[s]: 1/Z per row; out: 4 x E (+= when accumulate).
@@ -266,8 +265,8 @@ static int local_constraints(int kind, const u32* c, u32* out) {
     out[k++] = mmul(nl, msub(c[6], c[1]));
     out[k++] = mmul(nl, msub(c[7], c[2]));
     out[k++] = mmul(nl, msub(msub(c[8], c[3]), 1));
-  } else if (kind == 14) {
-    /* RangeCheckLookup: no local constraints */
+  } else if (kind == 14 || kind == 4 || kind == 10 || kind == 12) {
+    /* RangeCheckLookup / SinLookup / Exp2Lookup / Log2Lookup: no local constraints */
   } else if (kind == 13) { /* LessThan, less_than/component.rs:48-185 */
     u32 is_last = c[4], nl = msub(1, is_last), borrow = c[13];
     out[k++] = mmul(is_last, msub(is_last, 1));
@@ -282,7 +281,7 @@ static int local_constraints(int kind, const u32* c, u32* out) {
     out[k++] = mmul(nl, msub(c[6], c[1]));
     out[k++] = mmul(nl, msub(c[7], c[2]));
     out[k++] = mmul(nl, msub(msub(c[8], c[3]), 1));
-  } else { /* 5 SumReduce, 6 MaxReduce, 16 Contiguous: shared id/idx prefix, columns 0..6 */
+  } else { /* 5 SumReduce, 6 MaxReduce, 16 Contiguous, 3 Sin, 9 Exp2, 11 Log2: shared id/idx prefix, columns 0..6 */
     u32 is_last = c[3], nl = msub(1, is_last);
     out[k++] = mmul(is_last, msub(is_last, 1));
     if (kind == 5) {

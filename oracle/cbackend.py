@@ -141,7 +141,8 @@ class CKernels:
         PK = C.c_void_p * k
         keep = [np.ascontiguousarray(p, dtype=U32) for p in pre_list]
         val = PK(*[(keep[r.val] if r.pre else main2d[r.val]).ctypes.data for r in comp.relations])
-        idp = PK(*[(main2d[r.id].ctypes.data if r.id is not None else None) for r in comp.relations])
+        idp = PK(*[((keep[r.id] if r.pre else main2d[r.id]).ctypes.data if r.id is not None else None)
+                   for r in comp.relations])
         mult = PK(*[main2d[r.mult].ctypes.data for r in comp.relations])
         zs = np.array([elems[r.elems][0].v for r in comp.relations], dtype=U32).reshape(-1)
         als = np.array([elems[r.elems][1].v for r in comp.relations], dtype=U32).reshape(-1)

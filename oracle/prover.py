@@ -67,9 +67,10 @@ def combine(z: QM31, alpha: QM31, v0: np.ndarray, v1: Optional[np.ndarray]) -> n
 
 
 def rel_operands(rel, main_cols, pre_cols):
-    """(value vector, id vector or None, numerator vector) of one relation entry."""
-    val = pre_cols[rel.val] if rel.pre else main_cols[rel.val]
-    idv = main_cols[rel.id] if rel.id is not None else None
+    """(value vector, second value vector or None, numerator vector) of one relation entry."""
+    src = pre_cols if rel.pre else main_cols
+    val = src[rel.val]
+    idv = src[rel.id] if rel.id is not None else None
     mult = main_cols[rel.mult]
     if rel.neg:
         mult = (U64(P) - np.asarray(mult, dtype=U64)) % U64(P)
@@ -281,6 +282,14 @@ def draw_queries(channel: Blake2sChannel, log_domain_size: int, n_queries: int) 
                 return sorted(qs)
 
 
+def relation_elements(node, lut_draws):
+    """Element sets indexed by air.ELEMS_*: node, range_check, sin, exp2, log2.  HEAD draws sin, exp2,
+    log2, range_check after NodeElements; the KAT era drew a single LUT relation (sin)."""
+    if len(lut_draws) == 4:
+        return [node, lut_draws[3], lut_draws[0], lut_draws[1], lut_draws[2]]
+    return [node, None, lut_draws[0], None, None]
+
+
 # ----------------------------------------------------------------------------- kernel sets
 class NumpyKernels:
     """The per-row work of the prover as vectorised numpy (the KAT-pinned restatement).
@@ -371,7 +380,7 @@ def claim_slots(variant: ProtocolVariant) -> int:
 
 
 def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfig(),
-          variant: ProtocolVariant = ProtocolVariant.KAT, want_trace: bool = False, kernels=None):
+          variant: ProtocolVariant = ProtocolVariant.KAT, want_trace: bool = False, kernels=None, luts=None):
     """tables: [(kind, AoS rows (n_rows, n_cols) of canonical M31)] in pie order.
 
     Returns LuminairProof (and a ProverTrace if want_trace)."""
@@ -383,14 +392,17 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
 
     # PHASE 0: preprocessed trace (prover.rs:54-59): the LUT columns the present components use,
     # sorted by log size descending (PreProcessedTrace::new); empty for LUT-free graphs
-    pre_ids: List[Tuple[str, int]] = []
+    used = set()
     for kind, _ in tables:
         if kind in COMPONENTS:
-            for pc in COMPONENTS[kind].pre_cols:
-                if pc not in pre_ids:
-                    pre_ids.append(pc)
-    pre_ids.sort(key=lambda pc: -pc[1])
-    pre_evals = [air.preprocessed_column(cid, ls) for cid, ls in pre_ids]
+            used.update(COMPONENTS[kind].pre_cols)
+    pre_ids = [cid for cid in air.PREPROCESSED_ORDER if cid in used]
+    try:
+        pre_by_id = {cid: air.preprocessed_column(cid, luts) for cid in pre_ids}
+    except ValueError as e:
+        raise ProvingError(str(e)) from e
+    pre_ids.sort(key=lambda cid: -len(pre_by_id[cid]))          # PreProcessedTrace::new: stable, size desc
+    pre_evals = [pre_by_id[cid] for cid in pre_ids]
     tree0 = commit_evals(pre_evals, lb, K) if pre_evals else CommittedTree([], lb, K)
     channel.mix_root(tree0.root())
     tr.digests["root0"] = channel.digest
@@ -431,8 +443,8 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     z, alpha_rel = channel.draw_felts(2)          # NodeElements (relation!(NodeElements, 2))
     # LookupElements::draw (lookups/mod.rs:44-51): KAT era 1 LUT relation; HEAD: sin, exp2, log2, range_check
     n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
-    lut_draws = [channel.draw_felts(2) for _ in range(n_lut_rel)]
-    elems = [(z, alpha_rel), tuple(lut_draws[3]) if n_lut_rel == 4 else None]
+    lut_draws = [tuple(channel.draw_felts(2)) for _ in range(n_lut_rel)]
+    elems = relation_elements((z, alpha_rel), lut_draws)
     tr.z, tr.alpha_rel = z, alpha_rel
     inter_cols: List[np.ndarray] = []
     iclaim: List[Optional[QM31]] = [None] * n_slots
@@ -442,9 +454,11 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         if claim[kind] is None:
             continue
         comp, cols = seen[kind]
-        if any(r.elems == air.ELEMS_RANGE_CHECK for r in comp.relations) and elems[1] is None:
-            raise ProvingError("component needs RangeCheckLookupElements (PINNED variant only)")
+        if any(elems[r.elems] is None for r in comp.relations):
+            raise ProvingError("component needs relation elements this protocol variant does not draw")
         pre_idx = tuple(pre_ids.index(pc) for pc in comp.pre_cols)
+        if any(len(pre_evals[i]) != cols.shape[1] for i in pre_idx):
+            raise ProvingError("lookup table rows must match the LUT column size")
         base_cols, claimed = K.gen_interaction_trace(comp, cols, elems, [pre_evals[i] for i in pre_idx])
         iclaim[kind] = claimed
         # TraceLocationAllocator hands out spans in component (struct) order

@@ -39,9 +39,10 @@ def eval_composition_at_point(instances, sampled_values, oods, elems, comp_alpha
         for j, rel in enumerate(comp.relations):
             cols = [sampled_values[2][ci.inter_span[0] + 4 * j + t] for t in range(4)]
             z, alpha_rel = elems[rel.elems]
-            den = (pre[rel.val] if rel.pre else main[rel.val]) - z
+            src = pre if rel.pre else main
+            den = src[rel.val] - z
             if rel.id is not None:
-                den = den + alpha_rel * main[rel.id]
+                den = den + alpha_rel * src[rel.id]
             num = -main[rel.mult] if rel.neg else main[rel.mult]
             if j < n_rel - 1:
                 cur = QM31.from_partial_evals([c[0] for c in cols])
@@ -62,13 +63,14 @@ def eval_composition_at_point(instances, sampled_values, oods, elems, comp_alpha
 
 
 def _preprocessed_ids(claim):
-    """Tree-0 layout implied by the claim: the LUT columns of the present components, log size desc."""
-    pre_ids = []
+    """Tree-0 layout implied by the claim: [(column id, log size)] of the LUT columns the present lookup
+    components read (a LUT column has the log size of its lookup component), PreProcessedTrace order."""
+    size = {}
     for kind, ls in enumerate(claim):
         if ls is not None:
             for pc in COMPONENTS[kind].pre_cols:
-                if pc not in pre_ids:
-                    pre_ids.append(pc)
+                size[pc] = ls
+    pre_ids = [(cid, size[cid]) for cid in air.PREPROCESSED_ORDER if cid in size]
     pre_ids.sort(key=lambda pc: -pc[1])
     return pre_ids
 
@@ -84,7 +86,7 @@ def _instances_from_claim(claim, iclaim):
         comp = COMPONENTS[kind]
         ni = 4 * len(comp.relations)
         inst.append(ComponentInstance(comp, ls, (m_off, m_off + comp.n_cols), (i_off, i_off + ni), iclaim[kind],
-                                      tuple(pre_ids.index(pc) for pc in comp.pre_cols)))
+                                      tuple([cid for cid, _ in pre_ids].index(pc) for pc in comp.pre_cols)))
         m_off += comp.n_cols
         i_off += ni
     return inst
@@ -112,8 +114,9 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
     channel.mix_root(s.commitments[1])
     z, alpha_rel = channel.draw_felts(2)
     n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
-    lut_draws = [channel.draw_felts(2) for _ in range(n_lut_rel)]
-    elems = [(z, alpha_rel), tuple(lut_draws[3]) if n_lut_rel == 4 else None]
+    from .prover import relation_elements
+    lut_draws = [tuple(channel.draw_felts(2)) for _ in range(n_lut_rel)]
+    elems = relation_elements((z, alpha_rel), lut_draws)
     # log_sum_valid (verifier.rs:97-99)
     tot = ZERO
     for c in proof.interaction_claim:

@@ -19,7 +19,7 @@ def test_header_symbols_are_exported(root, hip_lib_path):
         assert hasattr(lib, name), "symbol %s declared in the header but not exported" % name
     assert sorted(backend.EXPORTS) == declared
     blib = backend.Library(hip_lib_path)
-    assert [blib.kind_columns(k) for k in (0, 1, 2, 15, 3)] == [15, 16, 13, 7, 0]
+    assert [blib.kind_columns(k) for k in range(18)] == [15, 16, 13, 12, 1, 14, 15, 13, 16, 12, 1, 12, 1, 22, 1, 7, 11, 0]
     cfg = blib.default_config()
     assert (cfg.pow_bits, cfg.log_blowup, cfg.log_last_layer, cfg.n_queries) == (5, 1, 0, 3)
 

@@ -55,8 +55,11 @@ def test_emu_error_codes(emu_ctx):
     with pytest.raises(backend.LuminairBackendError) as e:
         emu_ctx.prove_tables([(0, bad, len(bad))])
     assert e.value.code == backend.ERR_CONSTRAINTS
-    with pytest.raises(backend.LuminairBackendError) as e:   # Sin component is out of scope
-        emu_ctx.prove_tables([(3, np.zeros((4, 12), np.uint32), 4)])
+    with pytest.raises(backend.LuminairBackendError) as e:   # no such TraceTable variant
+        emu_ctx.prove_tables([(17, np.zeros((4, 12), np.uint32), 4)])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    with pytest.raises(backend.LuminairBackendError) as e:   # SinLookup table without its LUT columns in the settings
+        emu_ctx.prove_tables([(4, np.zeros((16, 1), np.uint32), 16)])
     assert e.value.code == backend.ERR_INVALID_ARGUMENT
     with pytest.raises(backend.LuminairBackendError) as e:   # wrong table order
         t = syn.chain_graph(16, 1)
@@ -104,8 +107,26 @@ def test_emu_pinned_variant_with_inputs_component(root):
     got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs3])
     assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs3], variant=ProtocolVariant.PINNED))
     lib.verify(got, backend.VARIANT_PINNED)
-    # the KAT-variant context has no claim slot for kind 15
+    # Sin / Exp2 / Log2 + their lookup components: two-column LUTs of different sizes in tree 0 (passed in as
+    # settings data), width-2 LUT relations with three more element sets
+    tabs4, luts = syn.activation_graph(50, 8)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs4], luts)
+    assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs4], variant=ProtocolVariant.PINNED,
+                                          luts=luts))
+    lib.verify(got, backend.VARIANT_PINNED)
+    bad = [(k, r.copy()) for k, r in tabs4]
+    bad[0][1][7, 8] ^= 1                  # a sin output that is not in the LUT: logup sums no longer cancel
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in bad], luts)
+    with pytest.raises(backend.LuminairBackendError) as e:
+        lib.verify(got, backend.VARIANT_PINNED)
+    assert e.value.code == backend.ERR_INVALID_LOGUP
+    # the KAT era drew one LUT relation (sin): Sin + SinLookup fit its 8-slot claim
     kat_ctx = backend.Context(0, None, lib)
+    tabs5, luts5 = syn.activation_graph(20, 9, names=("sin",))
+    tabs5 = [t for t in tabs5 if t[0] != 15]       # no Inputs component in the KAT era
+    got = kat_ctx.prove_tables([(k, r, len(r)) for k, r in tabs5], luts5)
+    assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs5], luts=luts5))
+    # the KAT-variant context has no claim slot for kind 15
     with pytest.raises(backend.LuminairBackendError) as e:
         kat_ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
     assert e.value.code == backend.ERR_INVALID_ARGUMENT

@@ -234,6 +234,39 @@ def test_gpu_less_than_2_18_rows_equals_c_oracle_bytes(gpu_prover_pinned, c_orac
     assert _gpu_bytes(gpu_prover_pinned, tabs) == want
 
 
+@pytest.mark.parametrize("n", [50, 3000])
+def test_gpu_lut_activations_equal_oracle(gpu_prover_pinned, n):
+    """Sin / Exp2 / Log2 + SinLookup / Exp2Lookup / Log2Lookup: LUT columns handed over as settings data,
+    two-column LUTs of three different sizes in tree 0, width-2 LUT relations."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs, luts = syn.activation_graph(n, 11)
+    got = gpu_prover_pinned.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts))
+    assert got.to_bincode() == to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, luts=luts))
+    from luminair_amd import backend
+    luminair_amd.verify(got, protocol_variant=backend.VARIANT_PINNED)
+
+
+def test_gpu_lut_activations_2_18_rows_equal_c_oracle_bytes(gpu_prover_pinned, c_oracle):
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs, luts = syn.activation_graph(1 << 18, 12)
+    got = gpu_prover_pinned.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts))
+    assert got.to_bincode() == to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=c_oracle, luts=luts))
+
+
+def test_gpu_kat_era_sin_equals_oracle(gpu_prover):
+    """The KAT-era transcript drew one LUT relation (sin): Sin + SinLookup in the 8-slot claim."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs, luts = syn.activation_graph(500, 13, names=("sin",))
+    tabs = [t for t in tabs if t[0] != 15]
+    got = gpu_prover.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts))
+    assert got.to_bincode() == to_bincode(prove(tabs, luts=luts))
+
+
 def test_gpu_proofs_pass_the_product_verifier(gpu_prover, gpu_prover_pinned, kat_bytes):
     """prove -> verify round trip through the C ABI only (the reference's own test strategy,
     crates/graph/src/tests/mod.rs:26-44), plus rejection of a tampered proof."""

@@ -35,6 +35,12 @@ def test_c_oracle_equals_numpy_oracle(ck, name, tabs, variant):
     assert a == b, name
 
 
+def test_c_oracle_equals_numpy_oracle_on_lut_activations(ck):
+    tabs, luts = syn.activation_graph(70, 5)
+    a = to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, luts=luts))
+    assert a == to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=ck, luts=luts))
+
+
 def test_c_kernels_individually(ck):
     from oracle import fft
     from oracle.field import P, QM31

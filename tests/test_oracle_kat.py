@@ -210,3 +210,38 @@ def test_oracle_less_than_with_range_check_lut():
     # range-check relations need the HEAD relation draws
     with pytest.raises(ProvingError):
         prove([(k, r.astype(np.uint64)) for k, r in tabs[:2]], variant=ProtocolVariant.KAT)
+
+
+def test_oracle_lut_activations():
+    """Sin / Exp2 / Log2 with their lookup components (sin/component.rs:50-122, lookups/sin/component.rs:40-59):
+    tree 0 holds the three two-column LUTs (different sizes, size-descending order), the LUT relations are
+    width 2 with their own element sets, logup sums cancel against Inputs."""
+    from oracle.prover import ProvingError
+    tabs, luts = syn.activation_graph(40, 3)
+    assert [k for k, _ in tabs] == [3, 4, 9, 10, 11, 12, 15]
+    proof = prove(tabs, variant=ProtocolVariant.PINNED, luts=luts)
+    assert [(k, c) for k, c in enumerate(proof.claim) if c is not None] == \
+        [(3, 6), (4, 16), (9, 6), (10, 15), (11, 6), (12, 14), (15, 7)]
+    assert [len(t) for t in proof.proof.sampled_values] == [6, 3 * 12 + 3 + 7, 3 * 12 + 3 * 4 + 4, 4]
+    verify(from_bincode(to_bincode(proof), 17), ProtocolVariant.PINNED)
+    # an output that is not the LUT's value for its input: the AIR holds (no local constraint ties out to
+    # input), the logup sum does not cancel
+    rows = tabs[0][1].copy()
+    rows[5, 8] ^= 1
+    p2 = prove([(3, rows)] + tabs[1:], variant=ProtocolVariant.PINNED, luts=luts)
+    with pytest.raises(VerificationError, match="InvalidLogUp"):
+        verify(p2, ProtocolVariant.PINNED)
+    # the LUT columns are inputs of the proof: omitted or mis-sized ones are rejected
+    with pytest.raises(ProvingError):
+        prove(tabs, variant=ProtocolVariant.PINNED, luts={k: v for k, v in luts.items() if k != "exp2"})
+    with pytest.raises(ProvingError):
+        prove(tabs, variant=ProtocolVariant.PINNED, luts=dict(luts, sin=(luts["sin"][0][:1 << 15], luts["sin"][1][:1 << 15])))
+    # KAT era: a single LUT relation draw (sin); exp2 needs the HEAD draws
+    lo, hi = -2 * 4096, 2 * 4096
+    a = np.random.default_rng(4).integers(lo, hi + 1, size=20)
+    rows, counts = syn.unary_lut_rows("sin", a, lo, mults=(0, 0))
+    lut = syn.make_lut("sin", lo, hi)
+    kat_tabs = [(3, rows), (4, syn.lut_lookup_rows(counts, len(lut[0])))]
+    verify(prove(kat_tabs, luts={"sin": lut}), ProtocolVariant.KAT)
+    with pytest.raises(ProvingError):
+        prove([t for t in tabs if t[0] in (9, 10)], luts=luts)
