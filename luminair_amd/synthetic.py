@@ -278,6 +278,101 @@ def linear_layer(n_out: int, dim: int, seed: int = 42, with_max: bool = False) -
     return tabs
 
 
+def config5_linear_layers(n_layers: int = 256, n_out: int = 128, dim: int = 256, seed: int = 42):
+    """BASELINE config 5: `n_layers` x (Mul n-row + SumReduce n-row + Add) with n = n_out*dim, laid into the three
+    per-kind tables (each layer keeps its own node ids; is_last closes every node's block).  Defaults: 256 layers
+    of 128x256 => Mul 2^23 + SumReduce 2^23 + Add 2^15 rows (2^24 total).  KAT-era multiplicities:
+    initializers are consumed with multiplicity 0, the Mul -> SumReduce -> Add chain cancels."""
+    rng = np.random.default_rng(seed)
+    adds, muls, sums = [], [], []
+    for l in range(n_layers):
+        base = 10 * l
+        x = rng.integers(0, 2048, size=(n_out, dim))
+        w = rng.integers(0, 2048, size=(n_out, dim))
+        b = rng.integers(-2048, 2048, size=n_out)
+        prod = (x * w) >> 12
+        y1 = prod.sum(axis=1)
+        adds.append(add_rows(y1, b, node=base + 5, lhs_id=base + 4, rhs_id=base + 9, mults=(-1, 0, 0)))
+        muls.append(mul_rows(x.reshape(-1), w.reshape(-1), node=base + 3, lhs_id=base + 7, rhs_id=base + 8,
+                             mults=(0, 0, 1)))
+        sums.append(sum_reduce_rows(prod, node=base + 4, input_id=base + 3, input_mult=-1, out_mult=1))
+    return [(KIND_ADD, np.concatenate(adds)), (KIND_MUL, np.concatenate(muls)), (KIND_SUM_REDUCE, np.concatenate(sums))]
+
+
+def config4_black_scholes_shape(batch: int = 1, seed: int = 42):
+    """BASELINE config 4: the black-schole-nn *shape* (2 -> 64 -> 64 -> 1 MLP with tanh,
+    examples/black-schole-nn/src/main.rs:61-103) with seeded synthetic weights, lowered the way SURVEY.md §8d
+    describes: Linear = Mul + SumReduce + Add(bias); tanh(x) = 2*sigmoid(2x) - 1 with
+    sigmoid(t) = Recip(1 + Exp2(-t/ln 2)).  Every tensor op is one node; multiplicities follow the KAT-era rule
+    (initializers 0, each intermediate yielded once and consumed once), the Exp2 LUT relation is balanced by the
+    Exp2Lookup table.  Returns (tables, luts); needs the PINNED variant (Exp2 has no KAT-era claim slot)."""
+    rng = np.random.default_rng(seed)
+    T = {k: [] for k in (KIND_ADD, KIND_MUL, KIND_RECIP, KIND_SUM_REDUCE, 9)}
+    lo, hi = -8 * SCALE, 8 * SCALE
+    counts = np.zeros(hi - lo + 1, dtype=np.int64)
+    node = [100]
+
+    def new_node():
+        node[0] += 1
+        return node[0]
+
+    def linear(x, x_id, n_in, n_out, consume):
+        """x: (batch, n_in) -> (batch, n_out); returns (values, node id)."""
+        w = rng.integers(-1024, 1024, size=(n_out, n_in))
+        b = rng.integers(-512, 512, size=n_out)
+        xe = np.broadcast_to(x[:, None, :], (len(x), n_out, n_in)).reshape(-1, n_in)
+        we = np.broadcast_to(w[None], (len(x), n_out, n_in)).reshape(-1, n_in)
+        m_id, s_id, a_id = new_node(), new_node(), new_node()
+        prod = (xe * we) >> 12
+        # each x element is consumed n_out times by the expanded Mul; its producer yields it n_out times
+        T[KIND_MUL].append(mul_rows(xe.reshape(-1), we.reshape(-1), node=m_id, lhs_id=x_id, rhs_id=new_node(),
+                                    mults=(-1 if consume else 0, 0, 1)))
+        T[KIND_SUM_REDUCE].append(sum_reduce_rows(prod, node=s_id, input_id=m_id, input_mult=-1, out_mult=1))
+        y1 = prod.sum(axis=1)
+        be = np.tile(b, len(x))
+        return y1, be, s_id, a_id, n_out
+
+    def tanh(v, v_id, fanout):
+        """elementwise on a flat vector; the result is yielded `fanout` times."""
+        n = len(v)
+        c = int(round(-2.0 / np.log(2.0) * SCALE))
+        ids = [new_node() for _ in range(6)]
+        t = (v * c) >> 12
+        T[KIND_MUL].append(mul_rows(v, np.full(n, c), node=ids[0], lhs_id=v_id, rhs_id=new_node(), mults=(-1, 0, 1)))
+        rows, cnt = unary_lut_rows("exp2", np.clip(t, lo, hi), lo, node=ids[1], input_id=ids[0], mults=(-1, 1))
+        assert np.all((t >= lo) & (t <= hi)), "activation outside the exp2 LUT range"
+        counts[:len(cnt)] += cnt
+        T[9].append(rows)
+        e = rows[:, 8].astype(np.int64)
+        T[KIND_ADD].append(add_rows(e, np.full(n, SCALE), node=ids[2], lhs_id=ids[1], rhs_id=new_node(), mults=(-1, 0, 1)))
+        s = e + SCALE
+        T[KIND_RECIP].append(recip_rows(s, node=ids[3], input_id=ids[2], mults=(-1, 1)))
+        r = (SCALE * SCALE) // s
+        T[KIND_MUL].append(mul_rows(r, np.full(n, 2 * SCALE), node=ids[4], lhs_id=ids[3], rhs_id=new_node(), mults=(-1, 0, 1)))
+        u = (r * 2 * SCALE) >> 12
+        T[KIND_ADD].append(add_rows(u, np.full(n, -SCALE), node=ids[5], lhs_id=ids[4], rhs_id=new_node(),
+                                    mults=(-1, 0, fanout)))
+        return u - SCALE, ids[5]
+
+    x = rng.integers(-2048, 2048, size=(batch, 2))
+    h, h_id, consume = x, 1, False
+    for n_in, n_out, act in ((2, 64, True), (64, 64, True), (64, 1, False)):
+        y1, be, s_id, a_id, _ = linear(h, h_id, n_in, n_out, consume)
+        fan = {64: 64, 1: 1}[n_out] if act else 0
+        # bias add yields its output once to the activation's first Mul (or 0 times for the network output)
+        T[KIND_ADD].append(add_rows(y1, be, node=a_id, lhs_id=s_id, rhs_id=new_node(), mults=(-1, 0, 1 if act else 0)))
+        y = y1 + be
+        if act:
+            nxt = {2: 64, 64: 1}[n_in]       # consumers of each activation output = next layer's n_out
+            v, h_id = tanh(y, a_id, nxt)
+            h = v.reshape(batch, n_out)
+            consume = True
+    lut = make_lut("exp2", lo, hi)
+    tables = [(k, np.concatenate(v)) for k, v in T.items()]
+    tables.append((10, lut_lookup_rows(counts, len(lut[0]))))
+    return sorted(tables, key=lambda kt: kt[0]), {"exp2": lut}
+
+
 def config2_add_only(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
     """BASELINE config 2a: one Add table, all multiplicities 0 (logup sums are trivially 0)."""
     rng = np.random.default_rng(seed)

@@ -40,6 +40,7 @@ def test_emu_reproduces_kat(emu_ctx, kat_bytes):
     ("mixed-sizes", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])]),
     ("single-row", syn.chain_graph(1, 6)),
     ("linear-layer+max", syn.linear_layer(20, 7, 2, True)),
+    ("config5-3-layers", syn.config5_linear_layers(3, 4, 5, 8)),
 ])
 def test_emu_matches_oracle(emu_ctx, name, tabs):
     got, want = _both(emu_ctx, tabs)

@@ -41,6 +41,13 @@ def test_c_oracle_equals_numpy_oracle_on_lut_activations(ck):
     assert a == to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=ck, luts=luts))
 
 
+def test_c_oracle_config4_black_scholes_shape_verifies(ck):
+    from oracle.verifier import verify
+    tabs, luts = syn.config4_black_scholes_shape()
+    assert [k for k, _ in tabs] == [0, 1, 2, 5, 9, 10]
+    verify(prove(tabs, variant=ProtocolVariant.PINNED, kernels=ck, luts=luts), ProtocolVariant.PINNED)
+
+
 def test_c_kernels_individually(ck):
     from oracle import fft
     from oracle.field import P, QM31
