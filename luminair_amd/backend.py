@@ -60,7 +60,8 @@ class LmnTimings(C.Structure):
 EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
-           "lmn_op_fft_selftest"]
+           "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
+           "lmn_op_grind"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -101,6 +102,12 @@ class Library:
                                            C.c_void_p]
         lib.lmn_op_eval_at_point.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.lmn_op_fft_selftest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.lmn_op_accumulate_quotients.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p]
+        lib.lmn_op_fold_line.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lmn_op_fold_circle_into_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.lmn_op_grind.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
 
     def default_config(self) -> LmnConfig:
         cfg = LmnConfig()
@@ -109,6 +116,14 @@ class Library:
 
     def kind_columns(self, kind: int) -> int:
         return int(self.lib.lmn_kind_columns(kind))
+
+    def grind(self, digest: bytes, pow_bits: int, variant: int = VARIANT_KAT) -> int:
+        """GrindOps::grind on a 32-byte channel digest."""
+        out = C.c_uint64()
+        rc = self.lib.lmn_op_grind(bytes(digest), pow_bits, variant, C.byref(out))
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, self.lib.lmn_strerror(rc).decode())
+        return int(out.value)
 
     def verify(self, proof: bytes, variant: int = VARIANT_KAT) -> None:
         """`verify(proof, settings)` on the host; raises LuminairBackendError on rejection."""
@@ -244,6 +259,42 @@ class Context:
         out = (C.c_uint32 * 4)()
         self._check(self.lib.lib.lmn_op_eval_at_point(self.handle, a.ctypes.data, len(a).bit_length() - 1, pt, out))
         return tuple(int(v) for v in out)
+
+    def accumulate_quotients(self, cols, samples, points, alpha) -> np.ndarray:
+        """QuotientOps::accumulate_quotients for equal-size columns.  cols: [2^k uint32 arrays];
+        samples: [(col index, point index, (4 words))] in (column, mask position) order; points: [(8 words)];
+        alpha: 4 words.  Returns the 4 coordinate columns, shape (4, 2^k)."""
+        keep = [np.ascontiguousarray(c, dtype=np.uint32) for c in cols]
+        L = len(keep[0])
+        ptrs = (C.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+        sc = np.array([s[0] for s in samples], dtype=np.uint32)
+        sp = np.array([s[1] for s in samples], dtype=np.uint32)
+        sv = np.array([list(s[2]) for s in samples], dtype=np.uint32).reshape(-1)
+        pts = np.array([list(p) for p in points], dtype=np.uint32).reshape(-1)
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        out = np.empty((4, L), dtype=np.uint32)
+        self._check(self.lib.lib.lmn_op_accumulate_quotients(
+            self.handle, L.bit_length() - 1, ptrs, len(keep), sc.ctypes.data, sp.ctypes.data, sv.ctypes.data, len(samples),
+            pts.ctypes.data, len(points), al, out.ctypes.data))
+        return out
+
+    def fold_line(self, src: np.ndarray, alpha) -> np.ndarray:
+        """FriOps::fold_line on 4 coordinate columns (4, 2^k) -> (4, 2^(k-1))."""
+        a = np.ascontiguousarray(src, dtype=np.uint32)
+        L = a.shape[1]
+        out = np.empty((4, L // 2), dtype=np.uint32)
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        self._check(self.lib.lib.lmn_op_fold_line(self.handle, a.ctypes.data, L.bit_length() - 1, al, out.ctypes.data))
+        return out
+
+    def fold_circle_into_line(self, dst: np.ndarray, src: np.ndarray, alpha) -> np.ndarray:
+        """FriOps::fold_circle_into_line: returns dst * alpha^2 + fold(src)."""
+        a = np.ascontiguousarray(src, dtype=np.uint32)
+        d = np.ascontiguousarray(dst, dtype=np.uint32).copy()
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        self._check(self.lib.lib.lmn_op_fold_circle_into_line(self.handle, d.ctypes.data, a.ctypes.data,
+                                                              a.shape[1].bit_length() - 1, al))
+        return d
 
     def fft_selftest(self, log_size: int, ncols: int = 2):
         self._check(self.lib.lib.lmn_op_fft_selftest(self.handle, log_size, ncols))

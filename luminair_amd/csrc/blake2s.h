@@ -57,6 +57,73 @@ LMN_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32
   h[7] ^= v7 ^ v15;
 }
 
+// Two independent compressions interleaved statement by statement: 8 independent dependency chains per
+// half-round instead of 4, which keeps the VALU issuing when only ~2 waves share a SIMD.
+#define LMN_B2_G2(a, b, c, d, x, y, A, B, C, D, X, Y) \
+  a = a + b + (x);                                    \
+  A = A + B + (X);                                    \
+  d = b2_rotr(d ^ a, 16);                             \
+  D = b2_rotr(D ^ A, 16);                             \
+  c = c + d;                                          \
+  C = C + D;                                          \
+  b = b2_rotr(b ^ c, 12);                             \
+  B = b2_rotr(B ^ C, 12);                             \
+  a = a + b + (y);                                    \
+  A = A + B + (Y);                                    \
+  d = b2_rotr(d ^ a, 8);                              \
+  D = b2_rotr(D ^ A, 8);                              \
+  c = c + d;                                          \
+  C = C + D;                                          \
+  b = b2_rotr(b ^ c, 7);                              \
+  B = b2_rotr(B ^ C, 7);
+
+#define LMN_B2_ROUND2(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)      \
+  LMN_B2_G2(v0, v4, v8, v12, m[s0], m[s1], w0, w4, w8, w12, n[s0], n[s1])                        \
+  LMN_B2_G2(v1, v5, v9, v13, m[s2], m[s3], w1, w5, w9, w13, n[s2], n[s3])                        \
+  LMN_B2_G2(v2, v6, v10, v14, m[s4], m[s5], w2, w6, w10, w14, n[s4], n[s5])                      \
+  LMN_B2_G2(v3, v7, v11, v15, m[s6], m[s7], w3, w7, w11, w15, n[s6], n[s7])                      \
+  LMN_B2_G2(v0, v5, v10, v15, m[s8], m[s9], w0, w5, w10, w15, n[s8], n[s9])                      \
+  LMN_B2_G2(v1, v6, v11, v12, m[s10], m[s11], w1, w6, w11, w12, n[s10], n[s11])                  \
+  LMN_B2_G2(v2, v7, v8, v13, m[s12], m[s13], w2, w7, w8, w13, n[s12], n[s13])                    \
+  LMN_B2_G2(v3, v4, v9, v14, m[s14], m[s15], w3, w4, w9, w14, n[s14], n[s15])
+
+// h <- F(h, m, t, f0) and g <- F(g, n, t, f0) (same counter / finalisation flag for both)
+LMN_HD void b2_compress2(uint32_t h[8], const uint32_t m[16], uint32_t g[8], const uint32_t n[16], uint32_t t0,
+                         uint32_t f0) {
+  uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+  uint32_t w0 = g[0], w1 = g[1], w2 = g[2], w3 = g[3], w4 = g[4], w5 = g[5], w6 = g[6], w7 = g[7];
+  uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+  uint32_t w8 = 0x6A09E667u, w9 = 0xBB67AE85u, w10 = 0x3C6EF372u, w11 = 0xA54FF53Au;
+  uint32_t v12 = 0x510E527Fu ^ t0, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu ^ f0, v15 = 0x5BE0CD19u;
+  uint32_t w12 = 0x510E527Fu ^ t0, w13 = 0x9B05688Cu, w14 = 0x1F83D9ABu ^ f0, w15 = 0x5BE0CD19u;
+  LMN_B2_ROUND2(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  LMN_B2_ROUND2(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_ROUND2(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_ROUND2(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_ROUND2(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_ROUND2(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_ROUND2(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_ROUND2(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_ROUND2(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_ROUND2(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  h[0] ^= v0 ^ v8;
+  h[1] ^= v1 ^ v9;
+  h[2] ^= v2 ^ v10;
+  h[3] ^= v3 ^ v11;
+  h[4] ^= v4 ^ v12;
+  h[5] ^= v5 ^ v13;
+  h[6] ^= v6 ^ v14;
+  h[7] ^= v7 ^ v15;
+  g[0] ^= w0 ^ w8;
+  g[1] ^= w1 ^ w9;
+  g[2] ^= w2 ^ w10;
+  g[3] ^= w3 ^ w11;
+  g[4] ^= w4 ^ w12;
+  g[5] ^= w5 ^ w13;
+  g[6] ^= w6 ^ w14;
+  g[7] ^= w7 ^ w15;
+}
+
 LMN_HD void b2_init(uint32_t h[8]) {
   h[0] = 0x6A09E667u ^ 0x01010020u;
   h[1] = 0xBB67AE85u;

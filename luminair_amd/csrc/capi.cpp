@@ -168,3 +168,35 @@ int lmn_op_fft_selftest(lmn_ctx* ctx, uint32_t log_size, uint32_t ncols) {
 }
 
 }  // extern "C"
+
+int lmn_op_accumulate_quotients(lmn_ctx* ctx, uint32_t log_size, const uint32_t* const* cols, uint32_t ncols,
+                                const uint32_t* sample_col, const uint32_t* sample_point, const uint32_t* sample_values,
+                                uint32_t nsamples, const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4],
+                                uint32_t* out) {
+  if (!ctx || !cols || !sample_col || !sample_point || !sample_values || !points_xy || !alpha || !out)
+    return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] {
+    ctx->impl->op_accumulate_quotients(log_size, cols, ncols, sample_col, sample_point, sample_values, nsamples, points_xy,
+                                       npoints, alpha, out);
+  });
+}
+
+int lmn_op_fold_line(lmn_ctx* ctx, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4], uint32_t* dst) {
+  if (!ctx || !src || !alpha || !dst) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_fold(0, dst, src, log_src, alpha); });
+}
+
+int lmn_op_fold_circle_into_line(lmn_ctx* ctx, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]) {
+  if (!ctx || !src || !alpha || !dst) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_fold(1, dst, src, log_src, alpha); });
+}
+
+int lmn_op_grind(const uint8_t digest[32], uint32_t pow_bits, uint32_t protocol_variant, uint64_t* nonce_out) {
+  if (!digest || !nonce_out || pow_bits > 40 || protocol_variant > LMN_VARIANT_PINNED) return LMN_ERR_INVALID_ARGUMENT;
+  lmn::Channel ch(protocol_variant);
+  lmn::Hash32 d;
+  memcpy(d.w, digest, 32);
+  ch.set_digest(d);
+  *nonce_out = ch.grind(pow_bits);
+  return LMN_OK;
+}

@@ -88,6 +88,7 @@ class Channel {
  public:
   explicit Channel(uint32_t variant) : variant_(variant) { memset(digest_.w, 0, sizeof digest_.w); }
   const Hash32& digest() const { return digest_; }
+  void set_digest(const Hash32& d) { update(d); }
 
   void mix_root(const Hash32& root) {
     uint32_t w[16];

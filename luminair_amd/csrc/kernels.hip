@@ -451,11 +451,11 @@ LMN_D const uint32_t* merkle_col_ptr(const MerkleSegs& sg, int c, uint64_t size)
   return sg.base[3] + (uint64_t)(c - n2) * size;
 }
 
-LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                             uint32_t i, uint32_t h[8]) {
-  b2_init(h);
-  uint32_t m[16];
-  int c0 = 0;  // first column of the current block
+// First 16 message words of start-level node i: the two child hashes when the level has a `prev`
+// layer, else its first 16 columns (zero padded).  Split from the hashing so that callers can issue the
+// loads of the next node before compressing the current one.
+LMN_D void merkle_load_first(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                             uint32_t i, uint32_t m[16]) {
   if (prev) {
     const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
     uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
@@ -463,14 +463,24 @@ LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs
     m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
     m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
     m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-    if (ncols == 0) {
-      b2_compress(h, m, 64u, 0xffffffffu);
-      return;
-    }
-    b2_compress(h, m, 64u, 0u);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = k < ncols ? merkle_col_ptr(sg, k, size)[i] : 0u;
   }
+}
+
+// Hash of start-level node i given its first 16 message words (merkle_load_first).
+LMN_D void merkle_hash_from(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16], uint32_t h[8]) {
+  b2_init(h);
   const uint32_t total = (prev ? 64u : 0u) + 4u * (uint32_t)ncols;
-  uint32_t done = prev ? 64u : 0u;
+  int c0 = prev ? 0 : 16;  // first column not yet consumed
+  if (c0 >= ncols) {
+    b2_compress(h, m, total, 0xffffffffu);
+    return;
+  }
+  b2_compress(h, m, 64u, 0u);
+  uint32_t done = 64u;
   while (c0 < ncols) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -482,6 +492,13 @@ LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs
     done += 64u;
     b2_compress(h, m, last ? total : done, last ? 0xffffffffu : 0u);
   }
+}
+
+LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                             uint32_t i, uint32_t h[8]) {
+  uint32_t m[16];
+  merkle_load_first(prev, sg, ncols, size, i, m);
+  merkle_hash_from(prev, sg, ncols, size, i, m, h);
 }
 
 LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
@@ -534,10 +551,18 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   const uint32_t W0 = (t >> 6) * (64u << sub);
   uint32_t cur[8];
   uint32_t cur_idx = 0;
+  uint32_t mnext[16];
+  merkle_load_first(prev, sg, ncols, size, W0 + lane, mnext);
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
-    merkle_hash_start(prev, sg, ncols, size, node, cur);
+    // software pipeline: the next batch's loads are in flight while this batch is compressed (only ~2
+    // waves share a SIMD here, too few to hide HBM latency by occupancy alone)
+    uint32_t mcur[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mcur[k] = mnext[k];
+    if (j + 1 < per) merkle_load_first(prev, sg, ncols, size, node + 64u, mnext);
+    merkle_hash_from(prev, sg, ncols, size, node, mcur, cur);
     store_hash(outs.p[0] + (uint64_t)node * 8, cur);
     uint32_t jj = j;
     int lvl = 0;

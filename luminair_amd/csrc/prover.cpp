@@ -683,6 +683,65 @@ struct HostMarks {
   }
 };
 
+// ------------------------------------------------------------------------------------ FRI quotients
+// Host side of `accumulate_quotients` for the columns of one LDE size: ColumnSampleBatch::new_vec groups
+// the (column, point, value) samples by point in first-appearance order; per sample the line through
+// (p.y, v) and (conj p.y, conj v) gives coefficients a, b, c scaled by alpha^k.
+QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
+                                         const std::vector<std::vector<std::pair<int, QM31>>>& samples,
+                                         const std::vector<QPt>& points, QM31 quot_alpha) {
+  std::vector<int> batch_point;
+  std::vector<std::vector<std::pair<int, QM31>>> batch_cols;
+  for (size_t c = 0; c < cols.size(); ++c)
+    for (auto& sm : samples[c]) {
+      size_t b = 0;
+      while (b < batch_point.size() && batch_point[b] != sm.first) ++b;
+      if (b == batch_point.size()) {
+        batch_point.push_back(sm.first);
+        batch_cols.emplace_back();
+      }
+      batch_cols[b].push_back({(int)c, sm.second});
+    }
+  if (batch_point.size() > (size_t)QUOT_MAX_BATCH) throw LmnError(LMN_ERR_INTERNAL, "too many sample batches");
+  QuotientArgs a{};
+  a.log_size = ls;
+  a.nbatch = (int)batch_point.size();
+  std::vector<int> col_idx;
+  std::vector<QM31> coeff_c;
+  for (size_t b = 0; b < batch_point.size(); ++b) {
+    QPt pt = points[batch_point[b]];
+    a.batch_start[b] = (int)col_idx.size();
+    QM31 alpha = q_one(), A = q_zero(), B = q_zero();
+    for (auto& cv : batch_cols[b]) {
+      alpha = q_mul(alpha, quot_alpha);
+      QM31 val = cv.second;
+      QM31 la = q_sub(q_conj(val), val);
+      QM31 lc = q_sub(q_conj(pt.y), pt.y);
+      QM31 lbb = q_sub(q_mul(val, lc), q_mul(la, pt.y));
+      A = q_add(A, q_mul(alpha, la));
+      B = q_add(B, q_mul(alpha, lbb));
+      col_idx.push_back(cv.first);
+      coeff_c.push_back(q_mul(alpha, lc));
+    }
+    a.A[b] = A;
+    a.B[b] = B;
+    a.batch_coeff[b] = q_pow(quot_alpha, batch_cols[b].size());
+    a.prx[b] = {pt.x.a, pt.x.b};
+    a.pix[b] = {pt.x.c, pt.x.d};
+    a.pry[b] = {pt.y.a, pt.y.b};
+    a.piy[b] = {pt.y.c, pt.y.d};
+  }
+  a.batch_start[batch_point.size()] = (int)col_idx.size();
+  if (col_idx.size() > (size_t)QUOT_MAX_ENTRIES) throw LmnError(LMN_ERR_INTERNAL, "too many column samples");
+  std::vector<QuotEntry> entries(col_idx.size());
+  for (size_t k = 0; k < col_idx.size(); ++k) entries[k] = {cols[col_idx[k]], coeff_c[k]};
+  a.entries = upload_vec(entries);
+  a.tw_y = twY_[ls];
+  a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
+  a.out = arena_.alloc_words(4ull << ls);
+  return a;
+}
+
 // ------------------------------------------------------------------------------------ prove
 std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
 #ifndef LMN_EMU
@@ -1109,56 +1168,13 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       std::vector<const FlatCol*> cols;
       for (auto& f : flat)
         if (f.lde_log == ls) cols.push_back(&f);
-      // ColumnSampleBatch::new_vec: group by point in first-appearance order
-      std::vector<int> batch_point;
-      std::vector<std::vector<std::pair<int, QM31>>> batch_cols;
-      for (size_t c = 0; c < cols.size(); ++c)
-        for (auto& sm : cols[c]->samples) {
-          size_t b = 0;
-          while (b < batch_point.size() && batch_point[b] != sm.first) ++b;
-          if (b == batch_point.size()) {
-            batch_point.push_back(sm.first);
-            batch_cols.emplace_back();
-          }
-          batch_cols[b].push_back({(int)c, sm.second});
-        }
-      if (batch_point.size() > (size_t)QUOT_MAX_BATCH) throw LmnError(LMN_ERR_INTERNAL, "too many sample batches");
-      QuotientArgs a{};
-      a.log_size = ls;
-      a.nbatch = (int)batch_point.size();
-      std::vector<int> col_idx;
-      std::vector<QM31> coeff_c;
-      for (size_t b = 0; b < batch_point.size(); ++b) {
-        QPt pt = points[batch_point[b]];
-        a.batch_start[b] = (int)col_idx.size();
-        QM31 alpha = q_one(), A = q_zero(), B = q_zero();
-        for (auto& cv : batch_cols[b]) {
-          alpha = q_mul(alpha, quot_alpha);
-          QM31 val = cv.second;
-          QM31 la = q_sub(q_conj(val), val);
-          QM31 lc = q_sub(q_conj(pt.y), pt.y);
-          QM31 lbb = q_sub(q_mul(val, lc), q_mul(la, pt.y));
-          A = q_add(A, q_mul(alpha, la));
-          B = q_add(B, q_mul(alpha, lbb));
-          col_idx.push_back(cv.first);
-          coeff_c.push_back(q_mul(alpha, lc));
-        }
-        a.A[b] = A;
-        a.B[b] = B;
-        a.batch_coeff[b] = q_pow(quot_alpha, batch_cols[b].size());
-        a.prx[b] = {pt.x.a, pt.x.b};
-        a.pix[b] = {pt.x.c, pt.x.d};
-        a.pry[b] = {pt.y.a, pt.y.b};
-        a.piy[b] = {pt.y.c, pt.y.d};
+      std::vector<const uint32_t*> ptrs;
+      std::vector<std::vector<std::pair<int, QM31>>> smp;
+      for (auto* c : cols) {
+        ptrs.push_back(c->lde);
+        smp.push_back(c->samples);
       }
-      a.batch_start[batch_point.size()] = (int)col_idx.size();
-      if (col_idx.size() > (size_t)QUOT_MAX_ENTRIES) throw LmnError(LMN_ERR_INTERNAL, "too many column samples");
-      std::vector<QuotEntry> entries(col_idx.size());
-      for (size_t k = 0; k < col_idx.size(); ++k) entries[k] = {cols[col_idx[k]]->lde, coeff_c[k]};
-      a.entries = upload_vec(entries);
-      a.tw_y = twY_[ls];
-      a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
-      a.out = arena_.alloc_words(4ull << ls);
+      QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha);
       launch_quotients(a, stream_);
       quots.push_back({ls, a.out});
     }
@@ -1537,6 +1553,64 @@ void Context::op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const 
   out[1] = r[0].b;
   out[2] = r[0].c;
   out[3] = r[0].d;
+}
+
+// QuotientOps::accumulate_quotients for the columns of one LDE size
+void Context::op_accumulate_quotients(uint32_t log_size, const uint32_t* const* cols, uint32_t ncols,
+                                      const uint32_t* sample_col, const uint32_t* sample_point, const uint32_t* sample_values,
+                                      uint32_t nsamples, const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4],
+                                      uint32_t* out) {
+  if (log_size < 2 || log_size > 26) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_size");
+  ensure_twiddles((int)log_size);
+  const uint64_t L = 1ull << log_size;
+  arena_.reserve(((uint64_t)ncols + 4) * L * 4 + (8u << 20));
+  arena_.reset();
+  pin_off_ = 0;
+  std::vector<const uint32_t*> d_cols(ncols);
+  for (uint32_t c = 0; c < ncols; ++c) {
+    uint32_t* d = arena_.alloc_words(L);
+    lmn_h2d(d, cols[c], L * 4, stream_);
+    d_cols[c] = d;
+  }
+  std::vector<QPt> pts(npoints);
+  for (uint32_t p = 0; p < npoints; ++p) {
+    const uint32_t* w = points_xy + 8 * p;
+    pts[p] = {{w[0], w[1], w[2], w[3]}, {w[4], w[5], w[6], w[7]}};
+  }
+  std::vector<std::vector<std::pair<int, QM31>>> smp(ncols);
+  for (uint32_t i = 0; i < nsamples; ++i) {
+    if (sample_col[i] >= ncols || sample_point[i] >= npoints) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad sample index");
+    const uint32_t* v = sample_values + 4 * i;
+    smp[sample_col[i]].push_back({(int)sample_point[i], QM31{v[0], v[1], v[2], v[3]}});
+  }
+  QuotientArgs a = make_quotient_args((int)log_size, d_cols, smp, pts, QM31{alpha[0], alpha[1], alpha[2], alpha[3]});
+  launch_quotients(a, stream_);
+  lmn_d2h(out, a.out, 16 * L, stream_);
+  lmn_sync(stream_);
+}
+
+// FriOps::fold_line (circle == 0) / FriOps::fold_circle_into_line (circle == 1; dst is accumulated:
+// dst = dst * alpha^2 + fold(src), as the FRI commit loop does)
+void Context::op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]) {
+  if (log_src < 1 || log_src > 27) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log size");
+  ensure_twiddles((int)log_src + 1);
+  const uint64_t L = 1ull << log_src;
+  arena_.reserve(6 * L * 4 + (1u << 20));
+  arena_.reset();
+  pin_off_ = 0;
+  uint32_t* d_src = arena_.alloc_words(4 * L);
+  uint32_t* d_dst = arena_.alloc_words(2 * L);
+  lmn_h2d(d_src, src, 16 * L, stream_);
+  std::vector<QM31> av{QM31{alpha[0], alpha[1], alpha[2], alpha[3]}};
+  QM31* d_alpha = upload_vec(av);
+  if (circle) {
+    lmn_h2d(d_dst, dst, 8 * L, stream_);
+    launch_fold_circle_into_line(d_dst, d_src, (uint32_t)L, itwY_[log_src], d_alpha, 1, stream_);
+  } else {
+    launch_fold_line(d_dst, d_src, (uint32_t)L, itwX_[log_src + 1], d_alpha, stream_);
+  }
+  lmn_d2h(dst, d_dst, 8 * L, stream_);
+  lmn_sync(stream_);
 }
 
 // tiled FFT vs one-layer-per-launch kernels on pseudo-random data (device-side differential check)

@@ -113,6 +113,10 @@ class Context {
   void op_merkle_root(const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols, uint8_t root[32]);
   void op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const uint32_t pt[8], uint32_t out[4]);
   void op_fft_selftest(uint32_t log_size, uint32_t ncols);
+  void op_accumulate_quotients(uint32_t log_size, const uint32_t* const* cols, uint32_t ncols, const uint32_t* sample_col,
+                               const uint32_t* sample_point, const uint32_t* sample_values, uint32_t nsamples,
+                               const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4], uint32_t* out);
+  void op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]);
 
   void* upload(const void* host, size_t bytes);
   void device_free(void* p);
@@ -132,6 +136,9 @@ class Context {
   void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
                     DevChannel* ch = nullptr, QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
+  QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
+                                  const std::vector<std::vector<std::pair<int, QM31>>>& samples,
+                                  const std::vector<QPt>& points, QM31 quot_alpha);
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets

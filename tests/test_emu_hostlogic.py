@@ -85,6 +85,8 @@ def test_emu_level2_ops(emu_ctx):
     want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
     assert emu_ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
     emu_ctx.fft_selftest(13, 1)
+    from level2_checks import check_quotient_fold_grind_ops
+    check_quotient_fold_grind_ops(emu_ctx, 7)
 
 
 def test_emu_pinned_variant_with_inputs_component(root):

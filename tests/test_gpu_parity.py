@@ -180,6 +180,9 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
         c = rng.integers(0, P, size=1 << log, dtype=np.uint64)
         want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
         assert ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
+    from level2_checks import check_quotient_fold_grind_ops
+    for log in (6, 13):
+        check_quotient_fold_grind_ops(ctx, log)
 
 
 @pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
