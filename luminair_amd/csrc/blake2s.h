@@ -124,6 +124,13 @@ LMN_HD void b2_compress2(uint32_t h[8], const uint32_t m[16], uint32_t g[8], con
   g[7] ^= w7 ^ w15;
 }
 
+// sigma schedule packed 4 bits per entry (entry i of round r at bits 4i..4i+3), for per-lane lookups
+#define LMN_B2_SIGMA_PACK(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                    \
+  ((uint64_t)(s0) | (uint64_t)(s1) << 4 | (uint64_t)(s2) << 8 | (uint64_t)(s3) << 12 | (uint64_t)(s4) << 16 |      \
+   (uint64_t)(s5) << 20 | (uint64_t)(s6) << 24 | (uint64_t)(s7) << 28 | (uint64_t)(s8) << 32 |                     \
+   (uint64_t)(s9) << 36 | (uint64_t)(s10) << 40 | (uint64_t)(s11) << 44 | (uint64_t)(s12) << 48 |                  \
+   (uint64_t)(s13) << 52 | (uint64_t)(s14) << 56 | (uint64_t)(s15) << 60)
+
 LMN_HD void b2_init(uint32_t h[8]) {
   h[0] = 0x6A09E667u ^ 0x01010020u;
   h[1] = 0xBB67AE85u;

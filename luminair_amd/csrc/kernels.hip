@@ -507,32 +507,109 @@ LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
   o4[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
-// LDS climb shared by the Merkle kernels: `lvl_size` hashes of this block sit in sh[idx*8..]; levels
-// first..last are produced, one lane per parent.  (A 4-lane cooperative, DPP-rotated Blake2s was
-// tried for the narrow levels: no faster — one lane already interleaves the four independent G
-// functions of each half-round, so a level costs ~1 us of issue plus two barriers either way.)
+// Quad-cooperative Blake2s of one 64-byte final block (a Merkle parent): lane q of a quad owns column q
+// of the 4x4 state (a, b, c, d = rows), so the four G functions of a half-round run on four lanes; the
+// diagonal step rotates rows b, c, d by 1, 2, 3 lanes with DPP quad_perm.  Message words are fetched from
+// LDS by per-lane sigma offsets.  ~400 issue slots instead of ~1000: single-hash latency 0.93 us vs 2.0 us
+// on MI355X (tools/microbench4.hip) - used where a level is too narrow to fill lanes anyway.
+// Returns words q and 4+q of the digest.  Must be executed by all four lanes of the quad.
+LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint32_t& o_hi) {
+#ifdef LMN_EMU
+  // CPU emulation (tests only): a cross-lane rendezvous per DPP move would be a block-wide fiber switch;
+  // every lane hashes the block alone and keeps its two words.  The DPP path is checked on the GPU.
+  uint32_t h[8], m[16];
+  for (int k = 0; k < 16; ++k) m[k] = msg[k];
+  b2_init(h);
+  b2_compress(h, m, 64u, 0xffffffffu);
+  o_lo = h[q];
+  o_hi = h[4 + q];
+  return;
+#endif
+  const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+  const uint32_t h_lo = q == 0 ? (0x6A09E667u ^ 0x01010020u) : iv_lo;
+  uint32_t a = h_lo, b = iv_hi, c = iv_lo, d = iv_hi ^ (q == 0 ? 64u : q == 2 ? 0xffffffffu : 0u);
+  const uint32_t sh8 = 8u * q;
+#define LMN_B2_QUAD_ROUND(...)                                            \
+  {                                                                       \
+    const uint64_t S = LMN_B2_SIGMA_PACK(__VA_ARGS__);                    \
+    const uint32_t lo = (uint32_t)(S >> sh8), hi = (uint32_t)(S >> (32u + sh8)); \
+    const uint32_t x0 = msg[lo & 15u], y0 = msg[(lo >> 4) & 15u];        \
+    const uint32_t x1 = msg[hi & 15u], y1 = msg[(hi >> 4) & 15u];        \
+    LMN_B2_G(a, b, c, d, x0, y0)                                          \
+    b = lmn_quad_perm(b, 0x39);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x93);                                           \
+    LMN_B2_G(a, b, c, d, x1, y1)                                          \
+    b = lmn_quad_perm(b, 0x93);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x39);                                           \
+  }
+  LMN_B2_QUAD_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  LMN_B2_QUAD_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_QUAD_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_QUAD_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_QUAD_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_QUAD_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_QUAD_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_QUAD_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_QUAD_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_QUAD_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef LMN_B2_QUAD_ROUND
+  o_lo = h_lo ^ a ^ c;
+  o_hi = iv_hi ^ b ^ d;
+}
+
+// One level of an in-LDS Merkle climb: the children of this block's `n_par` parents sit in sh[j*16 ..];
+// parent j is written back to sh[j*8 ..] and to out[(node0 + j)*8 ..].  Levels with at most BLOCK/4
+// parents use four lanes per hash (latency), wider ones one lane per hash (throughput).  Block-uniform
+// arguments; ends WITHOUT a barrier.
 template <int BLOCK>
-LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, int last, uint32_t lvl_size,
-                            uint32_t cur[8]) {
-  for (int l = first; l <= last; ++l) {
+LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t node0, uint32_t n_par) {
+  __syncthreads();
+  if (n_par * 4u <= (uint32_t)BLOCK) {
+    const uint32_t g = threadIdx.x >> 2, q = threadIdx.x & 3u;
+    const bool on = g < n_par;
+    uint32_t o_lo = 0u, o_hi = 0u;
+    const bool wave_on = ((threadIdx.x & ~63u) >> 2) < n_par;  // wave-uniform
+    if (wave_on) b2_quad_parent(sh + g * 16u, q, o_lo, o_hi);
     __syncthreads();
-    lvl_size >>= 1;
-    const uint32_t active = (uint32_t)BLOCK >> (l - first + 1);
-    const uint32_t node = blockIdx.x * active + threadIdx.x;
-    const bool on = threadIdx.x < active && node < lvl_size;
+    if (on) {
+      sh[g * 8u + q] = o_lo;
+      sh[g * 8u + 4u + q] = o_hi;
+      uint32_t* o = out + (uint64_t)(node0 + g) * 8;
+      o[q] = o_lo;
+      o[4u + q] = o_hi;
+    }
+  } else {
+    const bool on = threadIdx.x < n_par;
+    uint32_t cur[8];
     if (on) {
       uint32_t m[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) m[k] = sh[threadIdx.x * 16 + k];
       b2_init(cur);
       b2_compress(cur, m, 64u, 0xffffffffu);
-      store_hash(outs.p[l] + (uint64_t)node * 8, cur);
+      store_hash(out + (uint64_t)(node0 + threadIdx.x) * 8, cur);
     }
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = cur[k];
     }
+  }
+}
+
+// LDS climb shared by the Merkle kernels: `lvl_size` hashes of the whole level exist, this block's share
+// sits in sh[idx*8..]; levels first..last are produced.
+template <int BLOCK>
+LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, int last, uint32_t lvl_size) {
+  for (int l = first; l <= last; ++l) {
+    lvl_size >>= 1;
+    const uint32_t active = (uint32_t)BLOCK >> (l - first + 1);
+    const uint32_t node0 = blockIdx.x * active;
+    const uint32_t n_par = node0 >= lvl_size ? 0u : (lvl_size - node0 < active ? lvl_size - node0 : active);
+    merkle_lds_level<BLOCK>(sh, outs.p[l], node0, n_par);
   }
 }
 
@@ -596,7 +673,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh[local * 8 + k] = cur[k];
   }
-  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub, cur);
+  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub);
 }
 
 LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
@@ -654,7 +731,7 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
   }
-  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size, cur);
+  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
   // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
   if (ch != nullptr && (size >> nfused) == 1u) {
     __syncthreads();
@@ -723,25 +800,7 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
 #pragma unroll
       for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
     }
-    uint32_t lvl_size = size;
-    for (int l = L - 1; l >= 0; --l) {
-      __syncthreads();
-      lvl_size >>= 1;
-      const bool on = i < lvl_size;
-      if (on) {
-        uint32_t m[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m[k] = sh[i * 16 + k];
-        b2_init(cur);
-        b2_compress(cur, m, 64u, 0xffffffffu);
-        store_hash(ly.merkle[l] + (uint64_t)i * 8, cur);
-      }
-      __syncthreads();
-      if (on) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
-      }
-    }
+    for (int l = L - 1; l >= 0; --l) merkle_lds_level<MERKLE_SMALL_BLOCK>(sh, ly.merkle[l], 0u, 1u << l);
     __syncthreads();
     if (i == 0) {
       chan_mix_root_draw(ch, sh, &alphas_out[li], roots_out + li * 8);

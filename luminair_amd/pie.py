@@ -110,10 +110,20 @@ class CircuitSettings:
             out[name] = cols
         return out
 
-    def to_bincode(self) -> bytes:
+    def to_bincode(self, kat_era: bool = False) -> bytes:
+        """bincode of `CircuitSettings { lookups: Lookups }` for LUT-free graphs: one `None` tag per
+        `Lookups` field (HEAD: sin, exp2, log2, range_check; the KAT era had `sin` only, which is what
+        `ui/demo/public/settings` holds).  Settings WITH lookups carry numerair `Fixed` ranges and an
+        stwo-air-utils multiplicity column whose wire formats are un-vendored: not serialised here."""
         if self.lookups:
             raise LuminairError("SerializationError", "LUT layouts (value ranges) are not carried by this mirror")
-        return bytes(4)  # four `None` tags: sin, exp2, log2, range_check
+        return bytes(1 if kat_era else 4)
+
+    @staticmethod
+    def from_bincode(data: bytes) -> "CircuitSettings":
+        if len(data) not in (1, 4) or any(data):
+            raise LuminairError("SerializationError", "only LUT-free settings can be deserialised")
+        return CircuitSettings()
 
 
 @dataclass

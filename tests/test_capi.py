@@ -41,3 +41,14 @@ def test_product_sources_do_not_touch_the_oracle(root):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libluminair_emu" not in src, f
+
+
+def test_settings_bincode_matches_the_reference_fixture(root):
+    """`ui/demo/public/settings` (KAT era: a single `None` for `lookups.sin`) round-trips through the mirror."""
+    import luminair_amd
+    data = open(os.path.join(root, "tests", "golden", "kat_simple", "settings"), "rb").read()
+    assert luminair_amd.CircuitSettings().to_bincode(kat_era=True) == data
+    assert luminair_amd.CircuitSettings.from_bincode(data).lookups is None
+    assert luminair_amd.CircuitSettings().to_bincode() == bytes(4)
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.CircuitSettings.from_bincode(b"\x01")
