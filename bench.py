@@ -38,6 +38,7 @@ def parse_args(argv=None):
     ap.add_argument("--host-rows", action="store_true",
                     help="hand the trace rows over as host buffers (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-anchor", action="store_true", help="skip the 32x32 reference-shape latency anchor")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
     return ap.parse_args(argv)
 
@@ -231,7 +232,7 @@ def main(argv=None):
     # the reference's own published shape (32x32 Add, 1 024 Add rows + 2 048 Inputs rows,
     # 13.05 ms on a GitHub Actions runner) as a sanity anchor: solo GPU latency, median of 9
     anchor = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_anchor:
         from luminair_amd import backend as _bk
         ap = luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED)
         atabs = [(k, r, len(r)) for k, r in syn.config2_graph_faithful(1024, 42)]

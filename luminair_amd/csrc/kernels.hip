@@ -160,8 +160,19 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
   uint32_t* __restrict__ tdst = col + base;
   const uint64_t span = src_len > base ? src_len - base : 0;
   const uint32_t lim = span > 0x10000000ull ? 0x10000000u : (uint32_t)span;  // readable words from tsrc
+  // The 2^R points of a group sit at tile index e0 + (j << p) (bits [p, p+R) of e0 are zero), so both
+  // address maps are affine in j: global offset ((e >> cb) << lo) + (e & cmask) has stride
+  // 2^(p - cb + lo) (p >= cb always), and the padded LDS index e + (e >> 5) has stride 2^p + 2^(p-5)
+  // when p >= 5.  One add per point instead of re-deriving each address.
+  const uint32_t gstride = 1u << (p - cb + lo);
+  const bool lds_affine = p >= 5;
+  const uint32_t lstride = lds_affine ? (1u << p) + (1u << (p - 5)) : 0u;
+  const uint32_t tile_span = (((tile_elems - 1u) >> cb) << lo) + cmask + 1u;  // words of [tsrc, ...) the tile touches
+  const bool full = tile_span <= lim;                                           // block-uniform: no zero-extension here
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const uint32_t e0 = ((g >> p) << (p + R)) | (g & ((1u << p) - 1u));
+    const uint32_t off0 = ((e0 >> cb) << lo) + (e0 & cmask);
+    LMN_ASSUME(off0 < 0x10000000u);
     uint32_t v[1 << R];
     if (from_global) {
       if (p == 0 && cb == 0 && R >= 2) {
@@ -179,15 +190,20 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
 #pragma unroll
           for (int j = 0; j < (1 << R); ++j) v[j] = 0u;
         }
+      } else if (full) {
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) v[j] = tsrc[off0 + (uint32_t)j * gstride];
       } else {
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) {
-          const uint32_t e = e0 + ((uint32_t)j << p);
-          const uint32_t off = ((e >> cb) << lo) + (e & cmask);
-          LMN_ASSUME(off < 0x10000000u);
+          const uint32_t off = off0 + (uint32_t)j * gstride;
           v[j] = off < lim ? tsrc[off] : 0u;
         }
       }
+    } else if (lds_affine) {
+      const uint32_t pb = fft_lds_pad(e0);
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) v[j] = sm[pb + (uint32_t)j * lstride];
     } else {
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) v[j] = sm[fft_lds_pad(e0 + ((uint32_t)j << p))];
@@ -205,13 +221,12 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
         for (int k = 0; k < (1 << R) / 4; ++k) q[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
       } else {
 #pragma unroll
-        for (int j = 0; j < (1 << R); ++j) {
-          const uint32_t e = e0 + ((uint32_t)j << p);
-          const uint32_t off = ((e >> cb) << lo) + (e & cmask);
-          LMN_ASSUME(off < 0x10000000u);
-          tdst[off] = v[j];
-        }
+        for (int j = 0; j < (1 << R); ++j) tdst[off0 + (uint32_t)j * gstride] = v[j];
       }
+    } else if (lds_affine) {
+      const uint32_t pb = fft_lds_pad(e0);
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) sm[pb + (uint32_t)j * lstride] = v[j];
     } else {
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) sm[fft_lds_pad(e0 + ((uint32_t)j << p))] = v[j];
@@ -561,13 +576,13 @@ LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint3
 }
 
 // One level of an in-LDS Merkle climb: the children of this block's `n_par` parents sit in sh[j*16 ..];
-// parent j is written back to sh[j*8 ..] and to out[(node0 + j)*8 ..].  Levels with at most BLOCK/4
-// parents use four lanes per hash (latency), wider ones one lane per hash (throughput).  Block-uniform
-// arguments; ends WITHOUT a barrier.
+// parent j is written back to sh[j*8 ..] and to out[(node0 + j)*8 ..].  Levels with at most 128 parents
+// (two quad-waves per SIMD of the CU) use four lanes per hash, which is faster there; wider levels are
+// throughput-bound inside the CU and keep one lane per hash.  Block-uniform arguments; ends WITHOUT a barrier.
 template <int BLOCK>
 LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t node0, uint32_t n_par) {
   __syncthreads();
-  if (n_par * 4u <= (uint32_t)BLOCK) {
+  if (n_par * 4u <= (uint32_t)BLOCK && n_par <= 128u) {
     const uint32_t g = threadIdx.x >> 2, q = threadIdx.x & 3u;
     const bool on = g < n_par;
     uint32_t o_lo = 0u, o_hi = 0u;
