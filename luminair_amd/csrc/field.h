@@ -22,7 +22,7 @@ LMN_HD uint32_t m_mul(uint32_t a, uint32_t b) {
 }
 LMN_HD uint32_t m_sqr(uint32_t a) { return m_mul(a, a); }
 LMN_HD uint32_t m_dbl(uint32_t a) { return m_add(a, a); }
-// reduce a 64-bit value (< 2^62) to canonical M31
+// reduce any 64-bit value to canonical M31
 LMN_HD uint32_t m_red64(uint64_t p) {
   uint64_t s = (p & P31) + (p >> 31);       // < 2^32
   uint32_t t = (uint32_t)(s & P31) + (uint32_t)(s >> 31);
@@ -83,6 +83,29 @@ LMN_HD QM31 q_mul(QM31 x, QM31 y) {
   return {lo.a, lo.b, hi.a, hi.b};
 }
 LMN_HD QM31 q_sqr(QM31 x) { return q_mul(x, x); }
+
+// Lazy dot-product accumulator: sum_k c_k * f_k with c_k in QM31, f_k in M31 (canonical factors).
+// Each product is < 2^62, so one 64-bit lane per coordinate takes three products on top of a folded
+// value (< 2^34) before it must be folded again: one v_mad_u64_u32 per multiply-accumulate instead of
+// a full multiply-reduce-add-reduce chain.  Results are identical after qacc_reduce.
+struct QAcc {
+  uint64_t a, b, c, d;
+};
+LMN_HD QAcc qacc_zero() { return {0ull, 0ull, 0ull, 0ull}; }
+LMN_HD void qacc_mad(QAcc& s, const QM31& c, uint32_t f) {
+  s.a += (uint64_t)c.a * f;
+  s.b += (uint64_t)c.b * f;
+  s.c += (uint64_t)c.c * f;
+  s.d += (uint64_t)c.d * f;
+}
+LMN_HD uint64_t m_fold64(uint64_t s) { return (s & P31) + (s >> 31); }  // any s -> < 2^31 + 2^33, same residue
+LMN_HD void qacc_fold(QAcc& s) {
+  s.a = m_fold64(s.a);
+  s.b = m_fold64(s.b);
+  s.c = m_fold64(s.c);
+  s.d = m_fold64(s.d);
+}
+LMN_HD QM31 qacc_reduce(const QAcc& s) { return {m_red64(s.a), m_red64(s.b), m_red64(s.c), m_red64(s.d)}; }
 LMN_HD QM31 q_mul_c(QM31 x, CM31 c) {
   CM31 lo = c_mul({x.a, x.b}, c), hi = c_mul({x.c, x.d}, c);
   return {lo.a, lo.b, hi.a, hi.b};

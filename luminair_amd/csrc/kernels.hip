@@ -1062,17 +1062,27 @@ LMN_D uint32_t prev_row_storage(uint32_t s, int eval_log, int log_size) {
   return (t << 1) | low;
 }
 
+// sum_k coeff[k] * constraint_k, accumulated lazily (QAcc: one v_mad_u64_u32 per coordinate for the
+// M31-valued local constraints, folded every third term; k is compile-time after unrolling)
 struct ConsAcc {
-  QM31 acc;
+  QAcc acc;
   const QM31* coeff;
   int k;
-  LMN_HD void add_m(uint32_t c) {
-    acc = q_add(acc, q_mul_m(coeff[k], c));
+  LMN_HD void bump() {
     ++k;
+    if (k % 3 == 0) qacc_fold(acc);
+  }
+  LMN_HD void add_m(uint32_t c) {
+    qacc_mad(acc, coeff[k], c);
+    bump();
   }
   LMN_HD void add_q(QM31 c) {
-    acc = q_add(acc, q_mul(coeff[k], c));
-    ++k;
+    const QM31 t = q_mul(coeff[k], c);
+    acc.a += t.a;
+    acc.b += t.b;
+    acc.c += t.c;
+    acc.d += t.d;
+    bump();
   }
 };
 
@@ -1119,7 +1129,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
   const uint64_t E = 1ull << a.eval_log;
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= E) return;
-  ConsAcc ca{q_zero(), a.coeff, 0};
+  ConsAcc ca{qacc_zero(), a.coeff, 0};
   const uint32_t* __restrict__ mn = a.main + s;
 #define LMN_COL(k) mn[(uint64_t)(k) * E]
   if (KIND == 0 || KIND == 1) {
@@ -1268,7 +1278,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, E);
   }
 #undef LMN_COL
-  QM31 r = q_mul_m(ca.acc, a.zinv[(s >> a.log_size) & 1u]);
+  QM31 r = q_mul_m(qacc_reduce(ca.acc), a.zinv[(s >> a.log_size) & 1u]);
   uint32_t* o = a.out + s;
   if (a.accumulate) {
     r.a = m_add(r.a, o[0]);
@@ -1348,21 +1358,37 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
     uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
     Lr[k] = lo < lo_n ? L[lo] : q_zero();
   }
-  QM31 acc = q_zero();
+  // sum_hi H[hi] * (sum_lo L[lo] * c[hi, lo]) regrouped as sum_lo L[lo] * (sum_hi H[hi] * c[hi, lo]): the
+  // inner sums are QM31 (wave-uniform H) x M31 products, accumulated lazily in 64-bit lanes; one full
+  // QM31 product per owned lo position closes the chunk.
+  QAcc in0 = qacc_zero(), in1 = qacc_zero(), in2 = qacc_zero(), in3 = qacc_zero();
+  uint32_t pending = 0;
   for (uint32_t hh = 0; hh < hpc; ++hh) {
     const uint32_t hi = chunk * hpc + hh;
     const uint32_t* __restrict__ cp = job.coeffs + ((uint64_t)hi << lb);
+    const QM31 Hv = Hh[hi];
     uint32_t cv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
       cv[k] = lo < lo_n ? cp[lo] : 0u;
     }
-    QM31 inner = q_mul_m(Lr[0], cv[0]);
-#pragma unroll
-    for (int k = 1; k < 4; ++k) inner = q_add(inner, q_mul_m(Lr[k], cv[k]));
-    acc = q_add(acc, q_mul(Hh[hi], inner));
+    qacc_mad(in0, Hv, cv[0]);
+    qacc_mad(in1, Hv, cv[1]);
+    qacc_mad(in2, Hv, cv[2]);
+    qacc_mad(in3, Hv, cv[3]);
+    if (++pending == 3) {
+      pending = 0;
+      qacc_fold(in0);
+      qacc_fold(in1);
+      qacc_fold(in2);
+      qacc_fold(in3);
+    }
   }
+  QM31 acc = q_mul(Lr[0], qacc_reduce(in0));
+  acc = q_add(acc, q_mul(Lr[1], qacc_reduce(in1)));
+  acc = q_add(acc, q_mul(Lr[2], qacc_reduce(in2)));
+  acc = q_add(acc, q_mul(Lr[3], qacc_reduce(in3)));
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int st = TPB / 2; st > 0; st >>= 1) {
@@ -1482,17 +1508,27 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
 #pragma unroll
   for (int b = 0; b < QUOT_MAX_BATCH; ++b) {
     if (b >= a.nbatch) break;
-    QM31 num = q_zero();
+    // sum_k c_k * f_k(s) accumulated lazily in 64-bit lanes (three products per fold)
+    QAcc acc = qacc_zero();
     const int k1 = a.batch_start[b + 1];
     int k = a.batch_start[b];
-    for (; k + 4 <= k1; k += 4) {
-      uint32_t f0 = tab[k].col[s], f1 = tab[k + 1].col[s], f2 = tab[k + 2].col[s], f3 = tab[k + 3].col[s];
-      num = q_add(num, q_mul_m(tab[k].c, f0));
-      num = q_add(num, q_mul_m(tab[k + 1].c, f1));
-      num = q_add(num, q_mul_m(tab[k + 2].c, f2));
-      num = q_add(num, q_mul_m(tab[k + 3].c, f3));
+    for (; k + 6 <= k1; k += 6) {
+      uint32_t f0 = tab[k].col[s], f1 = tab[k + 1].col[s], f2 = tab[k + 2].col[s];
+      uint32_t f3 = tab[k + 3].col[s], f4 = tab[k + 4].col[s], f5 = tab[k + 5].col[s];
+      qacc_mad(acc, tab[k].c, f0);
+      qacc_mad(acc, tab[k + 1].c, f1);
+      qacc_mad(acc, tab[k + 2].c, f2);
+      qacc_fold(acc);
+      qacc_mad(acc, tab[k + 3].c, f3);
+      qacc_mad(acc, tab[k + 4].c, f4);
+      qacc_mad(acc, tab[k + 5].c, f5);
+      qacc_fold(acc);
     }
-    for (; k < k1; ++k) num = q_add(num, q_mul_m(tab[k].c, tab[k].col[s]));
+    for (; k < k1; ++k) {
+      qacc_mad(acc, tab[k].c, tab[k].col[s]);
+      qacc_fold(acc);
+    }
+    QM31 num = qacc_reduce(acc);
     num = q_sub(num, q_add(q_mul_m(a.A[b], y), a.B[b]));
     row = q_add(q_mul(row, a.batch_coeff[b]), q_mul_c(num, dinv[b]));
   }
