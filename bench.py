@@ -246,6 +246,28 @@ def main(argv=None):
                   "gpu_latency_ms": sorted(ts)[4], "reference_published_ms": 13.05,
                   "reference_hardware": "GitHub Actions ubuntu-latest CPU (docs/snippets/benchmark-component.mdx:172)"}
 
+    # the step before the path: `process_trace` of the Add node on device tensors
+    trace_gen = None
+    if rank == 0:
+        import numpy as _np
+        n_rows = 1 << args.log_rows
+        rng = _np.random.default_rng(7)
+        dl = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(_np.int32))
+        dr = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(_np.int32))
+        rows_buf = prover.ctx.alloc(n_rows * 15 * 4)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            _, ob = prover.ctx.trace_elementwise(0, dl, dr, n_rows, node_id=2, input_ids=(0, 1), num_consumers=0,
+                                                 is_final_output=True, input_mults=(0, 0), rows=rows_buf)
+            ts.append(1e3 * (time.perf_counter() - t0))
+            ob.free()
+        for b_ in (dl, dr, rows_buf):
+            b_.free()
+        trace_gen = {"workload": "Add node process_trace on device tensors, 2^%d elements -> 15-column rows in HBM"
+                                 % args.log_rows, "ms": sorted(ts)[2],
+                     "reference_published_ms": 0.0959, "reference_workload": "32x32 Add trace generation (BASELINE.md §1)"}
+
     line = {
         "metric": "proofs/sec, 2^%d-row Add trace" % args.log_rows, "value": agg["value"], "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": agg["ms_per_step"],
@@ -264,6 +286,8 @@ def main(argv=None):
     }
     if anchor:
         line["reference_shape_anchor"] = anchor
+    if trace_gen:
+        line["device_trace_generation"] = trace_gen
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows)
     if rank == 0:

@@ -44,6 +44,12 @@ class LmnSettings(C.Structure):
 LUT_KINDS = {"sin": 0, "exp2": 1, "log2": 2}   # LMN_LUT_*
 
 
+class LmnNodeInfo(C.Structure):
+    """`NodeInfo` fields `process_trace` reads (crates/graph/src/utils.rs / op/prim.rs:980-990)."""
+    _fields_ = [("node_id", C.c_uint32), ("input_ids", C.c_uint32 * 2), ("num_consumers", C.c_uint32),
+                ("is_final_output", C.c_uint32), ("input_mults", C.c_int32 * 2)]
+
+
 class LmnTimings(C.Structure):
     _fields_ = [("total_ms", C.c_float)] + [(n, C.c_float) for n in (
         "transpose_ms", "main_commit_ms", "logup_ms", "interaction_commit_ms", "composition_ms",
@@ -61,7 +67,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
-           "lmn_op_grind"]
+           "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -108,6 +114,10 @@ class Library:
         lib.lmn_op_fold_line.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.lmn_op_fold_circle_into_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.lmn_op_grind.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.lmn_trace_elementwise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
 
     def default_config(self) -> LmnConfig:
         cfg = LmnConfig()
@@ -187,6 +197,33 @@ class Context:
         out = C.c_void_p()
         self._check(self.lib.lib.lmn_upload(self.handle, arr.ctypes.data, arr.nbytes, C.byref(out)))
         return DeviceBuffer(self, out.value, arr.nbytes)
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_device_alloc(self.handle, nbytes, C.byref(out)))
+        return DeviceBuffer(self, out.value, nbytes)
+
+    def download(self, buf: DeviceBuffer, dtype=np.uint32) -> np.ndarray:
+        host = np.empty(buf.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._check(self.lib.lib.lmn_download(self.handle, buf.ptr, host.ctypes.data, buf.nbytes))
+        return host
+
+    def trace_elementwise(self, kind: int, lhs: DeviceBuffer, rhs: Optional[DeviceBuffer], n: int, node_id: int,
+                          input_ids, num_consumers: int, is_final_output: bool = False, input_mults=(-1, -1),
+                          rows: Optional[DeviceBuffer] = None, row_offset: int = 0):
+        """`process_trace` of one Add / Mul / Recip node on device tensors (int32 Fixed<12> values).
+        Returns (rows DeviceBuffer, out DeviceBuffer)."""
+        ncols = self.lib.kind_columns(kind)
+        if rows is None:
+            rows = self.alloc((row_offset + n) * ncols * 4)
+        out = self.alloc(n * 4)
+        ids = list(input_ids) + [0] * (2 - len(input_ids))
+        mults = list(input_mults) + [0] * (2 - len(input_mults))
+        info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(*ids), num_consumers, 1 if is_final_output else 0,
+                           (C.c_int32 * 2)(*mults))
+        self._check(self.lib.lib.lmn_trace_elementwise(self.handle, kind, lhs.ptr, rhs.ptr if rhs is not None else None,
+                                                       n, C.byref(info), rows.ptr, row_offset, out.ptr))
+        return rows, out
 
     def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:
         """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer;

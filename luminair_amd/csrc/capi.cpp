@@ -200,3 +200,19 @@ int lmn_op_grind(const uint8_t digest[32], uint32_t pow_bits, uint32_t protocol_
   *nonce_out = ch.grind(pow_bits);
   return LMN_OK;
 }
+
+int lmn_device_alloc(lmn_ctx* ctx, size_t bytes, void** device_out) {
+  if (!ctx || !device_out) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { *device_out = ctx->impl->device_alloc(bytes); });
+}
+
+int lmn_download(lmn_ctx* ctx, const void* device, void* host, size_t bytes) {
+  if (!ctx || !device || !host) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->download(device, host, bytes); });
+}
+
+int lmn_trace_elementwise(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const int32_t* rhs_dev, uint64_t n,
+                          const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !lhs_dev || !info || !rows_dev || (kind != LMN_KIND_RECIP && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, rhs_dev, n, *info, rows_dev, row_offset, out_dev); });
+}

@@ -88,6 +88,14 @@ struct GatherEntry {
 void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, uint32_t* out,
                    lmn_stream_t s);
 
+// ---- trace generation for the elementwise primitives (the producer of the hot path's input)
+struct TraceNode {
+  uint32_t node_id, lhs_id, rhs_id;
+  uint32_t lhs_mult, rhs_mult, out_mult;  // canonical M31
+};
+void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const TraceNode& nd,
+                              uint32_t* rows, int32_t* out, lmn_stream_t s);
+
 // ---- a6: logup
 constexpr int LOGUP_MAX_REL = 7;
 struct LogupArgs {

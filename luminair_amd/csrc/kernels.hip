@@ -48,6 +48,72 @@ void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int 
 }
 
 // =============================================================================================
+// gen_trace for Add / Mul / Recip nodes (crates/graph/src/op/prim.rs:967-1013, :1090-1139, :388-431):
+// one lane per tensor element computes the fixed-point op and its row; the block stages its rows in LDS
+// and writes them out as one contiguous, coalesced run of words.
+// =============================================================================================
+LMN_HD uint32_t fixed_to_m31(int64_t v) { return v >= 0 ? (uint32_t)v : (uint32_t)((int64_t)P31 + v); }
+
+template <int KIND>
+LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* __restrict__ rhs, uint64_t n,
+                               TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
+  constexpr int NC = KIND == 0 ? 15 : (KIND == 1 ? 16 : 13);
+  constexpr int ST = NC | 1;  // odd LDS row stride: conflict-free column writes
+  LMN_SHARED uint32_t tile[TPB * ST];
+  const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
+  const uint64_t r = row0 + threadIdx.x;
+  if (r < n) {
+    uint32_t* t = tile + threadIdx.x * ST;
+    const int64_t a = lhs[r];
+    const uint32_t idx = (uint32_t)r, last = r + 1 == n ? 1u : 0u;
+    if (KIND == 2) {
+      // node, input, idx, is_last, next_node, next_input, next_idx, input, out, rem, scale, in_mult, out_mult
+      const int64_t sc2 = 4096ll * 4096ll;
+      const int64_t o = sc2 / a, rem = sc2 - a * o;
+      t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = idx; t[3] = last;
+      t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = idx + 1u;
+      t[7] = fixed_to_m31(a); t[8] = fixed_to_m31(o); t[9] = fixed_to_m31(rem); t[10] = 4096u;
+      t[11] = nd.lhs_mult; t[12] = nd.out_mult;
+      if (out) out[r] = (int32_t)o;
+    } else {
+      const int64_t b = rhs[r];
+      t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = nd.rhs_id; t[3] = idx; t[4] = last;
+      t[5] = nd.node_id; t[6] = nd.lhs_id; t[7] = nd.rhs_id; t[8] = idx + 1u;
+      t[9] = fixed_to_m31(a); t[10] = fixed_to_m31(b);
+      int64_t o;
+      if (KIND == 0) {
+        o = a + b;
+        t[11] = fixed_to_m31(o);
+        t[12] = nd.lhs_mult; t[13] = nd.rhs_mult; t[14] = nd.out_mult;
+      } else {
+        const int64_t prod = a * b;
+        o = prod >> 12;  // floor
+        t[11] = fixed_to_m31(o);
+        t[12] = (uint32_t)(prod & 4095);
+        t[13] = nd.lhs_mult; t[14] = nd.rhs_mult; t[15] = nd.out_mult;
+      }
+      if (out) out[r] = (int32_t)o;
+    }
+  }
+  __syncthreads();
+  const uint64_t rows_here = n - row0 < (uint64_t)TPB ? n - row0 : (uint64_t)TPB;
+  const uint32_t words = (uint32_t)rows_here * NC;
+  uint32_t* dst = rows + row0 * NC;
+  for (uint32_t w = threadIdx.x; w < words; w += TPB) dst[w] = tile[(w / NC) * ST + (w % NC)];
+}
+
+void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const TraceNode& nd,
+                              uint32_t* rows, int32_t* out, lmn_stream_t s) {
+  dim3 g(cdiv(n, TPB)), b(TPB);
+  switch (kind) {
+    case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
+    case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
+    case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
+    default: throw LmnError(-100, "trace_elementwise: unsupported kind");
+  }
+}
+
+// =============================================================================================
 // a4  Circle FFT.  Layer i pairs indices differing in bit i; twiddle index = idx >> (i+1).
 //     A pass runs layers [lo, hi) on LDS tiles of 2^(hi-lo) rows x 2^cb contiguous words.
 // =============================================================================================

@@ -236,6 +236,43 @@ void* Context::upload(const void* host, size_t bytes) {
   return d;
 }
 void Context::device_free(void* p) { lmn_dev_free(p); }
+void* Context::device_alloc(size_t bytes) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  return lmn_dev_malloc(bytes ? bytes : 4);
+}
+void Context::download(const void* device, void* host, size_t bytes) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  lmn_d2h(host, device, bytes, stream_);
+  lmn_sync(stream_);
+}
+
+// `process_trace` of one Add / Mul / Recip node on device tensors (prim.rs:967-1013, :1090-1139, :388-431)
+void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t* rhs, uint64_t n,
+                                const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  const ComponentSpec* sp = component_spec((int)kind);
+  if (!sp || (kind != LMN_KIND_ADD && kind != LMN_KIND_MUL && kind != LMN_KIND_RECIP))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: kind must be Add, Mul or Recip");
+  if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
+  if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
+  auto m31 = [](int64_t v) { return (uint32_t)(((v % (int64_t)P31) + (int64_t)P31) % (int64_t)P31); };
+  TraceNode nd{};
+  nd.node_id = info.node_id;
+  nd.lhs_id = info.input_ids[0];
+  nd.rhs_id = info.input_ids[1];
+  nd.lhs_mult = m31(info.input_mults[0]);
+  nd.rhs_mult = m31(info.input_mults[1]);
+  nd.out_mult = info.is_final_output ? 0u : m31(info.num_consumers);
+  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : 2), lhs, rhs, n, nd,
+                           rows + row_offset * (uint64_t)sp->n_cols, out, stream_);
+  lmn_sync(stream_);
+}
 
 // Twiddle tables for every canonic domain up to 2^max_domain_log (computed
 // once per context and cached across proofs, instead of once per proof as prover.rs:38-42 does).

@@ -119,6 +119,10 @@ class Context {
   void op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]);
 
   void* upload(const void* host, size_t bytes);
+  void* device_alloc(size_t bytes);
+  void download(const void* device, void* host, size_t bytes);
+  void trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const lmn_node_info& info,
+                         uint32_t* rows, uint64_t row_offset, int32_t* out);
   void device_free(void* p);
 
   lmn_config cfg;

@@ -36,3 +36,39 @@ def check_quotient_fold_grind_ops(ctx, log):
         assert nonce == c2.grind(9)
         c2.mix_u64(nonce)
         assert c2.trailing_zeros() >= 9
+
+
+def check_device_trace_generation(ctx, n, seed=21):
+    """Device-side `process_trace` (lmn_trace_elementwise) for the chain c = a*b; d = c + w; e = recip(d):
+    rows equal the host generator's rows (luminair_amd.synthetic restates prim.rs), intermediate tensors stay
+    in device memory, and the proof from device-resident rows equals the proof from host rows."""
+    from luminair_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    a = rng.integers(1, 2048, size=n).astype(np.int32)
+    b = rng.integers(1, 2048, size=n).astype(np.int32)
+    w = rng.integers(8, 2048, size=n).astype(np.int32)
+    want = syn.chain_graph(n, seed)            # same draws, KAT-era multiplicities
+    da, db, dw = ctx.upload(a), ctx.upload(b), ctx.upload(w)
+    mul_rows, c = ctx.trace_elementwise(1, da, db, n, node_id=3, input_ids=(6, 7), num_consumers=1, input_mults=(0, 0))
+    add_rows, d = ctx.trace_elementwise(0, c, dw, n, node_id=4, input_ids=(3, 8), num_consumers=1, input_mults=(-1, 0))
+    rec_rows, e = ctx.trace_elementwise(2, d, None, n, node_id=5, input_ids=(4,), num_consumers=0, is_final_output=True,
+                                        input_mults=(-1,))
+    got = {0: ctx.download(add_rows).reshape(n, 15), 1: ctx.download(mul_rows).reshape(n, 16),
+           2: ctx.download(rec_rows).reshape(n, 13)}
+    for kind, rows in want:
+        assert np.array_equal(got[kind], rows), kind
+    cc = (a.astype(np.int64) * b) >> 12
+    assert np.array_equal(ctx.download(e, np.int32), (4096 * 4096) // (cc + w))
+    host = ctx.prove_tables([(k, r, len(r)) for k, r in want])
+    dev = ctx.prove_tables([(0, add_rows, n), (1, mul_rows, n), (2, rec_rows, n)])
+    assert dev == host
+    # two nodes of one kind share a table: the second node's rows are appended at row_offset
+    rows2, _ = ctx.trace_elementwise(0, da, db, n, node_id=9, input_ids=(6, 7), num_consumers=2, input_mults=(0, 0),
+                                     rows=ctx.alloc(2 * n * 15 * 4), row_offset=0)
+    ctx.trace_elementwise(0, db, dw, n, node_id=10, input_ids=(7, 8), num_consumers=0, is_final_output=True,
+                          input_mults=(0, 0), rows=rows2, row_offset=n)
+    both = ctx.download(rows2).reshape(2 * n, 15)
+    assert np.array_equal(both[:n], syn.add_rows(a, b, node=9, lhs_id=6, rhs_id=7, mults=(0, 0, 2)))
+    assert np.array_equal(both[n:], syn.add_rows(b, w, node=10, lhs_id=7, rhs_id=8, mults=(0, 0, 0)))
+    for buf in (da, db, dw, mul_rows, c, add_rows, d, rec_rows, e, rows2):
+        buf.free()

@@ -89,6 +89,12 @@ def test_emu_level2_ops(emu_ctx):
     check_quotient_fold_grind_ops(emu_ctx, 7)
 
 
+def test_emu_device_trace_generation(emu_ctx):
+    from level2_checks import check_device_trace_generation
+    check_device_trace_generation(emu_ctx, 300)
+    check_device_trace_generation(emu_ctx, 1)
+
+
 def test_emu_pinned_variant_with_inputs_component(root):
     """17-slot claim + Inputs table (mixed column sizes inside one Merkle tree)."""
     from oracle.channel import ProtocolVariant

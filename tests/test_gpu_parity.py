@@ -185,6 +185,13 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
         check_quotient_fold_grind_ops(ctx, log)
 
 
+def test_gpu_device_trace_generation(gpu_prover):
+    """§8f-3: Add / Mul / Recip `process_trace` on device tensors feeding lmn_prove without a host round trip."""
+    from level2_checks import check_device_trace_generation
+    for n in (1, 1000, (1 << 18) + 5):
+        check_device_trace_generation(gpu_prover.ctx, n)
+
+
 @pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
 def test_gpu_fft_tiled_equals_layerwise(gpu_prover, log):
     """Device-side differential check at full sizes: LDS-tiled passes vs one-layer-per-launch."""
