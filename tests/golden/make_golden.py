@@ -26,13 +26,21 @@ CASES = {
     "graph_faithful_100_seed3/pinned": (lambda: syn.config2_graph_faithful(100, 3), "PINNED"),
     "less_than_100_seed3/pinned": (lambda: syn.less_than_graph(100, 3), "PINNED"),
     "sqrt_rem_50_seed4/pinned": (lambda: syn.sqrt_rem_graph(50, 4), "PINNED"),
+    # generators returning (tables, luts): LUT components with their preprocessed columns
+    "activations_40_seed3/pinned": (lambda: syn.activation_graph(40, 3), "PINNED"),
+    "config5_3x4x5_seed8/kat": (lambda: syn.config5_linear_layers(3, 4, 5, 8), "KAT"),
 }
 
 
+def tables_and_luts(name):
+    out = CASES[name][0]()
+    return out if isinstance(out, tuple) else (out, None)
+
+
 def digest(name):
-    gen, variant = CASES[name]
-    tabs = gen()
-    proof = prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant[variant])
+    variant = CASES[name][1]
+    tabs, luts = tables_and_luts(name)
+    proof = prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant[variant], luts=luts)
     b = to_bincode(proof)
     return {"sha256": hashlib.sha256(b).hexdigest(), "len": len(b)}
 

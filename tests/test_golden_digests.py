@@ -27,7 +27,8 @@ def test_kat_digest_is_the_reference_file(kat_bytes):
 def test_gpu_reproduces_golden_digest(name, hip_lib_path):
     import luminair_amd
     from luminair_amd import backend
-    gen, variant = mg.CASES[name]
+    variant = mg.CASES[name][1]
+    tabs, luts = mg.tables_and_luts(name)
     prover = luminair_amd.Prover(0, protocol_variant=backend.VARIANT_PINNED if variant == "PINNED" else backend.VARIANT_KAT)
-    b = prover.prove(luminair_amd.LuminairPie.from_tables(gen())).to_bincode()
+    b = prover.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts)).to_bincode()
     assert {"sha256": hashlib.sha256(b).hexdigest(), "len": len(b)} == GOLD[name]
