@@ -72,3 +72,43 @@ def check_device_trace_generation(ctx, n, seed=21):
     assert np.array_equal(both[n:], syn.add_rows(b, w, node=10, lhs_id=7, rhs_id=8, mults=(0, 0, 0)))
     for buf in (da, db, dw, mul_rows, c, add_rows, d, rec_rows, e, rows2):
         buf.free()
+
+
+def random_pie(seed, scale=1):
+    """A pie of randomly chosen components with random (ragged) row counts; multiplicities are arbitrary
+    (prove does not need the logup sums to cancel), values satisfy every component's AIR."""
+    rng = np.random.default_rng(1000 + seed)
+    from luminair_amd import synthetic as syn
+    n = lambda: int(rng.integers(1, 700)) * scale
+    pool = {
+        0: lambda: syn.add_rows(rng.integers(-2048, 2048, size=(k := n())), rng.integers(-2048, 2048, size=k),
+                                mults=(-1, 0, 2)),
+        1: lambda: syn.mul_rows(rng.integers(0, 2048, size=(k := n())), rng.integers(0, 2048, size=k), node=5,
+                                mults=(0, -1, 1)),
+        2: lambda: syn.recip_rows(rng.integers(4, 2048, size=n()), node=7, mults=(-1, 1)),
+        5: lambda: syn.sum_reduce_rows(rng.integers(-100, 100, size=(int(rng.integers(1, 20)), int(rng.integers(1, 30)))),
+                                       node=8),
+        6: lambda: syn.max_reduce_rows(rng.integers(-100, 100, size=(int(rng.integers(1, 20)), int(rng.integers(1, 30)))),
+                                       node=9),
+        7: lambda: syn.sqrt_rows(rng.integers(1, 1 << 20, size=n()), node=10),
+        8: lambda: syn.rem_rows(rng.integers(1, 1 << 16, size=(k := n())), rng.integers(1, 4096, size=k), node=11),
+        15: lambda: syn.inputs_rows(rng.integers(-2048, 2048, size=n()), 12, 3),
+        16: lambda: syn.contiguous_rows(rng.integers(-2048, 2048, size=n()), node=13),
+    }
+    kinds = sorted(rng.choice(sorted(pool), size=int(rng.integers(2, 6)), replace=False).tolist())
+    tabs = [(k, pool[k]()) for k in kinds]
+    luts = None
+    if seed % 2 == 0:     # add a LUT op with its lookup table (and, every fourth seed, LessThan + range check)
+        name = ("sin", "exp2", "log2")[seed // 2 % 3]
+        lo, hi = {"sin": (-3000, 3000), "exp2": (-5000, 100), "log2": (1, 9000)}[name]
+        x = rng.integers(lo, hi + 1, size=n())
+        rows, counts = syn.unary_lut_rows(name, x, lo, node=14, input_id=20, mults=(0, 1))
+        lut = syn.make_lut(name, lo, hi)
+        kind, lk = syn._LUT_KINDS[name]
+        tabs += [(kind, rows), (lk, syn.lut_lookup_rows(counts, len(lut[0])))]
+        luts = {name: lut}
+    if seed % 4 == 0:
+        lt, counts = syn.less_than_rows(rng.integers(-4096, 4096, size=(k := n())), rng.integers(-4096, 4096, size=k),
+                                        node=15)
+        tabs += [(13, lt), (14, syn.range_check_lookup_rows(counts))]
+    return sorted(tabs, key=lambda t: t[0]), luts

@@ -139,3 +139,19 @@ def test_emu_pinned_variant_with_inputs_component(root):
     with pytest.raises(backend.LuminairBackendError) as e:
         kat_ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
     assert e.value.code == backend.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emu_random_pies_match_oracle(root, seed):
+    """Differential test over random component mixes and ragged sizes (mixed-size Merkle trees, several
+    composition sizes, tree-0 layouts), PINNED variant so that every component has a claim slot."""
+    from oracle.channel import ProtocolVariant
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    from level2_checks import random_pie
+    tabs, luts = random_pie(seed)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts)
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED, luts=luts))
+    assert got == want, [k for k, _ in tabs]

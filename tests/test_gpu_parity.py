@@ -185,6 +185,19 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
         check_quotient_fold_grind_ops(ctx, log)
 
 
+@pytest.mark.parametrize("seed,scale", [(0, 1), (1, 1), (2, 40), (3, 40), (4, 150), (5, 150)])
+def test_gpu_random_pies_equal_c_oracle(gpu_prover_pinned, c_oracle, seed, scale):
+    """Random component mixes with ragged sizes (up to ~10^5 rows): mixed-size Merkle trees, several
+    composition sizes, tree-0 layouts; byte-for-byte against the C oracle."""
+    from level2_checks import random_pie
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs, luts = random_pie(seed, scale)
+    got = gpu_prover_pinned.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts))
+    assert got.to_bincode() == to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=c_oracle, luts=luts))
+
+
 def test_gpu_device_trace_generation(gpu_prover):
     """§8f-3: Add / Mul / Recip `process_trace` on device tensors feeding lmn_prove without a host round trip."""
     from level2_checks import check_device_trace_generation
