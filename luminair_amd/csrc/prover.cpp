@@ -825,6 +825,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     uint64_t cells = (uint64_t)(sp->n_cols + 4 * sp->n_rel) << ls;
     words += cells * (2 + (1ull << lb));                       // evals + coeffs + lde
     if (!infos.back().on_device) words += tb.n_rows * sp->n_cols;  // staging
+    words += (uint64_t)sp->n_pre * (4ull << ls);               // preprocessed columns: evals + coeffs + lde
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
   }

@@ -68,3 +68,28 @@ def test_product_verifier_agrees_with_oracle_verifier_on_tampered_proofs(lib, ka
         assert prod_ok == ora_ok, off
         n_rej += not prod_ok
     assert n_rej > 100
+
+
+def test_product_verifier_survives_fuzzed_proofs(hip_lib_path, kat_bytes):
+    """Bit flips, truncations, overwritten length fields and inserted bytes: always a clean rejection
+    (LuminairBackendError), never a crash, never an acceptance."""
+    import random
+    from luminair_amd import backend
+    lib = backend.Library(hip_lib_path)
+    rnd = random.Random(7)
+    for it in range(800):
+        b = bytearray(kat_bytes)
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            b = b[:rnd.randrange(len(b))]
+        elif mode == 2:
+            i = rnd.randrange(len(b) - 8)
+            b[i:i + 8] = rnd.getrandbits(64).to_bytes(8, "little")
+        else:
+            i = rnd.randrange(len(b))
+            b[i:i] = bytes(rnd.getrandbits(8) for _ in range(rnd.randint(1, 64)))
+        with pytest.raises(backend.LuminairBackendError):
+            lib.verify(bytes(b), rnd.choice([0, 0, 0, 1]))
