@@ -13,7 +13,11 @@ LMN_HD uint32_t m_add(uint32_t a, uint32_t b) {
   uint32_t s = a + b;
   return s >= P31 ? s - P31 : s;
 }
-LMN_HD uint32_t m_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P31 - b; }
+LMN_HD uint32_t m_sub(uint32_t a, uint32_t b) {
+  // a >= b: d = a-b < P <= d+P; a < b: d wrapped (> 2^32-P), d+P wraps to a-b+P < P.  sub, add, min.
+  uint32_t d = a - b, e = d + P31;
+  return d < e ? d : e;
+}
 LMN_HD uint32_t m_neg(uint32_t a) { return a ? P31 - a : 0u; }
 LMN_HD uint32_t m_mul(uint32_t a, uint32_t b) {
   uint64_t p = (uint64_t)a * (uint64_t)b;
