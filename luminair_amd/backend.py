@@ -67,7 +67,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
-           "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise"]
+           "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -116,6 +116,8 @@ class Library:
         lib.lmn_op_grind.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.lmn_trace_sum_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                             C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_elementwise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                               C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
 
@@ -223,6 +225,20 @@ class Context:
                            (C.c_int32 * 2)(*mults))
         self._check(self.lib.lib.lmn_trace_elementwise(self.handle, kind, lhs.ptr, rhs.ptr if rhs is not None else None,
                                                        n, C.byref(info), rows.ptr, row_offset, out.ptr))
+        return rows, out
+
+    def trace_sum_reduce(self, inp: DeviceBuffer, front: int, dim: int, back: int, node_id: int, input_id: int,
+                         num_consumers: int, is_final_output: bool = False, input_mult: int = -1,
+                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0):
+        """`LuminairSumReduce::process_trace` on a contiguous (front, dim, back) int32 device tensor."""
+        n_rows, n_out = front * dim * back, front * back
+        if rows is None:
+            rows = self.alloc((row_offset + n_rows) * 14 * 4)
+        out = self.alloc(n_out * 4)
+        info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
+                           (C.c_int32 * 2)(input_mult, 0))
+        self._check(self.lib.lib.lmn_trace_sum_reduce(self.handle, inp.ptr, front, dim, back, C.byref(info), rows.ptr,
+                                                      row_offset, out.ptr))
         return rows, out
 
     def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:

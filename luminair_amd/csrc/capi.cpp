@@ -216,3 +216,9 @@ int lmn_trace_elementwise(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, c
   if (!ctx || !lhs_dev || !info || !rows_dev || (kind != LMN_KIND_RECIP && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, rhs_dev, n, *info, rows_dev, row_offset, out_dev); });
 }
+
+int lmn_trace_sum_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front, uint64_t dim, uint64_t back,
+                         const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->trace_sum_reduce(input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
+}

@@ -96,6 +96,9 @@ struct TraceNode {
 void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const TraceNode& nd,
                               uint32_t* rows, int32_t* out, lmn_stream_t s);
 
+void launch_trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const TraceNode& nd,
+                             uint32_t* rows, int32_t* out, lmn_stream_t s);
+
 // ---- a6: logup
 constexpr int LOGUP_MAX_REL = 7;
 struct LogupArgs {

@@ -102,6 +102,44 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* _
   for (uint32_t w = threadIdx.x; w < words; w += TPB) dst[w] = tile[(w / NC) * ST + (w % NC)];
 }
 
+// SumReduce rows (prim.rs:1486-1510, 1536-1561): row r = (i*back + j)*dim + k holds input[i, k, j], the
+// running sum before and after it, and the output on the group's last step.  One lane per row; the prefix
+// inside a group is re-summed per lane (dim is a tensor axis, at most a few hundred), rows leave through LDS.
+LMN_KERNEL k_trace_sum_reduce(const int32_t* __restrict__ input, uint64_t dim, uint64_t back, uint64_t n_rows,
+                              uint64_t n_out, TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
+  constexpr int NC = 14, ST = 15;
+  LMN_SHARED uint32_t tile[TPB * ST];
+  const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
+  const uint64_t r = row0 + threadIdx.x;
+  if (r < n_rows) {
+    const uint64_t g = r / dim, k = r % dim;  // output index (i*back + j), reduction step
+    const uint64_t i = g / back, j = g % back;
+    const int32_t* p = input + i * dim * back + j;
+    int64_t acc = 0;
+    for (uint64_t kk = 0; kk < k; ++kk) acc += p[kk * back];
+    const int64_t v = p[k * back], next = acc + v;
+    const bool last_step = k + 1 == dim;
+    uint32_t* t = tile + threadIdx.x * ST;
+    t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = (uint32_t)g; t[3] = g + 1 == n_out ? 1u : 0u;
+    t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = (uint32_t)g + 1u;
+    t[7] = fixed_to_m31(v); t[8] = last_step ? fixed_to_m31(next) : 0u;
+    t[9] = fixed_to_m31(acc); t[10] = fixed_to_m31(next); t[11] = last_step ? 1u : 0u;
+    t[12] = nd.lhs_mult; t[13] = last_step ? nd.out_mult : 0u;
+    if (last_step && out) out[g] = (int32_t)next;
+  }
+  __syncthreads();
+  const uint64_t rows_here = n_rows - row0 < (uint64_t)TPB ? n_rows - row0 : (uint64_t)TPB;
+  const uint32_t words = (uint32_t)rows_here * NC;
+  uint32_t* dst = rows + row0 * NC;
+  for (uint32_t w = threadIdx.x; w < words; w += TPB) dst[w] = tile[(w / NC) * ST + (w % NC)];
+}
+
+void launch_trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const TraceNode& nd,
+                             uint32_t* rows, int32_t* out, lmn_stream_t s) {
+  const uint64_t n_out = front * back, n_rows = n_out * dim;
+  LMN_LAUNCH(k_trace_sum_reduce, dim3(cdiv(n_rows, TPB)), dim3(TPB), 0, s, input, dim, back, n_rows, n_out, nd, rows, out);
+}
+
 void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const TraceNode& nd,
                               uint32_t* rows, int32_t* out, lmn_stream_t s) {
   dim3 g(cdiv(n, TPB)), b(TPB);

@@ -250,6 +250,30 @@ void Context::download(const void* device, void* host, size_t bytes) {
   lmn_sync(stream_);
 }
 
+static TraceNode trace_node(const lmn_node_info& info) {
+  auto m31 = [](int64_t v) { return (uint32_t)(((v % (int64_t)P31) + (int64_t)P31) % (int64_t)P31); };
+  TraceNode nd{};
+  nd.node_id = info.node_id;
+  nd.lhs_id = info.input_ids[0];
+  nd.rhs_id = info.input_ids[1];
+  nd.lhs_mult = m31(info.input_mults[0]);
+  nd.rhs_mult = m31(info.input_mults[1]);
+  nd.out_mult = info.is_final_output ? 0u : m31(info.num_consumers);
+  return nd;
+}
+
+// `LuminairSumReduce::process_trace` (prim.rs:1450-1565) on a contiguous (front, dim, back) device tensor
+void Context::trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
+                               const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  if (front == 0 || dim == 0 || back == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
+  if (front * back * dim >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
+  launch_trace_sum_reduce(input, front, dim, back, trace_node(info), rows + row_offset * 14ull, out, stream_);
+  lmn_sync(stream_);
+}
+
 // `process_trace` of one Add / Mul / Recip node on device tensors (prim.rs:967-1013, :1090-1139, :388-431)
 void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t* rhs, uint64_t n,
                                 const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
@@ -261,14 +285,7 @@ void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: kind must be Add, Mul or Recip");
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
-  auto m31 = [](int64_t v) { return (uint32_t)(((v % (int64_t)P31) + (int64_t)P31) % (int64_t)P31); };
-  TraceNode nd{};
-  nd.node_id = info.node_id;
-  nd.lhs_id = info.input_ids[0];
-  nd.rhs_id = info.input_ids[1];
-  nd.lhs_mult = m31(info.input_mults[0]);
-  nd.rhs_mult = m31(info.input_mults[1]);
-  nd.out_mult = info.is_final_output ? 0u : m31(info.num_consumers);
+  const TraceNode nd = trace_node(info);
   launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : 2), lhs, rhs, n, nd,
                            rows + row_offset * (uint64_t)sp->n_cols, out, stream_);
   lmn_sync(stream_);

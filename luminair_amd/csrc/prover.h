@@ -121,6 +121,8 @@ class Context {
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
   void download(const void* device, void* host, size_t bytes);
+  void trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const lmn_node_info& info,
+                        uint32_t* rows, uint64_t row_offset, int32_t* out);
   void trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const lmn_node_info& info,
                          uint32_t* rows, uint64_t row_offset, int32_t* out);
   void device_free(void* p);

@@ -112,3 +112,35 @@ def random_pie(seed, scale=1):
                                         node=15)
         tabs += [(13, lt), (14, syn.range_check_lookup_rows(counts))]
     return sorted(tabs, key=lambda t: t[0]), luts
+
+
+def check_device_linear_layer(ctx, n_out=20, dim=7, seed=2):
+    """Mul -> SumReduce -> Add on the device (the lowering of a linear layer): rows equal synthetic.linear_layer's,
+    the proof from device-resident tables equals the proof from host tables."""
+    from luminair_amd import synthetic as syn
+    want = dict(syn.linear_layer(n_out, dim, seed))
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 2048, size=(n_out, dim)).astype(np.int32)
+    w = rng.integers(0, 2048, size=(n_out, dim)).astype(np.int32)
+    b = rng.integers(-2048, 2048, size=n_out).astype(np.int32)
+    dx, dw, db = ctx.upload(x.reshape(-1)), ctx.upload(w.reshape(-1)), ctx.upload(b)
+    n = n_out * dim
+    mul_rows, prod = ctx.trace_elementwise(1, dx, dw, n, node_id=3, input_ids=(7, 8), num_consumers=1, input_mults=(0, 0))
+    sum_rows, y1 = ctx.trace_sum_reduce(prod, n_out, dim, 1, node_id=4, input_id=3, num_consumers=1)
+    add_rows, y = ctx.trace_elementwise(0, y1, db, n_out, node_id=5, input_ids=(4, 9), num_consumers=0,
+                                        is_final_output=True, input_mults=(-1, 0))
+    assert np.array_equal(ctx.download(mul_rows).reshape(n, 16), want[1])
+    assert np.array_equal(ctx.download(sum_rows).reshape(n, 14), want[5])
+    assert np.array_equal(ctx.download(add_rows).reshape(n_out, 15), want[0])
+    assert ctx.prove_tables([(0, add_rows, n_out), (1, mul_rows, n), (5, sum_rows, n)]) == \
+        ctx.prove_tables([(k, want[k], len(want[k])) for k in (0, 1, 5)])
+    # a middle axis: shape (front, dim, back) = (3, 5, 4)
+    t = rng.integers(-500, 500, size=(3, 5, 4)).astype(np.int32)
+    dt = ctx.upload(t.reshape(-1))
+    rows, out = ctx.trace_sum_reduce(dt, 3, 5, 4, node_id=11, input_id=10, num_consumers=2)
+    groups = t.transpose(0, 2, 1).reshape(12, 5)          # (i, j) groups, k along the row
+    assert np.array_equal(ctx.download(rows).reshape(60, 14),
+                          syn.sum_reduce_rows(groups, node=11, input_id=10, input_mult=-1, out_mult=2))
+    assert np.array_equal(ctx.download(out, np.int32), groups.sum(axis=1))
+    for buf in (dx, dw, db, mul_rows, prod, sum_rows, y1, add_rows, y, dt, rows, out):
+        buf.free()

@@ -93,6 +93,8 @@ def test_emu_device_trace_generation(emu_ctx):
     from level2_checks import check_device_trace_generation
     check_device_trace_generation(emu_ctx, 300)
     check_device_trace_generation(emu_ctx, 1)
+    from level2_checks import check_device_linear_layer
+    check_device_linear_layer(emu_ctx)
 
 
 def test_emu_pinned_variant_with_inputs_component(root):

@@ -203,6 +203,9 @@ def test_gpu_device_trace_generation(gpu_prover):
     from level2_checks import check_device_trace_generation
     for n in (1, 1000, (1 << 18) + 5):
         check_device_trace_generation(gpu_prover.ctx, n)
+    from level2_checks import check_device_linear_layer
+    check_device_linear_layer(gpu_prover.ctx)
+    check_device_linear_layer(gpu_prover.ctx, n_out=300, dim=129, seed=5)
 
 
 @pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
