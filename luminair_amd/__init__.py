@@ -7,7 +7,8 @@ gfx950 behind the C ABI of `include/luminair_hip.h`; there is no CPU fallback.
 """
 from .pie import (CircuitSettings, ExecutionResources, LuminairError, LuminairPie, LuminairProof, Metadata,
                   TraceTable, TraceTableKind)
+from .graph import DeviceGraph
 from .prover import Prover, prove, verify
 
 __all__ = ["CircuitSettings", "ExecutionResources", "LuminairError", "LuminairPie", "LuminairProof", "Metadata",
-           "TraceTable", "TraceTableKind", "Prover", "prove", "verify"]
+           "TraceTable", "TraceTableKind", "Prover", "prove", "verify", "DeviceGraph"]

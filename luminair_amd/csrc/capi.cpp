@@ -213,7 +213,7 @@ int lmn_download(lmn_ctx* ctx, const void* device, void* host, size_t bytes) {
 
 int lmn_trace_elementwise(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const int32_t* rhs_dev, uint64_t n,
                           const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
-  if (!ctx || !lhs_dev || !info || !rows_dev || (kind != LMN_KIND_RECIP && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
+  if (!ctx || !lhs_dev || !info || !rows_dev || ((kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, rhs_dev, n, *info, rows_dev, row_offset, out_dev); });
 }
 

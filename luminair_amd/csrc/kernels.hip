@@ -57,7 +57,7 @@ LMN_HD uint32_t fixed_to_m31(int64_t v) { return v >= 0 ? (uint32_t)v : (uint32_
 template <int KIND>
 LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* __restrict__ rhs, uint64_t n,
                                TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
-  constexpr int NC = KIND == 0 ? 15 : (KIND == 1 ? 16 : 13);
+  constexpr int NC = KIND == 0 ? 15 : (KIND == 1 ? 16 : (KIND == 2 ? 13 : 7));
   constexpr int ST = NC | 1;  // odd LDS row stride: conflict-free column writes
   LMN_SHARED uint32_t tile[TPB * ST];
   const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
@@ -66,7 +66,12 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* _
     uint32_t* t = tile + threadIdx.x * ST;
     const int64_t a = lhs[r];
     const uint32_t idx = (uint32_t)r, last = r + 1 == n ? 1u : 0u;
-    if (KIND == 2) {
+    if (KIND == 15) {
+      // CopyToStwo / Inputs (prim.rs:52-88): node, idx, is_last, next_node, next_idx, val, multiplicity
+      t[0] = nd.node_id; t[1] = idx; t[2] = last; t[3] = nd.node_id; t[4] = idx + 1u;
+      t[5] = fixed_to_m31(a); t[6] = nd.out_mult;
+      if (out) out[r] = (int32_t)a;
+    } else if (KIND == 2) {
       // node, input, idx, is_last, next_node, next_input, next_idx, input, out, rem, scale, in_mult, out_mult
       const int64_t sc2 = 4096ll * 4096ll;
       const int64_t o = sc2 / a, rem = sc2 - a * o;
@@ -147,6 +152,7 @@ void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, 
     case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
     case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
     case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
+    case 15: LMN_LAUNCH(k_trace_elementwise<15>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
     default: throw LmnError(-100, "trace_elementwise: unsupported kind");
   }
 }

@@ -281,12 +281,12 @@ void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   const ComponentSpec* sp = component_spec((int)kind);
-  if (!sp || (kind != LMN_KIND_ADD && kind != LMN_KIND_MUL && kind != LMN_KIND_RECIP))
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: kind must be Add, Mul or Recip");
+  if (!sp || (kind != LMN_KIND_ADD && kind != LMN_KIND_MUL && kind != LMN_KIND_RECIP && kind != LMN_KIND_INPUTS))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: kind must be Add, Mul, Recip or Inputs");
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
   const TraceNode nd = trace_node(info);
-  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : 2), lhs, rhs, n, nd,
+  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : (kind == LMN_KIND_RECIP ? 2 : 15)), lhs, rhs, n, nd,
                            rows + row_offset * (uint64_t)sp->n_cols, out, stream_);
   lmn_sync(stream_);
 }

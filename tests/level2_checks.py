@@ -144,3 +144,64 @@ def check_device_linear_layer(ctx, n_out=20, dim=7, seed=2):
     assert np.array_equal(ctx.download(out, np.int32), groups.sum(axis=1))
     for buf in (dx, dw, db, mul_rows, prod, sum_rows, y1, add_rows, y, dt, rows, out):
         buf.free()
+
+
+def check_device_graph(lib, device=0):
+    """`DeviceGraph` (host mirror of gen_trace over the device-side process_trace kernels): the simple example
+    c = a*b; d = c + w; e = c*d and a linear layer y = sum(x*w, axis=1) + b, HEAD multiplicities.  The tables
+    equal the host generators' rows, and the proofs pass the verifier (the logup sums of a whole graph cancel)."""
+    from luminair_amd import synthetic as syn
+    from luminair_amd.graph import DeviceGraph
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend_mod().VARIANT_PINNED
+    ctx = backend_mod().Context(device, cfg, lib)
+    S = 4096
+    a = np.array([[1, 2], [3, 4]]) * S
+    b = np.array([[10, 20], [30, 40]]) * S
+    w = np.array([[-1, -1], [-1, -1]]) * S
+    g = DeviceGraph(ctx)
+    ta, tb, tw = g.input(a), g.input(b), g.input(w)
+    tc = g.mul(ta, tb)
+    td = g.add(tc, tw)
+    te = g.output(g.mul(tc, td))
+    tables, bufs = g.gen_trace()
+    c = (a * b) >> 12
+    d = c + w
+    assert np.array_equal(g.read(te), (c * d) >> 12)
+    got = {k: ctx.download(buf).reshape(n, -1) for k, buf, n in tables}
+    assert sorted(got) == [0, 1, 15]
+    f = lambda x: x.reshape(-1)
+    assert np.array_equal(got[0], syn.add_rows(f(c), f(w), node=4, lhs_id=3, rhs_id=2, mults=(-1, -1, 1)))
+    assert np.array_equal(got[1], np.concatenate([
+        syn.mul_rows(f(a), f(b), node=3, lhs_id=0, rhs_id=1, mults=(-1, -1, 2)),
+        syn.mul_rows(f(c), f(d), node=5, lhs_id=3, rhs_id=4, mults=(-1, -1, 0))]))
+    assert np.array_equal(got[15], np.concatenate([syn.inputs_rows(f(a), 0, 1), syn.inputs_rows(f(b), 1, 1),
+                                                   syn.inputs_rows(f(w), 2, 1)]))
+    proof = ctx.prove_tables(tables)
+    lib.verify(proof, backend_mod().VARIANT_PINNED)
+    assert proof == ctx.prove_tables([(k, got[k], len(got[k])) for k in sorted(got)])
+    for buf in bufs:
+        buf.free()
+    # linear layer: y = sum(x * w, axis=1) + bias, then 1/y on positive data
+    rng = np.random.default_rng(3)
+    x = rng.integers(1, 2048, size=(12, 9))
+    wt = rng.integers(1, 2048, size=(12, 9))
+    bias = rng.integers(1, 2048, size=12)
+    g = DeviceGraph(ctx)
+    tx, twt, tbias = g.input(x), g.input(wt), g.input(bias)
+    ty = g.add(g.sum_reduce(g.mul(tx, twt), axis=1), tbias)
+    tz = g.output(g.recip(ty))
+    tables, bufs = g.gen_trace()
+    y = ((x * wt) >> 12).sum(axis=1) + bias
+    assert np.array_equal(g.read(tz), (S * S) // y)
+    assert [k for k, _, _ in tables] == [0, 1, 2, 5, 15]
+    proof = ctx.prove_tables(tables)
+    lib.verify(proof, backend_mod().VARIANT_PINNED)
+    for buf in bufs:
+        buf.free()
+    ctx.close()
+
+
+def backend_mod():
+    from luminair_amd import backend
+    return backend

@@ -208,6 +208,13 @@ def test_gpu_device_trace_generation(gpu_prover):
     check_device_linear_layer(gpu_prover.ctx, n_out=300, dim=129, seed=5)
 
 
+def test_gpu_device_graph_gen_trace_then_prove(hip_lib_path):
+    """gen_trace on the device (DeviceGraph over lmn_trace_*) -> lmn_prove on device-resident tables -> lmn_verify."""
+    from level2_checks import check_device_graph
+    from luminair_amd import backend
+    check_device_graph(backend.Library(hip_lib_path))
+
+
 @pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
 def test_gpu_fft_tiled_equals_layerwise(gpu_prover, log):
     """Device-side differential check at full sizes: LDS-tiled passes vs one-layer-per-launch."""
