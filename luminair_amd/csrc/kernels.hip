@@ -271,12 +271,11 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
   const uint64_t span = src_len > base ? src_len - base : 0;
   const uint32_t lim = span > 0x10000000ull ? 0x10000000u : (uint32_t)span;  // readable words from tsrc
   // The 2^R points of a group sit at tile index e0 + (j << p) (bits [p, p+R) of e0 are zero), so both
-  // address maps are affine in j: global offset ((e >> cb) << lo) + (e & cmask) has stride
-  // 2^(p - cb + lo) (p >= cb always), and the padded LDS index e + (e >> 5) has stride 2^p + 2^(p-5)
-  // when p >= 5.  One add per point instead of re-deriving each address.
+  // address maps split into a per-lane base plus a wave-uniform term in j: global offset
+  // ((e >> cb) << lo) + (e & cmask) has stride 2^(p - cb + lo) (p >= cb always), and the padded LDS index
+  // pad(e) = e + (e >> 5) satisfies pad(e0 + (j << p)) = pad(e0) + pad(j << p) because the two addends
+  // occupy disjoint bits (no carry into bit 5).  One add per point instead of re-deriving each address.
   const uint32_t gstride = 1u << (p - cb + lo);
-  const bool lds_affine = p >= 5;
-  const uint32_t lstride = lds_affine ? (1u << p) + (1u << (p - 5)) : 0u;
   const uint32_t tile_span = (((tile_elems - 1u) >> cb) << lo) + cmask + 1u;  // words of [tsrc, ...) the tile touches
   const bool full = tile_span <= lim;                                           // block-uniform: no zero-extension here
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
@@ -310,13 +309,10 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
           v[j] = off < lim ? tsrc[off] : 0u;
         }
       }
-    } else if (lds_affine) {
+    } else {
       const uint32_t pb = fft_lds_pad(e0);
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) v[j] = sm[pb + (uint32_t)j * lstride];
-    } else {
-#pragma unroll
-      for (int j = 0; j < (1 << R); ++j) v[j] = sm[fft_lds_pad(e0 + ((uint32_t)j << p))];
+      for (int j = 0; j < (1 << R); ++j) v[j] = sm[pb + fft_lds_pad((uint32_t)j << p)];
     }
     const uint32_t m0 = e0 >> cb;
     radix_butterflies<R, INV>(v, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
@@ -333,13 +329,10 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) tdst[off0 + (uint32_t)j * gstride] = v[j];
       }
-    } else if (lds_affine) {
+    } else {
       const uint32_t pb = fft_lds_pad(e0);
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) sm[pb + (uint32_t)j * lstride] = v[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < (1 << R); ++j) sm[fft_lds_pad(e0 + ((uint32_t)j << p))] = v[j];
+      for (int j = 0; j < (1 << R); ++j) sm[pb + fft_lds_pad((uint32_t)j << p)] = v[j];
     }
   }
 }
