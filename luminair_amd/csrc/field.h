@@ -80,11 +80,25 @@ LMN_HD QM31 q_neg(QM31 x) { return {m_neg(x.a), m_neg(x.b), m_neg(x.c), m_neg(x.
 LMN_HD QM31 q_add_m(QM31 x, uint32_t m) { return {m_add(x.a, m), x.b, x.c, x.d}; }
 LMN_HD QM31 q_sub_m(QM31 x, uint32_t m) { return {m_sub(x.a, m), x.b, x.c, x.d}; }
 LMN_HD QM31 q_mul_m(QM31 x, uint32_t m) { return {m_mul(x.a, m), m_mul(x.b, m), m_mul(x.c, m), m_mul(x.d, m)}; }
+// (A + B u)(C + D u) with u^2 = 2 + i:  lo = A C + (2+i) B D,  hi = A D + B C.  Written out per
+// coordinate, every output is a sum of exactly four products once the signs and the factor (2+i) are
+// folded into the left operands (P - v for negation, canonical doubles, three M31 sums):
+//   lo.re = xa ya - xb yb + (2xc - xd) yc - (2xd + xc) yd
+//   lo.im = xa yb + xb ya + (xc + 2xd) yc + (2xc - xd) yd
+//   hi.re = xa yc - xb yd + xc ya - xd yb          hi.im = xa yd + xb yc + xc yb + xd ya
+// Four products of 31-bit values fit one 64-bit accumulator (4 (2^31-1)^2 < 2^64), so each coordinate is
+// four v_mad_u64_u32 and ONE reduction instead of four multiply-reduce and three add-reduce steps.
 LMN_HD QM31 q_mul(QM31 x, QM31 y) {
-  CM31 A{x.a, x.b}, B{x.c, x.d}, C{y.a, y.b}, D{y.c, y.d};
-  CM31 lo = c_add(c_mul(A, C), c_mul_r(c_mul(B, D)));
-  CM31 hi = c_add(c_mul(A, D), c_mul(B, C));
-  return {lo.a, lo.b, hi.a, hi.b};
+  const uint32_t nb = P31 - x.b, nd = P31 - x.d;               // -xb, -xd (P itself stands for 0)
+  const uint32_t c2 = m_dbl(x.c), d2 = m_dbl(x.d);
+  const uint32_t e1 = m_sub(c2, x.d);                           // 2xc - xd
+  const uint32_t e2 = P31 - m_add(d2, x.c);                     // -(2xd + xc)
+  const uint32_t f1 = m_add(x.c, d2);                           // xc + 2xd
+  const uint64_t lre = (uint64_t)x.a * y.a + (uint64_t)nb * y.b + (uint64_t)e1 * y.c + (uint64_t)e2 * y.d;
+  const uint64_t lim = (uint64_t)x.a * y.b + (uint64_t)x.b * y.a + (uint64_t)f1 * y.c + (uint64_t)e1 * y.d;
+  const uint64_t hre = (uint64_t)x.a * y.c + (uint64_t)nb * y.d + (uint64_t)x.c * y.a + (uint64_t)nd * y.b;
+  const uint64_t him = (uint64_t)x.a * y.d + (uint64_t)x.b * y.c + (uint64_t)x.c * y.b + (uint64_t)x.d * y.a;
+  return {m_red64(lre), m_red64(lim), m_red64(hre), m_red64(him)};
 }
 LMN_HD QM31 q_sqr(QM31 x) { return q_mul(x, x); }
 
