@@ -661,7 +661,9 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair
                                  const std::map<int, std::vector<uint32_t>>& queries, std::vector<Ref>& queried,
                                  std::vector<Ref>& hash_wit, std::vector<Ref>& col_wit) {
   size_t pos = 0;
-  std::vector<uint32_t> last;
+  std::vector<uint32_t> last, total;
+  last.reserve(16);
+  total.reserve(16);
   for (int log = m.max_log; log >= 0; --log) {
     size_t start = pos;
     while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
@@ -670,7 +672,7 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair
     auto it = queries.find(log);
     const std::vector<uint32_t>& colq = it != queries.end() ? it->second : kNone;
     size_t pi = 0, ci = 0;
-    std::vector<uint32_t> total;
+    total.clear();
     while (pi < last.size() || ci < colq.size()) {
       uint32_t node;
       if (pi < last.size() && ci < colq.size())
@@ -1415,6 +1417,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     StageTimer st(this, log, stream_, C_DECOMMIT);
     struct Plan {
       std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
+      Plan() {
+        fri_wit.reserve(64);
+        queried.reserve(256);
+        hash_wit.reserve(128);
+        col_wit.reserve(256);
+      }
     };
     std::vector<Plan> plans;  // [first, inner..., tree0..3]
     plans.reserve(inner.size() + 5);
@@ -1478,6 +1486,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     size_t g = 0;
     auto take_q = [&](size_t nrefs) {
       std::vector<QM31> v;
+      v.reserve(nrefs / 4);
       for (size_t i = 0; i < nrefs / 4; ++i) {
         v.push_back({gathered[g], gathered[g + 1], gathered[g + 2], gathered[g + 3]});
         g += 4;
