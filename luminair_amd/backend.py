@@ -44,6 +44,19 @@ class LmnSettings(C.Structure):
 LUT_KINDS = {"sin": 0, "exp2": 1, "log2": 2}   # LMN_LUT_*
 
 
+class LmnView(C.Structure):
+    """Strided view of a device tensor (`lmn_view`): shape of the op's output, strides in elements, 0 = expanded."""
+    _fields_ = [("ndim", C.c_uint32), ("shape", C.c_uint32 * 4), ("strides", C.c_int64 * 4)]
+
+    @staticmethod
+    def make(shape, strides) -> "LmnView":
+        n = len(shape)
+        if not 1 <= n <= 4:
+            raise ValueError("views have 1..4 dimensions")
+        return LmnView(n, (C.c_uint32 * 4)(*(list(shape) + [0] * (4 - n))),
+                       (C.c_int64 * 4)(*(list(strides) + [0] * (4 - n))))
+
+
 class LmnNodeInfo(C.Structure):
     """`NodeInfo` fields `process_trace` reads (crates/graph/src/utils.rs / op/prim.rs:980-990)."""
     _fields_ = [("node_id", C.c_uint32), ("input_ids", C.c_uint32 * 2), ("num_consumers", C.c_uint32),
@@ -67,7 +80,8 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
-           "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce"]
+           "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
+           "lmn_trace_elementwise_v", "lmn_trace_lut"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -116,6 +130,12 @@ class Library:
         lib.lmn_op_grind.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.lmn_trace_elementwise_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_void_p,
+                                                C.POINTER(LmnView), C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p,
+                                                C.c_uint64, C.c_void_p]
+        lib.lmn_trace_lut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_uint64,
+                                      C.POINTER(LmnNodeInfo), C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_void_p]
         lib.lmn_trace_sum_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                              C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_elementwise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -212,7 +232,8 @@ class Context:
 
     def trace_elementwise(self, kind: int, lhs: DeviceBuffer, rhs: Optional[DeviceBuffer], n: int, node_id: int,
                           input_ids, num_consumers: int, is_final_output: bool = False, input_mults=(-1, -1),
-                          rows: Optional[DeviceBuffer] = None, row_offset: int = 0):
+                          rows: Optional[DeviceBuffer] = None, row_offset: int = 0,
+                          lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None):
         """`process_trace` of one Add / Mul / Recip node on device tensors (int32 Fixed<12> values).
         Returns (rows DeviceBuffer, out DeviceBuffer)."""
         ncols = self.lib.kind_columns(kind)
@@ -223,8 +244,29 @@ class Context:
         mults = list(input_mults) + [0] * (2 - len(input_mults))
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(*ids), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(*mults))
-        self._check(self.lib.lib.lmn_trace_elementwise(self.handle, kind, lhs.ptr, rhs.ptr if rhs is not None else None,
-                                                       n, C.byref(info), rows.ptr, row_offset, out.ptr))
+        if lhs_view is None and rhs_view is None:
+            self._check(self.lib.lib.lmn_trace_elementwise(self.handle, kind, lhs.ptr, rhs.ptr if rhs is not None else None,
+                                                           n, C.byref(info), rows.ptr, row_offset, out.ptr))
+        else:
+            self._check(self.lib.lib.lmn_trace_elementwise_v(
+                self.handle, kind, lhs.ptr, C.byref(lhs_view) if lhs_view is not None else None,
+                rhs.ptr if rhs is not None else None, C.byref(rhs_view) if rhs_view is not None else None, n,
+                C.byref(info), rows.ptr, row_offset, out.ptr))
+        return rows, out
+
+    def trace_lut(self, kind: int, inp: DeviceBuffer, n: int, node_id: int, input_id: int, num_consumers: int,
+                  lut_col1: DeviceBuffer, lo: int, lut_len: int, mult: DeviceBuffer, is_final_output: bool = False,
+                  input_mult: int = -1, view: Optional[LmnView] = None, rows: Optional[DeviceBuffer] = None,
+                  row_offset: int = 0):
+        """`process_trace` of a Sin / Exp2 / Log2 node; `mult` (the lookup component's table) is updated in place."""
+        if rows is None:
+            rows = self.alloc((row_offset + n) * 12 * 4)
+        out = self.alloc(n * 4)
+        info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
+                           (C.c_int32 * 2)(input_mult, 0))
+        self._check(self.lib.lib.lmn_trace_lut(self.handle, kind, inp.ptr, C.byref(view) if view is not None else None, n,
+                                               C.byref(info), lut_col1.ptr, lo, lut_len, mult.ptr, rows.ptr, row_offset,
+                                               out.ptr))
         return rows, out
 
     def trace_sum_reduce(self, inp: DeviceBuffer, front: int, dim: int, back: int, node_id: int, input_id: int,

@@ -214,11 +214,30 @@ int lmn_download(lmn_ctx* ctx, const void* device, void* host, size_t bytes) {
 int lmn_trace_elementwise(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const int32_t* rhs_dev, uint64_t n,
                           const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
   if (!ctx || !lhs_dev || !info || !rows_dev || ((kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
-  return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, rhs_dev, n, *info, rows_dev, row_offset, out_dev); });
+  return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, nullptr, rhs_dev, nullptr, n, *info, rows_dev, row_offset, out_dev); });
 }
 
 int lmn_trace_sum_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front, uint64_t dim, uint64_t back,
                          const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
   if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->trace_sum_reduce(input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
+}
+
+int lmn_trace_elementwise_v(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const lmn_view* lhs_view,
+                            const int32_t* rhs_dev, const lmn_view* rhs_view, uint64_t n, const lmn_node_info* info,
+                            uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !lhs_dev || !info || !rows_dev || ((kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) && !rhs_dev))
+    return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] {
+    ctx->impl->trace_elementwise(kind, lhs_dev, lhs_view, rhs_dev, rhs_view, n, *info, rows_dev, row_offset, out_dev);
+  });
+}
+
+int lmn_trace_lut(lmn_ctx* ctx, uint32_t kind, const int32_t* input_dev, const lmn_view* view, uint64_t n,
+                  const lmn_node_info* info, const uint32_t* lut_col1_dev, int32_t lo, uint32_t lut_len,
+                  uint32_t* mult_dev, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !input_dev || !info || !lut_col1_dev || !mult_dev || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] {
+    ctx->impl->trace_lut(kind, input_dev, view, n, *info, lut_col1_dev, lo, lut_len, mult_dev, rows_dev, row_offset, out_dev);
+  });
 }

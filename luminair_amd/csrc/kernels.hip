@@ -54,9 +54,21 @@ void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int 
 // =============================================================================================
 LMN_HD uint32_t fixed_to_m31(int64_t v) { return v >= 0 ? (uint32_t)v : (uint32_t)((int64_t)P31 + v); }
 
+LMN_D uint64_t view_offset(const TraceView& v, uint64_t r) {
+  if (v.ndim == 0) return r;
+  int64_t off = 0;
+  for (int k = (int)v.ndim - 1; k >= 0; --k) {
+    const uint64_t d = v.shape[k];
+    off += (int64_t)(r % d) * v.strides[k];
+    r /= d;
+  }
+  return (uint64_t)off;
+}
+
 template <int KIND>
-LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* __restrict__ rhs, uint64_t n,
-                               TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
+LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, const int32_t* __restrict__ rhs,
+                               TraceView rv, uint64_t n, TraceNode nd, uint32_t* __restrict__ rows,
+                               int32_t* __restrict__ out) {
   constexpr int NC = KIND == 0 ? 15 : (KIND == 1 ? 16 : (KIND == 2 ? 13 : 7));
   constexpr int ST = NC | 1;  // odd LDS row stride: conflict-free column writes
   LMN_SHARED uint32_t tile[TPB * ST];
@@ -64,7 +76,7 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* _
   const uint64_t r = row0 + threadIdx.x;
   if (r < n) {
     uint32_t* t = tile + threadIdx.x * ST;
-    const int64_t a = lhs[r];
+    const int64_t a = lhs[view_offset(lv, r)];
     const uint32_t idx = (uint32_t)r, last = r + 1 == n ? 1u : 0u;
     if (KIND == 15) {
       // CopyToStwo / Inputs (prim.rs:52-88): node, idx, is_last, next_node, next_idx, val, multiplicity
@@ -81,7 +93,7 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, const int32_t* _
       t[11] = nd.lhs_mult; t[12] = nd.out_mult;
       if (out) out[r] = (int32_t)o;
     } else {
-      const int64_t b = rhs[r];
+      const int64_t b = rhs[view_offset(rv, r)];
       t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = nd.rhs_id; t[3] = idx; t[4] = last;
       t[5] = nd.node_id; t[6] = nd.lhs_id; t[7] = nd.rhs_id; t[8] = idx + 1u;
       t[9] = fixed_to_m31(a); t[10] = fixed_to_m31(b);
@@ -145,16 +157,55 @@ void launch_trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim,
   LMN_LAUNCH(k_trace_sum_reduce, dim3(cdiv(n_rows, TPB)), dim3(TPB), 0, s, input, dim, back, n_rows, n_out, nd, rows, out);
 }
 
-void launch_trace_elementwise(int kind, const int32_t* lhs, const int32_t* rhs, uint64_t n, const TraceNode& nd,
-                              uint32_t* rows, int32_t* out, lmn_stream_t s) {
+void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv, const int32_t* rhs, const TraceView& rv,
+                              uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, lmn_stream_t s) {
   dim3 g(cdiv(n, TPB)), b(TPB);
   switch (kind) {
-    case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
-    case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
-    case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
-    case 15: LMN_LAUNCH(k_trace_elementwise<15>, g, b, 0, s, lhs, rhs, n, nd, rows, out); break;
+    case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
+    case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
+    case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
+    case 15: LMN_LAUNCH(k_trace_elementwise<15>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
     default: throw LmnError(-100, "trace_elementwise: unsupported kind");
   }
+}
+
+// Sin / Exp2 / Log2 rows (sin/table.rs: node, input, idx, is_last, next_node, next_input, next_idx, input, out,
+// input_mult, out_mult, lookup_mult) with out read from the LUT's output column, plus the LUT multiplicities.
+LMN_KERNEL k_trace_lut(const int32_t* __restrict__ input, TraceView view, uint64_t n, TraceNode nd,
+                       const uint32_t* __restrict__ lut1, int32_t lo, uint32_t lut_len, uint32_t* __restrict__ mult,
+                       uint32_t* __restrict__ rows, int32_t* __restrict__ out, uint32_t* __restrict__ err_flag) {
+  constexpr int NC = 12, ST = 13;
+  LMN_SHARED uint32_t tile[TPB * ST];
+  const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
+  const uint64_t r = row0 + threadIdx.x;
+  if (r < n) {
+    const int64_t a = input[view_offset(view, r)];
+    const int64_t li = a - (int64_t)lo;
+    uint32_t ow = 0u;
+    if (li < 0 || li >= (int64_t)lut_len) {
+      *err_flag = 1u;
+    } else {
+      ow = lut1[li];
+      atomicAdd(&mult[li], 1u);
+    }
+    uint32_t* t = tile + threadIdx.x * ST;
+    t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = (uint32_t)r; t[3] = r + 1 == n ? 1u : 0u;
+    t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = (uint32_t)r + 1u;
+    t[7] = fixed_to_m31(a); t[8] = ow; t[9] = nd.lhs_mult; t[10] = nd.out_mult; t[11] = 1u;
+    if (out) out[r] = ow > (P31 >> 1) ? (int32_t)ow - (int32_t)P31 : (int32_t)ow;
+  }
+  __syncthreads();
+  const uint64_t rows_here = n - row0 < (uint64_t)TPB ? n - row0 : (uint64_t)TPB;
+  const uint32_t words = (uint32_t)rows_here * NC;
+  uint32_t* dst = rows + row0 * NC;
+  for (uint32_t w = threadIdx.x; w < words; w += TPB) dst[w] = tile[(w / NC) * ST + (w % NC)];
+}
+
+void launch_trace_lut(const int32_t* input, const TraceView& view, uint64_t n, const TraceNode& nd,
+                      const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                      int32_t* out, uint32_t* err_flag, lmn_stream_t s) {
+  LMN_LAUNCH(k_trace_lut, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, input, view, n, nd, lut_col1, lo, lut_len, mult, rows, out,
+             err_flag);
 }
 
 // =============================================================================================

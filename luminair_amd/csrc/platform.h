@@ -134,6 +134,11 @@ inline unsigned lmn_shfl_xor(unsigned v, int mask) {  // all lanes of the block 
   lmn_emu_syncthreads();
   return r;
 }
+inline unsigned atomicAdd(unsigned* p, unsigned v) {  // fibers are cooperative: no real concurrency
+  unsigned o = *p;
+  *p += v;
+  return o;
+}
 inline unsigned lmn_quad_perm(unsigned v, int ctrl) {  // all lanes of the block must call it together
   lmn_emu_shfl_scratch[threadIdx.x] = v;
   lmn_emu_syncthreads();

@@ -275,8 +275,49 @@ void Context::trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t di
 }
 
 // `process_trace` of one Add / Mul / Recip node on device tensors (prim.rs:967-1013, :1090-1139, :388-431)
-void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t* rhs, uint64_t n,
-                                const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
+static TraceView trace_view(const lmn_view* v, uint64_t n) {
+  TraceView t{};
+  if (!v) return t;
+  if (v->ndim < 1 || v->ndim > 4) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: ndim must be 1..4");
+  uint64_t prod = 1;
+  t.ndim = v->ndim;
+  for (uint32_t k = 0; k < v->ndim; ++k) {
+    if (v->shape[k] == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: empty dimension");
+    t.shape[k] = v->shape[k];
+    t.strides[k] = v->strides[k];
+    prod *= v->shape[k];
+  }
+  if (prod != n) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: shape does not match the element count");
+  return t;
+}
+
+// `process_trace` of a Sin / Exp2 / Log2 node on a device tensor; fills the LUT multiplicity column too
+void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* view, uint64_t n, const lmn_node_info& info,
+                        const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                        uint64_t row_offset, int32_t* out) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  if (kind != LMN_KIND_SIN && kind != LMN_KIND_EXP2 && kind != LMN_KIND_LOG2)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: kind must be Sin, Exp2 or Log2");
+  if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
+  if (n >= (1ull << 31) || lut_len == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad sizes");
+  const TraceView tv = trace_view(view, n);
+  uint32_t zero = 0u;
+  uint32_t* d_err = (uint32_t*)lmn_dev_malloc(4);
+  lmn_h2d(d_err, &zero, 4, stream_);
+  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, lo, lut_len, mult, rows + row_offset * 12ull, out, d_err,
+                   stream_);
+  uint32_t err = 0;
+  lmn_d2h(&err, d_err, 4, stream_);
+  lmn_sync(stream_);
+  lmn_dev_free(d_err);
+  if (err) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: an input value lies outside the LUT's range");
+}
+
+void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_view* lv, const int32_t* rhs,
+                                const lmn_view* rv, uint64_t n, const lmn_node_info& info, uint32_t* rows,
+                                uint64_t row_offset, int32_t* out) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
@@ -286,7 +327,8 @@ void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const int32_t
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
   const TraceNode nd = trace_node(info);
-  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : (kind == LMN_KIND_RECIP ? 2 : 15)), lhs, rhs, n, nd,
+  const TraceView tlv = trace_view(lv, n), trv = trace_view(rv, n);
+  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : (kind == LMN_KIND_RECIP ? 2 : 15)), lhs, tlv, rhs, trv, n, nd,
                            rows + row_offset * (uint64_t)sp->n_cols, out, stream_);
   lmn_sync(stream_);
 }

@@ -1,5 +1,6 @@
 """Device-side `gen_trace` for graphs of the primitives whose `process_trace` runs on the GPU
-(Add, Mul, Recip, SumReduce and the graph inputs): a small host mirror of
+(Add, Mul, Recip, SumReduce, the LUT ops Sin / Exp2 / Log2 with their lookup tables, and the graph inputs,
+with expanded ("fake") dimensions as in luminal's ShapeTracker): a small host mirror of
 `LuminairGraph::gen_trace` (`crates/graph/src/graph.rs:161-604`) over `lmn_trace_elementwise` /
 `lmn_trace_sum_reduce`.  Nodes execute in creation (= topological) order, every tensor stays in HBM
 as int32 `Fixed<12>` values, each node appends its rows to its kind's device-resident table, and the
@@ -8,6 +9,8 @@ resulting pie feeds `lmn_prove` with `LMN_TABLE_ROWS_ON_DEVICE`.
 Multiplicities follow HEAD (`crates/graph/src/op/prim.rs:66-83,1005-1006`): an op consumes each input
 with multiplicity -1 and yields its output `num_consumers` times (0 for a final output); a graph input
 is yielded `num_consumers` times by its Inputs rows — so the logup sums of a complete graph cancel.
+`num_consumers` is expansion-adjusted as in `graph.rs:215-243`: a consumer that reads the tensor through a
+view with expanded dimensions counts once per repetition of each element.
 The graph front-end itself (luminal's compiler passes, shape tracking, f32 -> fixed conversion rules)
 is outside the hot-path scope; this is the execution + table-fill step only."""
 from __future__ import annotations
@@ -20,7 +23,8 @@ import numpy as np
 from . import backend
 from .pie import TraceTableKind
 
-_NCOLS = {0: 15, 1: 16, 2: 13, 5: 14, 15: 7}
+_NCOLS = {0: 15, 1: 16, 2: 13, 3: 12, 5: 14, 9: 12, 11: 12, 15: 7}
+_LUT_OF = {3: ("sin", 4), 9: ("exp2", 10), 11: ("log2", 12)}     # op kind -> (LUT name, lookup-table kind)
 
 
 @dataclass
@@ -37,6 +41,32 @@ class GraphTensor:
 
 
 @dataclass
+class TensorView:
+    """A tensor seen through a shape with expanded dimensions (stride 0): luminal's `expand`."""
+    base: GraphTensor
+    shape: Tuple[int, ...]
+    strides: Tuple[int, ...]
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape))
+
+    @property
+    def expansion(self) -> int:
+        return int(np.prod([d for d, st in zip(self.shape, self.strides) if st == 0 and d > 1] or [1]))
+
+
+def _as_view(t) -> TensorView:
+    if isinstance(t, TensorView):
+        return t
+    strides, acc = [], 1
+    for d in reversed(t.shape):
+        strides.append(acc)
+        acc *= d
+    return TensorView(t, t.shape, tuple(reversed(strides)))
+
+
+@dataclass
 class _Node:
     kind: int
     out: GraphTensor
@@ -50,6 +80,7 @@ class DeviceGraph:
         self.ctx = ctx
         self.nodes: List[_Node] = []
         self._next_id = 0
+        self.luts: Dict[str, tuple] = {}
 
     def _tensor(self, shape) -> GraphTensor:
         t = GraphTensor(self._next_id, tuple(int(s) for s in shape))
@@ -63,13 +94,35 @@ class DeviceGraph:
         self.nodes.append(_Node(int(TraceTableKind.Inputs), t, [], host=v))
         return t
 
-    def _binary(self, kind, a: GraphTensor, b: GraphTensor) -> GraphTensor:
-        if a.shape != b.shape:
-            raise ValueError("elementwise operands must have equal shapes (no broadcasting in this mirror)")
-        a.consumers += 1
-        b.consumers += 1
-        t = self._tensor(a.shape)
-        self.nodes.append(_Node(kind, t, [a, b]))
+    def constant(self, value: int) -> GraphTensor:
+        """`LuminairConstant` (prim.rs:151-200): a one-element tensor, expanded by its consumers."""
+        return self.input(np.array([value], dtype=np.int32))
+
+    @staticmethod
+    def expand(t, axis: int, size: int) -> TensorView:
+        """Insert an expanded dimension of `size` at `axis` (stride 0)."""
+        v = _as_view(t)
+        return TensorView(v.base, v.shape[:axis] + (int(size),) + v.shape[axis:], v.strides[:axis] + (0,) + v.strides[axis:])
+
+    @staticmethod
+    def broadcast_to(t, shape) -> TensorView:
+        """View a one-element tensor (a constant) with the given shape."""
+        v = _as_view(t)
+        if v.base.size != 1:
+            raise ValueError("broadcast_to takes a one-element tensor")
+        return TensorView(v.base, tuple(int(d) for d in shape), (0,) * len(shape))
+
+    def _consume(self, t) -> TensorView:
+        v = _as_view(t)
+        v.base.consumers += v.expansion
+        return v
+
+    def _binary(self, kind, a, b) -> GraphTensor:
+        va, vb = _as_view(a), _as_view(b)
+        if va.shape != vb.shape:
+            raise ValueError("elementwise operands must have equal (view) shapes: expand / broadcast_to first")
+        t = self._tensor(va.shape)
+        self.nodes.append(_Node(kind, t, [self._consume(a), self._consume(b)]))
         return t
 
     def add(self, a, b):
@@ -78,58 +131,104 @@ class DeviceGraph:
     def mul(self, a, b):
         return self._binary(int(TraceTableKind.Mul), a, b)
 
-    def recip(self, a: GraphTensor) -> GraphTensor:
-        a.consumers += 1
-        t = self._tensor(a.shape)
-        self.nodes.append(_Node(int(TraceTableKind.Recip), t, [a]))
+    def recip(self, a) -> GraphTensor:
+        v = self._consume(a)
+        t = self._tensor(v.shape)
+        self.nodes.append(_Node(int(TraceTableKind.Recip), t, [v]))
         return t
 
     def sum_reduce(self, a: GraphTensor, axis: int) -> GraphTensor:
-        a.consumers += 1
+        if isinstance(a, TensorView):
+            raise ValueError("sum_reduce takes a materialised tensor")
+        v = self._consume(a)
         shape = a.shape[:axis] + a.shape[axis + 1:]
         t = self._tensor(shape if shape else (1,))
-        self.nodes.append(_Node(int(TraceTableKind.SumReduce), t, [a], axis=axis))
+        self.nodes.append(_Node(int(TraceTableKind.SumReduce), t, [v], axis=axis))
         return t
+
+    def set_lut(self, name: str, lo: int, hi: int):
+        """Declare the value range of a LUT (what `gen_circuit_settings` derives from a dry run,
+        graph.rs:61-159); the columns are generated on the host as the reference does (f64 math)."""
+        from . import synthetic
+        self.luts[name] = (int(lo), int(hi), synthetic.make_lut(name, int(lo), int(hi)))
+
+    def _lut_op(self, kind, a) -> GraphTensor:
+        if _LUT_OF[kind][0] not in self.luts:
+            raise ValueError("declare the LUT range with set_lut(%r, lo, hi) first" % _LUT_OF[kind][0])
+        v = self._consume(a)
+        t = self._tensor(v.shape)
+        self.nodes.append(_Node(kind, t, [v]))
+        return t
+
+    def sin(self, a):
+        return self._lut_op(int(TraceTableKind.Sin), a)
+
+    def exp2(self, a):
+        return self._lut_op(int(TraceTableKind.Exp2), a)
+
+    def log2(self, a):
+        return self._lut_op(int(TraceTableKind.Log2), a)
 
     def output(self, t: GraphTensor) -> GraphTensor:
         t.is_output = True
         return t
 
     def gen_trace(self):
-        """Runs every node on the device.  Returns (tables, buffers): tables = [(kind, rows DeviceBuffer,
-        n_rows)] in `gen_trace` order (ascending kind), ready for Context.prove_tables; buffers = every device
-        allocation made (free them after proving)."""
+        """Runs every node on the device.  Returns (tables, luts, buffers): tables = [(kind, rows DeviceBuffer,
+        n_rows)] in `gen_trace` order (ascending kind) and luts = {name: (col0, col1)} for
+        Context.prove_tables(tables, luts); buffers = every device allocation made (free them after proving)."""
         ctx = self.ctx
-        rows_of = lambda n: n.inputs[0].size if n.kind == int(TraceTableKind.SumReduce) else n.out.size
+        K = TraceTableKind
+        view_of = lambda v: None if v.strides == _as_view(v.base).strides and v.shape == v.base.shape \
+            else backend.LmnView.make(v.shape, v.strides)
+        rows_of = lambda n: n.inputs[0].size if n.kind == int(K.SumReduce) else n.out.size
         total: Dict[int, int] = {}
         for n in self.nodes:
             total[n.kind] = total.get(n.kind, 0) + rows_of(n)
         tables = {k: ctx.alloc(total[k] * _NCOLS[k] * 4) for k in total}
         offset = {k: 0 for k in total}
         bufs = list(tables.values())
+        lut_dev, lut_tables, luts_out = {}, {}, {}
+        for kind in sorted(total):
+            if kind in _LUT_OF:
+                name, lookup_kind = _LUT_OF[kind]
+                lo, hi, (c0, c1) = self.luts[name]
+                lut_dev[name] = (ctx.upload(c1), ctx.upload(np.zeros(len(c0), dtype=np.uint32)))   # outputs, multiplicities
+                bufs += list(lut_dev[name])
+                lut_tables[lookup_kind] = (lut_dev[name][1], len(c0))
+                luts_out[name] = (c0, c1)
         for n in self.nodes:
             t = n.out
             common = dict(num_consumers=t.consumers, is_final_output=t.is_output, rows=tables[n.kind],
                           row_offset=offset[n.kind])
-            if n.kind == int(TraceTableKind.Inputs):
+            if n.kind == int(K.Inputs):
                 src = ctx.upload(n.host.reshape(-1))
                 bufs.append(src)
                 _, t.buf = ctx.trace_elementwise(n.kind, src, None, t.size, node_id=t.node_id, input_ids=(),
                                                  input_mults=(), **common)
-            elif n.kind == int(TraceTableKind.SumReduce):
-                a = n.inputs[0]
+            elif n.kind == int(K.SumReduce):
+                a = n.inputs[0].base
                 front = int(np.prod(a.shape[:n.axis])) if n.axis else 1
                 back = int(np.prod(a.shape[n.axis + 1:])) if n.axis + 1 < len(a.shape) else 1
                 _, t.buf = ctx.trace_sum_reduce(a.buf, front, a.shape[n.axis], back, node_id=t.node_id,
                                                 input_id=a.node_id, **common)
+            elif n.kind in _LUT_OF:
+                name = _LUT_OF[n.kind][0]
+                lo, hi, (c0, _) = self.luts[name]
+                v = n.inputs[0]
+                _, t.buf = ctx.trace_lut(n.kind, v.base.buf, t.size, node_id=t.node_id, input_id=v.base.node_id,
+                                         lut_col1=lut_dev[name][0], lo=lo, lut_len=hi - lo + 1, mult=lut_dev[name][1],
+                                         view=view_of(v), **common)
             else:
                 ins = n.inputs
-                _, t.buf = ctx.trace_elementwise(n.kind, ins[0].buf, ins[1].buf if len(ins) > 1 else None, t.size,
-                                                 node_id=t.node_id, input_ids=tuple(i.node_id for i in ins),
-                                                 input_mults=tuple(-1 for _ in ins), **common)
+                _, t.buf = ctx.trace_elementwise(
+                    n.kind, ins[0].base.buf, ins[1].base.buf if len(ins) > 1 else None, t.size, node_id=t.node_id,
+                    input_ids=tuple(i.base.node_id for i in ins), input_mults=tuple(-1 for _ in ins),
+                    lhs_view=view_of(ins[0]), rhs_view=view_of(ins[1]) if len(ins) > 1 else None, **common)
             bufs.append(t.buf)
             offset[n.kind] += rows_of(n)
-        return [(k, tables[k], total[k]) for k in sorted(tables)], bufs
+        out = [(k, tables[k], total[k]) for k in tables] + [(k, b, n) for k, (b, n) in lut_tables.items()]
+        return sorted(out, key=lambda e: e[0]), luts_out, bufs
 
     def read(self, t: GraphTensor) -> np.ndarray:
         return self.ctx.download(t.buf, np.int32).reshape(t.shape)

@@ -164,7 +164,7 @@ def check_device_graph(lib, device=0):
     tc = g.mul(ta, tb)
     td = g.add(tc, tw)
     te = g.output(g.mul(tc, td))
-    tables, bufs = g.gen_trace()
+    tables, _, bufs = g.gen_trace()
     c = (a * b) >> 12
     d = c + w
     assert np.array_equal(g.read(te), (c * d) >> 12)
@@ -191,12 +191,56 @@ def check_device_graph(lib, device=0):
     tx, twt, tbias = g.input(x), g.input(wt), g.input(bias)
     ty = g.add(g.sum_reduce(g.mul(tx, twt), axis=1), tbias)
     tz = g.output(g.recip(ty))
-    tables, bufs = g.gen_trace()
+    tables, _, bufs = g.gen_trace()
     y = ((x * wt) >> 12).sum(axis=1) + bias
     assert np.array_equal(g.read(tz), (S * S) // y)
     assert [k for k, _, _ in tables] == [0, 1, 2, 5, 15]
     proof = ctx.prove_tables(tables)
     lib.verify(proof, backend_mod().VARIANT_PINNED)
+    for buf in bufs:
+        buf.free()
+    # the black-scholes MLP shape (BASELINE config 4) entirely on the device: Linear = expand + Mul + SumReduce + Add,
+    # tanh(v) = 2 * recip(1 + exp2(v * (-2/ln 2))) - 1 with the Exp2 LUT; constants are one-element inputs expanded
+    # by their consumers; the proof verifying means every multiplicity (expansion-adjusted, LUT) is right
+    rng = np.random.default_rng(5)
+    g = DeviceGraph(ctx)
+    g.set_lut("exp2", -S, S)          # 8 193 LUT rows -> a 2^14-row Exp2Lookup table
+    c_scale = g.constant(int(round(-2.0 / np.log(2.0) * S)))
+    c_one, c_two, c_neg1 = g.constant(S), g.constant(2 * S), g.constant(-S)
+
+    def linear(h, n_in, n_out):
+        w = rng.integers(-128, 128, size=(n_out, n_in))
+        b = rng.integers(-64, 64, size=n_out)
+        prod = g.mul(g.expand(h, 0, n_out), g.input(w))
+        return g.add(g.sum_reduce(prod, axis=1), g.input(b)), w, b
+
+    def tanh(v, n):
+        t = g.mul(v, g.broadcast_to(c_scale, (n,)))
+        e = g.exp2(t)
+        s1 = g.add(e, g.broadcast_to(c_one, (n,)))
+        r = g.recip(s1)
+        u = g.mul(r, g.broadcast_to(c_two, (n,)))
+        return g.add(u, g.broadcast_to(c_neg1, (n,)))
+
+    x0 = rng.integers(-2048, 2048, size=2)
+    h, ref, params = g.input(x0), x0.astype(np.int64), []
+    for n_in, n_out, act in ((2, 8, True), (8, 8, True), (8, 1, False)):
+        y, w, b = linear(h, n_in, n_out)
+        ref = ((ref[None, :] * w) >> 12).sum(axis=1) + b
+        if act:
+            h = tanh(y, n_out)
+            tt = (ref * int(round(-2.0 / np.log(2.0) * S))) >> 12
+            e = np.rint(np.exp2(tt / S) * S).astype(np.int64)
+            ref = ((((S * S) // (e + S)) * 2 * S) >> 12) - S
+        else:
+            h = y
+    g.output(h)
+    tables, luts, bufs = g.gen_trace()
+    assert np.array_equal(g.read(h), ref)
+    assert [k for k, _, _ in tables] == [0, 1, 2, 5, 9, 10, 15]
+    proof = ctx.prove_tables(tables, luts)
+    lib.verify(proof, backend_mod().VARIANT_PINNED)
+    assert proof == ctx.prove_tables(tables, luts)
     for buf in bufs:
         buf.free()
     ctx.close()
@@ -205,3 +249,32 @@ def check_device_graph(lib, device=0):
 def backend_mod():
     from luminair_amd import backend
     return backend
+
+
+def device_mlp(ctx, widths=(2, 64, 64, 1), seed=42, lut_half_range=8 * 4096):
+    """BASELINE config 4's shape (2 -> 64 -> 64 -> 1 MLP with tanh, examples/black-schole-nn/src/main.rs:61-103)
+    built and executed with DeviceGraph.  Returns (graph, output tensor, numpy reference of the forward pass)."""
+    from luminair_amd.graph import DeviceGraph
+    S = 4096
+    rng = np.random.default_rng(seed)
+    g = DeviceGraph(ctx)
+    g.set_lut("exp2", -lut_half_range, lut_half_range)
+    cs = int(round(-2.0 / np.log(2.0) * S))
+    c_scale, c_one, c_two, c_neg1 = g.constant(cs), g.constant(S), g.constant(2 * S), g.constant(-S)
+    x0 = rng.integers(-2048, 2048, size=widths[0])
+    h, ref = g.input(x0), x0.astype(np.int64)
+    for li, (n_in, n_out) in enumerate(zip(widths[:-1], widths[1:])):
+        w = rng.integers(-600, 600, size=(n_out, n_in))
+        b = rng.integers(-512, 512, size=n_out)
+        y = g.add(g.sum_reduce(g.mul(g.expand(h, 0, n_out), g.input(w)), axis=1), g.input(b))
+        ref = ((ref[None, :] * w) >> 12).sum(axis=1) + b
+        if li + 2 < len(widths):
+            t = g.mul(y, g.broadcast_to(c_scale, (n_out,)))
+            u = g.mul(g.recip(g.add(g.exp2(t), g.broadcast_to(c_one, (n_out,)))), g.broadcast_to(c_two, (n_out,)))
+            h = g.add(u, g.broadcast_to(c_neg1, (n_out,)))
+            e = np.rint(np.exp2(((ref * cs) >> 12) / S) * S).astype(np.int64)
+            ref = ((((S * S) // (e + S)) * 2 * S) >> 12) - S
+        else:
+            h = y
+    g.output(h)
+    return g, h, ref

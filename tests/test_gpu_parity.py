@@ -215,6 +215,28 @@ def test_gpu_device_graph_gen_trace_then_prove(hip_lib_path):
     check_device_graph(backend.Library(hip_lib_path))
 
 
+def test_gpu_config4_mlp_generated_and_proved_on_device(hip_lib_path):
+    """BASELINE config 4 end to end on the GPU: the 2 -> 64 -> 64 -> 1 tanh MLP is executed by DeviceGraph
+    (expanded views, constants, Exp2 LUT with its multiplicities), its device-resident tables are proved and the
+    proof passes the verifier; the forward pass equals the numpy fixed-point reference."""
+    from level2_checks import device_mlp
+    from luminair_amd import backend
+    lib = backend.Library(hip_lib_path)
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    g, out, ref = device_mlp(ctx)
+    tables, luts, bufs = g.gen_trace()
+    assert np.array_equal(g.read(out), ref)
+    assert [k for k, _, _ in tables] == [0, 1, 2, 5, 9, 10, 15]
+    assert dict((k, n) for k, _, n in tables)[1] == 2 * 64 + 64 * 64 + 64 + 4 * 64      # Mul rows
+    proof = ctx.prove_tables(tables, luts)
+    lib.verify(proof, backend.VARIANT_PINNED)
+    for b in bufs:
+        b.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
 def test_gpu_fft_tiled_equals_layerwise(gpu_prover, log):
     """Device-side differential check at full sizes: LDS-tiled passes vs one-layer-per-launch."""
