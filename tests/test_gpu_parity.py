@@ -237,7 +237,7 @@ def test_gpu_config4_mlp_generated_and_proved_on_device(hip_lib_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("log", [12, 13, 20, 22, 23])
+@pytest.mark.parametrize("log", [12, 13, 20, 22, 23, 24, 25])
 def test_gpu_fft_tiled_equals_layerwise(gpu_prover, log):
     """Device-side differential check at full sizes: LDS-tiled passes vs one-layer-per-launch."""
     gpu_prover.ctx.fft_selftest(log, 2)
