@@ -81,7 +81,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut"]
+           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -136,6 +136,11 @@ class Library:
         lib.lmn_trace_lut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_uint64,
                                       C.POINTER(LmnNodeInfo), C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p]
+        lib.lmn_trace_less_than.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(LmnView), C.c_void_p, C.POINTER(LmnView),
+                                            C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p, C.c_void_p, C.c_uint64,
+                                            C.c_void_p]
+        lib.lmn_trace_max_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                             C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_sum_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                              C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_elementwise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -271,16 +276,33 @@ class Context:
 
     def trace_sum_reduce(self, inp: DeviceBuffer, front: int, dim: int, back: int, node_id: int, input_id: int,
                          num_consumers: int, is_final_output: bool = False, input_mult: int = -1,
-                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0):
-        """`LuminairSumReduce::process_trace` on a contiguous (front, dim, back) int32 device tensor."""
+                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0, maximum: bool = False):
+        """`LuminairSumReduce::process_trace` (or MaxReduce with maximum=True) on a contiguous
+        (front, dim, back) int32 device tensor."""
         n_rows, n_out = front * dim * back, front * back
         if rows is None:
-            rows = self.alloc((row_offset + n_rows) * 14 * 4)
+            rows = self.alloc((row_offset + n_rows) * (15 if maximum else 14) * 4)
         out = self.alloc(n_out * 4)
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(input_mult, 0))
-        self._check(self.lib.lib.lmn_trace_sum_reduce(self.handle, inp.ptr, front, dim, back, C.byref(info), rows.ptr,
-                                                      row_offset, out.ptr))
+        fn = self.lib.lib.lmn_trace_max_reduce if maximum else self.lib.lib.lmn_trace_sum_reduce
+        self._check(fn(self.handle, inp.ptr, front, dim, back, C.byref(info), rows.ptr, row_offset, out.ptr))
+        return rows, out
+
+    def trace_less_than(self, lhs: DeviceBuffer, rhs: DeviceBuffer, n: int, node_id: int, input_ids, num_consumers: int,
+                        range_check_mult: DeviceBuffer, is_final_output: bool = False, input_mults=(-1, -1),
+                        rows: Optional[DeviceBuffer] = None, row_offset: int = 0,
+                        lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None):
+        """`LuminairLessThan::process_trace`; `range_check_mult` (256 words) is the RangeCheckLookup table."""
+        if rows is None:
+            rows = self.alloc((row_offset + n) * 22 * 4)
+        out = self.alloc(n * 4)
+        info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(*input_ids), num_consumers, 1 if is_final_output else 0,
+                           (C.c_int32 * 2)(*input_mults))
+        self._check(self.lib.lib.lmn_trace_less_than(
+            self.handle, lhs.ptr, C.byref(lhs_view) if lhs_view is not None else None, rhs.ptr,
+            C.byref(rhs_view) if rhs_view is not None else None, n, C.byref(info), range_check_mult.ptr, rows.ptr,
+            row_offset, out.ptr))
         return rows, out
 
     def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:

@@ -213,21 +213,20 @@ int lmn_download(lmn_ctx* ctx, const void* device, void* host, size_t bytes) {
 
 int lmn_trace_elementwise(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const int32_t* rhs_dev, uint64_t n,
                           const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
-  if (!ctx || !lhs_dev || !info || !rows_dev || ((kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) && !rhs_dev)) return LMN_ERR_INVALID_ARGUMENT;
+  if (!ctx || !lhs_dev || !info || !rows_dev || kind == LMN_KIND_LESS_THAN) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->trace_elementwise(kind, lhs_dev, nullptr, rhs_dev, nullptr, n, *info, rows_dev, row_offset, out_dev); });
 }
 
 int lmn_trace_sum_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front, uint64_t dim, uint64_t back,
                          const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
   if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
-  return guard(ctx, [&] { ctx->impl->trace_sum_reduce(input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
+  return guard(ctx, [&] { ctx->impl->trace_reduce(false, input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
 }
 
 int lmn_trace_elementwise_v(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev, const lmn_view* lhs_view,
                             const int32_t* rhs_dev, const lmn_view* rhs_view, uint64_t n, const lmn_node_info* info,
                             uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
-  if (!ctx || !lhs_dev || !info || !rows_dev || ((kind == LMN_KIND_ADD || kind == LMN_KIND_MUL) && !rhs_dev))
-    return LMN_ERR_INVALID_ARGUMENT;
+  if (!ctx || !lhs_dev || !info || !rows_dev || kind == LMN_KIND_LESS_THAN) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] {
     ctx->impl->trace_elementwise(kind, lhs_dev, lhs_view, rhs_dev, rhs_view, n, *info, rows_dev, row_offset, out_dev);
   });
@@ -240,4 +239,20 @@ int lmn_trace_lut(lmn_ctx* ctx, uint32_t kind, const int32_t* input_dev, const l
   return guard(ctx, [&] {
     ctx->impl->trace_lut(kind, input_dev, view, n, *info, lut_col1_dev, lo, lut_len, mult_dev, rows_dev, row_offset, out_dev);
   });
+}
+
+int lmn_trace_less_than(lmn_ctx* ctx, const int32_t* lhs_dev, const lmn_view* lhs_view, const int32_t* rhs_dev,
+                        const lmn_view* rhs_view, uint64_t n, const lmn_node_info* info, uint32_t* range_check_mult_dev,
+                        uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !lhs_dev || !rhs_dev || !info || !range_check_mult_dev || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] {
+    ctx->impl->trace_elementwise(LMN_KIND_LESS_THAN, lhs_dev, lhs_view, rhs_dev, rhs_view, n, *info, rows_dev, row_offset,
+                                 out_dev, range_check_mult_dev);
+  });
+}
+
+int lmn_trace_max_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front, uint64_t dim, uint64_t back,
+                         const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->trace_reduce(true, input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
 }

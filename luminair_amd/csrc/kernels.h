@@ -99,14 +99,15 @@ struct TraceView {  // strided view; ndim == 0: contiguous
   int64_t strides[4];
 };
 void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv, const int32_t* rhs, const TraceView& rv,
-                              uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, lmn_stream_t s);
+                              uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, uint32_t* aux,
+                              lmn_stream_t s);
 // LUT op rows + LUT multiplicities; *err_flag (device word) is set when an input falls outside the LUT range
 void launch_trace_lut(const int32_t* input, const TraceView& view, uint64_t n, const TraceNode& nd,
                       const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
                       int32_t* out, uint32_t* err_flag, lmn_stream_t s);
 
-void launch_trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const TraceNode& nd,
-                             uint32_t* rows, int32_t* out, lmn_stream_t s);
+void launch_trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
+                         const TraceNode& nd, uint32_t* rows, int32_t* out, lmn_stream_t s);
 
 // ---- a6: logup
 constexpr int LOGUP_MAX_REL = 7;

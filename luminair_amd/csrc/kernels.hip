@@ -1,6 +1,7 @@
 // gfx950 kernels for the LuminAIR prove hot path.  One wavefront = 64 lanes; all global accesses
 // are laid out so consecutive lanes touch consecutive 4-byte words of a column (column-major
 // trace data).  See DESIGN.md for the per-kernel roofline notes.
+#include <cmath>
 #include "kernels.h"
 
 #include <algorithm>
@@ -65,11 +66,23 @@ LMN_D uint64_t view_offset(const TraceView& v, uint64_t r) {
   return (uint64_t)off;
 }
 
+LMN_HD constexpr int trace_ncols(int kind) {
+  return kind == 0 ? 15 : kind == 1 ? 16 : kind == 2 ? 13 : kind == 7 ? 13 : kind == 8 ? 16 : kind == 13 ? 22
+                                                                                       : kind == 16 ? 11 : 7;
+}
+// floor(sqrt(v)) for v < 2^44, exact (double sqrt + one correction step each way)
+LMN_D int64_t isqrt_u64(int64_t v) {
+  int64_t r = (int64_t)sqrt((double)v);
+  while (r * r > v) --r;
+  while ((r + 1) * (r + 1) <= v) ++r;
+  return r;
+}
+
 template <int KIND>
 LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, const int32_t* __restrict__ rhs,
                                TraceView rv, uint64_t n, TraceNode nd, uint32_t* __restrict__ rows,
-                               int32_t* __restrict__ out) {
-  constexpr int NC = KIND == 0 ? 15 : (KIND == 1 ? 16 : (KIND == 2 ? 13 : 7));
+                               int32_t* __restrict__ out, uint32_t* __restrict__ aux) {
+  constexpr int NC = trace_ncols(KIND);
   constexpr int ST = NC | 1;  // odd LDS row stride: conflict-free column writes
   LMN_SHARED uint32_t tile[TPB * ST];
   const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
@@ -78,7 +91,50 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, co
     uint32_t* t = tile + threadIdx.x * ST;
     const int64_t a = lhs[view_offset(lv, r)];
     const uint32_t idx = (uint32_t)r, last = r + 1 == n ? 1u : 0u;
-    if (KIND == 15) {
+    if (KIND == 16 || KIND == 7) {
+      // Contiguous (prim.rs:229-301): out = input.  Sqrt (prim.rs:573-660): out = floor(sqrt(input * scale)),
+      // rem = input * scale - out^2 (natural identity; numerair's form is unpinned)
+      t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = idx; t[3] = last;
+      t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = idx + 1u;
+      t[7] = fixed_to_m31(a);
+      if (KIND == 16) {
+        t[8] = fixed_to_m31(a); t[9] = nd.lhs_mult; t[10] = nd.out_mult;
+        if (out) out[r] = (int32_t)a;
+      } else {
+        const int64_t o = isqrt_u64(a * 4096ll);
+        t[8] = fixed_to_m31(o); t[9] = fixed_to_m31(a * 4096ll - o * o); t[10] = 4096u;
+        t[11] = nd.lhs_mult; t[12] = nd.out_mult;
+        if (out) out[r] = (int32_t)o;
+      }
+    } else if (KIND == 8 || KIND == 13) {
+      const int64_t b = rhs[view_offset(rv, r)];
+      t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = nd.rhs_id; t[3] = idx; t[4] = last;
+      t[5] = nd.node_id; t[6] = nd.lhs_id; t[7] = nd.rhs_id; t[8] = idx + 1u;
+      t[9] = fixed_to_m31(a); t[10] = fixed_to_m31(b);
+      if (KIND == 8) {
+        // Rem (prim.rs:1323-1421), operands > 0: lhs = rhs * quotient + rem; the out relation carries rem
+        const int64_t quo = a / b, rem = a % b;
+        t[11] = fixed_to_m31(rem); t[12] = fixed_to_m31(quo);
+        t[13] = nd.lhs_mult; t[14] = nd.rhs_mult; t[15] = nd.out_mult;
+        if (out) out[r] = (int32_t)rem;
+      } else {
+        // LessThan (prim.rs:1203-1295): out = 1.0 iff lhs < rhs; diff = rhs - lhs (+ P with borrow) in four
+        // range-checked 8-bit limbs; aux = the RangeCheckLookup multiplicity column (256 entries)
+        const bool lt = a < b;
+        const int64_t diff = b - a + (lt ? 0 : (int64_t)P31);
+        t[11] = lt ? 4096u : 0u;
+        t[12] = (uint32_t)(diff % (int64_t)P31);
+        t[13] = lt ? 0u : 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t limb = (uint32_t)(diff >> (8 * k)) & 0xFFu;
+          t[14 + k] = limb;
+          atomicAdd(&aux[limb], 1u);
+        }
+        t[18] = nd.lhs_mult; t[19] = nd.rhs_mult; t[20] = nd.out_mult; t[21] = 1u;
+        if (out) out[r] = lt ? 4096 : 0;
+      }
+    } else if (KIND == 15) {
       // CopyToStwo / Inputs (prim.rs:52-88): node, idx, is_last, next_node, next_idx, val, multiplicity
       t[0] = nd.node_id; t[1] = idx; t[2] = last; t[3] = nd.node_id; t[4] = idx + 1u;
       t[5] = fixed_to_m31(a); t[6] = nd.out_mult;
@@ -122,9 +178,12 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, co
 // SumReduce rows (prim.rs:1486-1510, 1536-1561): row r = (i*back + j)*dim + k holds input[i, k, j], the
 // running sum before and after it, and the output on the group's last step.  One lane per row; the prefix
 // inside a group is re-summed per lane (dim is a tensor axis, at most a few hundred), rows leave through LDS.
-LMN_KERNEL k_trace_sum_reduce(const int32_t* __restrict__ input, uint64_t dim, uint64_t back, uint64_t n_rows,
-                              uint64_t n_out, TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
-  constexpr int NC = 14, ST = 15;
+// MAX: MaxReduce rows (prim.rs:1591-1734): the running maximum starts at the group's first element, is_max marks
+// the rows whose input becomes the new maximum (strict comparison).
+template <bool MAX>
+LMN_KERNEL k_trace_reduce(const int32_t* __restrict__ input, uint64_t dim, uint64_t back, uint64_t n_rows,
+                          uint64_t n_out, TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
+  constexpr int NC = MAX ? 15 : 14, ST = MAX ? 17 : 15;
   LMN_SHARED uint32_t tile[TPB * ST];
   const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
   const uint64_t r = row0 + threadIdx.x;
@@ -132,16 +191,20 @@ LMN_KERNEL k_trace_sum_reduce(const int32_t* __restrict__ input, uint64_t dim, u
     const uint64_t g = r / dim, k = r % dim;  // output index (i*back + j), reduction step
     const uint64_t i = g / back, j = g % back;
     const int32_t* p = input + i * dim * back + j;
-    int64_t acc = 0;
-    for (uint64_t kk = 0; kk < k; ++kk) acc += p[kk * back];
-    const int64_t v = p[k * back], next = acc + v;
+    int64_t acc = MAX ? (int64_t)p[0] : 0;
+    for (uint64_t kk = 0; kk < k; ++kk) acc = MAX ? (p[kk * back] > acc ? (int64_t)p[kk * back] : acc) : acc + p[kk * back];
+    const int64_t v = p[k * back], next = MAX ? (v > acc ? v : acc) : acc + v;
     const bool last_step = k + 1 == dim;
     uint32_t* t = tile + threadIdx.x * ST;
     t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = (uint32_t)g; t[3] = g + 1 == n_out ? 1u : 0u;
     t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = (uint32_t)g + 1u;
     t[7] = fixed_to_m31(v); t[8] = last_step ? fixed_to_m31(next) : 0u;
     t[9] = fixed_to_m31(acc); t[10] = fixed_to_m31(next); t[11] = last_step ? 1u : 0u;
-    t[12] = nd.lhs_mult; t[13] = last_step ? nd.out_mult : 0u;
+    if (MAX) {
+      t[12] = v > acc ? 1u : 0u; t[13] = nd.lhs_mult; t[14] = last_step ? nd.out_mult : 0u;
+    } else {
+      t[12] = nd.lhs_mult; t[13] = last_step ? nd.out_mult : 0u;
+    }
     if (last_step && out) out[g] = (int32_t)next;
   }
   __syncthreads();
@@ -151,20 +214,28 @@ LMN_KERNEL k_trace_sum_reduce(const int32_t* __restrict__ input, uint64_t dim, u
   for (uint32_t w = threadIdx.x; w < words; w += TPB) dst[w] = tile[(w / NC) * ST + (w % NC)];
 }
 
-void launch_trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const TraceNode& nd,
-                             uint32_t* rows, int32_t* out, lmn_stream_t s) {
+void launch_trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
+                         const TraceNode& nd, uint32_t* rows, int32_t* out, lmn_stream_t s) {
   const uint64_t n_out = front * back, n_rows = n_out * dim;
-  LMN_LAUNCH(k_trace_sum_reduce, dim3(cdiv(n_rows, TPB)), dim3(TPB), 0, s, input, dim, back, n_rows, n_out, nd, rows, out);
+  if (is_max)
+    LMN_LAUNCH(k_trace_reduce<true>, dim3(cdiv(n_rows, TPB)), dim3(TPB), 0, s, input, dim, back, n_rows, n_out, nd, rows, out);
+  else
+    LMN_LAUNCH(k_trace_reduce<false>, dim3(cdiv(n_rows, TPB)), dim3(TPB), 0, s, input, dim, back, n_rows, n_out, nd, rows, out);
 }
 
 void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv, const int32_t* rhs, const TraceView& rv,
-                              uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, lmn_stream_t s) {
+                              uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, uint32_t* aux,
+                              lmn_stream_t s) {
   dim3 g(cdiv(n, TPB)), b(TPB);
   switch (kind) {
-    case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
-    case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
-    case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
-    case 15: LMN_LAUNCH(k_trace_elementwise<15>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out); break;
+    case 0: LMN_LAUNCH(k_trace_elementwise<0>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 1: LMN_LAUNCH(k_trace_elementwise<1>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 2: LMN_LAUNCH(k_trace_elementwise<2>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 7: LMN_LAUNCH(k_trace_elementwise<7>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 8: LMN_LAUNCH(k_trace_elementwise<8>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 13: LMN_LAUNCH(k_trace_elementwise<13>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 15: LMN_LAUNCH(k_trace_elementwise<15>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
+    case 16: LMN_LAUNCH(k_trace_elementwise<16>, g, b, 0, s, lhs, lv, rhs, rv, n, nd, rows, out, aux); break;
     default: throw LmnError(-100, "trace_elementwise: unsupported kind");
   }
 }

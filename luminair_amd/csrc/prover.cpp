@@ -263,14 +263,15 @@ static TraceNode trace_node(const lmn_node_info& info) {
 }
 
 // `LuminairSumReduce::process_trace` (prim.rs:1450-1565) on a contiguous (front, dim, back) device tensor
-void Context::trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
-                               const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
+void Context::trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
+                           const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   if (front == 0 || dim == 0 || back == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (front * back * dim >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
-  launch_trace_sum_reduce(input, front, dim, back, trace_node(info), rows + row_offset * 14ull, out, stream_);
+  launch_trace_reduce(is_max, input, front, dim, back, trace_node(info), rows + row_offset * (is_max ? 15ull : 14ull), out,
+                      stream_);
   lmn_sync(stream_);
 }
 
@@ -317,19 +318,24 @@ void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* vie
 
 void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_view* lv, const int32_t* rhs,
                                 const lmn_view* rv, uint64_t n, const lmn_node_info& info, uint32_t* rows,
-                                uint64_t row_offset, int32_t* out) {
+                                uint64_t row_offset, int32_t* out, uint32_t* aux) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   const ComponentSpec* sp = component_spec((int)kind);
-  if (!sp || (kind != LMN_KIND_ADD && kind != LMN_KIND_MUL && kind != LMN_KIND_RECIP && kind != LMN_KIND_INPUTS))
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: kind must be Add, Mul, Recip or Inputs");
+  const bool binary = kind == LMN_KIND_ADD || kind == LMN_KIND_MUL || kind == LMN_KIND_REM || kind == LMN_KIND_LESS_THAN;
+  const bool unary = kind == LMN_KIND_RECIP || kind == LMN_KIND_SQRT || kind == LMN_KIND_CONTIGUOUS || kind == LMN_KIND_INPUTS;
+  if (!sp || !(binary || unary))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: not an elementwise kind");
+  if (binary && !rhs) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: missing right operand");
+  if (kind == LMN_KIND_LESS_THAN && !aux)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_elementwise: LessThan needs the range-check multiplicity table");
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
   const TraceNode nd = trace_node(info);
   const TraceView tlv = trace_view(lv, n), trv = trace_view(rv, n);
-  launch_trace_elementwise(kind == LMN_KIND_ADD ? 0 : (kind == LMN_KIND_MUL ? 1 : (kind == LMN_KIND_RECIP ? 2 : 15)), lhs, tlv, rhs, trv, n, nd,
-                           rows + row_offset * (uint64_t)sp->n_cols, out, stream_);
+  launch_trace_elementwise((int)kind, lhs, tlv, rhs, trv, n, nd, rows + row_offset * (uint64_t)sp->n_cols, out, aux,
+                           stream_);
   lmn_sync(stream_);
 }
 

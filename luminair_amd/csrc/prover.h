@@ -121,10 +121,11 @@ class Context {
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
   void download(const void* device, void* host, size_t bytes);
-  void trace_sum_reduce(const int32_t* input, uint64_t front, uint64_t dim, uint64_t back, const lmn_node_info& info,
-                        uint32_t* rows, uint64_t row_offset, int32_t* out);
+  void trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
+                    const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out);
   void trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_view* lv, const int32_t* rhs, const lmn_view* rv,
-                         uint64_t n, const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out);
+                         uint64_t n, const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out,
+                         uint32_t* aux = nullptr);
   void trace_lut(uint32_t kind, const int32_t* input, const lmn_view* view, uint64_t n, const lmn_node_info& info,
                  const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
                  uint64_t row_offset, int32_t* out);

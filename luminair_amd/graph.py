@@ -1,5 +1,6 @@
 """Device-side `gen_trace` for graphs of the primitives whose `process_trace` runs on the GPU
-(Add, Mul, Recip, SumReduce, the LUT ops Sin / Exp2 / Log2 with their lookup tables, and the graph inputs,
+(Add, Mul, Recip, Sqrt, Rem, LessThan with its range-check table, SumReduce, MaxReduce, Contiguous, the LUT ops
+Sin / Exp2 / Log2 with their lookup tables, and the graph inputs,
 with expanded ("fake") dimensions as in luminal's ShapeTracker): a small host mirror of
 `LuminairGraph::gen_trace` (`crates/graph/src/graph.rs:161-604`) over `lmn_trace_elementwise` /
 `lmn_trace_sum_reduce`.  Nodes execute in creation (= topological) order, every tensor stays in HBM
@@ -23,7 +24,7 @@ import numpy as np
 from . import backend
 from .pie import TraceTableKind
 
-_NCOLS = {0: 15, 1: 16, 2: 13, 3: 12, 5: 14, 9: 12, 11: 12, 15: 7}
+_NCOLS = {0: 15, 1: 16, 2: 13, 3: 12, 5: 14, 6: 15, 7: 13, 8: 16, 9: 12, 11: 12, 13: 22, 15: 7, 16: 11}
 _LUT_OF = {3: ("sin", 4), 9: ("exp2", 10), 11: ("log2", 12)}     # op kind -> (LUT name, lookup-table kind)
 
 
@@ -131,10 +132,31 @@ class DeviceGraph:
     def mul(self, a, b):
         return self._binary(int(TraceTableKind.Mul), a, b)
 
-    def recip(self, a) -> GraphTensor:
+    def _unary(self, kind, a) -> GraphTensor:
         v = self._consume(a)
         t = self._tensor(v.shape)
-        self.nodes.append(_Node(int(TraceTableKind.Recip), t, [v]))
+        self.nodes.append(_Node(kind, t, [v]))
+        return t
+
+    def recip(self, a) -> GraphTensor:
+        return self._unary(int(TraceTableKind.Recip), a)
+
+    def sqrt(self, a) -> GraphTensor:
+        return self._unary(int(TraceTableKind.Sqrt), a)
+
+    def contiguous(self, a) -> GraphTensor:
+        """Materialise a view (`LuminairContiguous`, prim.rs:229-301)."""
+        return self._unary(int(TraceTableKind.Contiguous), a)
+
+    def rem(self, a, b) -> GraphTensor:
+        return self._binary(int(TraceTableKind.Rem), a, b)
+
+    def less_than(self, a, b) -> GraphTensor:
+        return self._binary(int(TraceTableKind.LessThan), a, b)
+
+    def max_reduce(self, a: GraphTensor, axis: int) -> GraphTensor:
+        t = self.sum_reduce(a, axis)
+        self.nodes[-1].kind = int(TraceTableKind.MaxReduce)
         return t
 
     def sum_reduce(self, a: GraphTensor, axis: int) -> GraphTensor:
@@ -181,7 +203,8 @@ class DeviceGraph:
         K = TraceTableKind
         view_of = lambda v: None if v.strides == _as_view(v.base).strides and v.shape == v.base.shape \
             else backend.LmnView.make(v.shape, v.strides)
-        rows_of = lambda n: n.inputs[0].size if n.kind == int(K.SumReduce) else n.out.size
+        reduces = (int(K.SumReduce), int(K.MaxReduce))
+        rows_of = lambda n: n.inputs[0].size if n.kind in reduces else n.out.size
         total: Dict[int, int] = {}
         for n in self.nodes:
             total[n.kind] = total.get(n.kind, 0) + rows_of(n)
@@ -197,6 +220,11 @@ class DeviceGraph:
                 bufs += list(lut_dev[name])
                 lut_tables[lookup_kind] = (lut_dev[name][1], len(c0))
                 luts_out[name] = (c0, c1)
+        rc_mult = None
+        if int(K.LessThan) in total:
+            rc_mult = ctx.upload(np.zeros(256, dtype=np.uint32))
+            bufs.append(rc_mult)
+            lut_tables[int(K.RangeCheckLookup)] = (rc_mult, 256)
         for n in self.nodes:
             t = n.out
             common = dict(num_consumers=t.consumers, is_final_output=t.is_output, rows=tables[n.kind],
@@ -206,12 +234,17 @@ class DeviceGraph:
                 bufs.append(src)
                 _, t.buf = ctx.trace_elementwise(n.kind, src, None, t.size, node_id=t.node_id, input_ids=(),
                                                  input_mults=(), **common)
-            elif n.kind == int(K.SumReduce):
+            elif n.kind in reduces:
                 a = n.inputs[0].base
                 front = int(np.prod(a.shape[:n.axis])) if n.axis else 1
                 back = int(np.prod(a.shape[n.axis + 1:])) if n.axis + 1 < len(a.shape) else 1
                 _, t.buf = ctx.trace_sum_reduce(a.buf, front, a.shape[n.axis], back, node_id=t.node_id,
-                                                input_id=a.node_id, **common)
+                                                input_id=a.node_id, maximum=n.kind == int(K.MaxReduce), **common)
+            elif n.kind == int(K.LessThan):
+                ins = n.inputs
+                _, t.buf = ctx.trace_less_than(ins[0].base.buf, ins[1].base.buf, t.size, node_id=t.node_id,
+                                               input_ids=tuple(i.base.node_id for i in ins), range_check_mult=rc_mult,
+                                               lhs_view=view_of(ins[0]), rhs_view=view_of(ins[1]), **common)
             elif n.kind in _LUT_OF:
                 name = _LUT_OF[n.kind][0]
                 lo, hi, (c0, _) = self.luts[name]

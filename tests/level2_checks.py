@@ -278,3 +278,65 @@ def device_mlp(ctx, widths=(2, 64, 64, 1), seed=42, lut_half_range=8 * 4096):
             h = y
     g.output(h)
     return g, h, ref
+
+
+def check_device_remaining_ops(lib, device=0):
+    """Sqrt, Rem, LessThan (+ RangeCheckLookup table), MaxReduce and Contiguous `process_trace` on the device: rows
+    equal the host generators', and a graph using all of them proves and verifies."""
+    from luminair_amd import synthetic as syn
+    from luminair_amd.graph import DeviceGraph
+    B = backend_mod()
+    cfg = lib.default_config()
+    cfg.protocol_variant = B.VARIANT_PINNED
+    ctx = B.Context(device, cfg, lib)
+    rng = np.random.default_rng(9)
+    n = 77
+    a = rng.integers(1, 1 << 20, size=n).astype(np.int32)
+    m = rng.integers(1, 4096, size=n).astype(np.int32)
+    da, dm = ctx.upload(a), ctx.upload(m)
+    rows, out = ctx.trace_elementwise(7, da, None, n, node_id=2, input_ids=(0,), num_consumers=1, input_mults=(-1,))
+    want = syn.sqrt_rows(a, node=2, input_id=0, mults=(-1, 1))
+    assert np.array_equal(ctx.download(rows).reshape(n, 13), want)
+    s_out = ctx.download(out, np.int32)
+    assert np.array_equal(s_out, want[:, 8].astype(np.int32))
+    rows2, out2 = ctx.trace_elementwise(8, out, dm, n, node_id=3, input_ids=(2, 1), num_consumers=0, is_final_output=True)
+    assert np.array_equal(ctx.download(rows2).reshape(n, 16), syn.rem_rows(s_out, m, node=3, lhs_id=2, rhs_id=1,
+                                                                            mults=(-1, -1, 0)))
+    rows3, _ = ctx.trace_elementwise(16, da, None, n, node_id=4, input_ids=(0,), num_consumers=3, input_mults=(-1,))
+    assert np.array_equal(ctx.download(rows3).reshape(n, 11), syn.contiguous_rows(a, node=4, input_id=0, input_mult=-1,
+                                                                                  out_mult=3))
+    x = rng.integers(-4096, 4096, size=n).astype(np.int32)
+    y = rng.integers(-4096, 4096, size=n).astype(np.int32)
+    y[:5] = x[:5]                                   # equal operands: the borrow / diff = P case
+    dx, dy = ctx.upload(x), ctx.upload(y)
+    rc = ctx.upload(np.zeros(256, dtype=np.uint32))
+    rows4, out4 = ctx.trace_less_than(dx, dy, n, node_id=5, input_ids=(6, 7), num_consumers=0, range_check_mult=rc,
+                                      is_final_output=True)
+    want_rows, want_counts = syn.less_than_rows(x, y, node=5, lhs_id=6, rhs_id=7, mults=(-1, -1, 0))
+    assert np.array_equal(ctx.download(rows4).reshape(n, 22), want_rows)
+    assert np.array_equal(ctx.download(rc).astype(np.int64), want_counts)
+    t = rng.integers(-500, 500, size=(6, 9)).astype(np.int32)
+    dt = ctx.upload(t.reshape(-1))
+    rows5, out5 = ctx.trace_sum_reduce(dt, 6, 9, 1, node_id=8, input_id=9, num_consumers=2, maximum=True)
+    assert np.array_equal(ctx.download(rows5).reshape(54, 15), syn.max_reduce_rows(t, node=8, input_id=9, input_mult=-1,
+                                                                                   out_mult=2))
+    assert np.array_equal(ctx.download(out5, np.int32), t.max(axis=1))
+    for b in (da, dm, rows, out, rows2, out2, rows3, dx, dy, rc, rows4, out4, dt, rows5, out5):
+        b.free()
+    # one graph with all of them: z = max_j sqrt(a)_ij ; r = z % m ; flag = (r < c) ; plus a materialised view
+    g = DeviceGraph(ctx)
+    ta = g.input(rng.integers(1, 1 << 20, size=(10, 6)))
+    tm = g.input(rng.integers(1, 4096, size=10))
+    tc = g.constant(1000)
+    z = g.max_reduce(g.sqrt(ta), axis=1)
+    r = g.rem(z, tm)
+    flag = g.output(g.less_than(r, g.broadcast_to(tc, (10,))))
+    mat = g.output(g.contiguous(g.expand(tm, 0, 3)))
+    tables, luts, bufs = g.gen_trace()
+    assert [k for k, _, _ in tables] == [6, 7, 8, 13, 14, 15, 16]
+    assert g.read(mat).shape == (3, 10) and np.array_equal(g.read(mat)[2], g.read(tm))
+    proof = ctx.prove_tables(tables, luts)
+    lib.verify(proof, B.VARIANT_PINNED)
+    for b in bufs:
+        b.free()
+    ctx.close()

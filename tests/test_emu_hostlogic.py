@@ -102,6 +102,11 @@ def test_emu_device_graph(root):
     check_device_graph(backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so")))
 
 
+def test_emu_device_remaining_ops(root):
+    from level2_checks import check_device_remaining_ops
+    check_device_remaining_ops(backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so")))
+
+
 def test_emu_pinned_variant_with_inputs_component(root):
     """17-slot claim + Inputs table (mixed column sizes inside one Merkle tree)."""
     from oracle.channel import ProtocolVariant

@@ -210,9 +210,10 @@ def test_gpu_device_trace_generation(gpu_prover):
 
 def test_gpu_device_graph_gen_trace_then_prove(hip_lib_path):
     """gen_trace on the device (DeviceGraph over lmn_trace_*) -> lmn_prove on device-resident tables -> lmn_verify."""
-    from level2_checks import check_device_graph
+    from level2_checks import check_device_graph, check_device_remaining_ops
     from luminair_amd import backend
     check_device_graph(backend.Library(hip_lib_path))
+    check_device_remaining_ops(backend.Library(hip_lib_path))
 
 
 def test_gpu_config4_mlp_generated_and_proved_on_device(hip_lib_path):
