@@ -28,3 +28,25 @@ run("3 add 2^21 + mul 2^20 + recip 2^20", syn.config3_mixed())
 t, l = syn.config4_black_scholes_shape()
 run("4 black-scholes shape", t, l, variant=backend.VARIANT_PINNED)
 run("5 256 linear layers 2^24 rows", syn.config5_linear_layers(), reps=3)
+
+# BASELINE config 4 end to end on the device: DeviceGraph gen_trace + prove + verify
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "tests"))
+from level2_checks import device_mlp
+lib = backend.default_library()
+cfg = lib.default_config(); cfg.protocol_variant = backend.VARIANT_PINNED
+ctx = backend.Context(0, cfg, lib)
+res = []
+for _ in range(4):
+    t0 = time.perf_counter()
+    g, out, ref = device_mlp(ctx)
+    tables, luts, bufs = g.gen_trace()
+    t1 = time.perf_counter()
+    proof = ctx.prove_tables(tables, luts)
+    t2 = time.perf_counter()
+    lib.verify(proof, backend.VARIANT_PINNED)
+    t3 = time.perf_counter()
+    for b in bufs:
+        b.free()
+    res.append((1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
+res.sort(key=lambda r: r[0] + r[1])
+print(json.dumps({"config": "4 on device: gen_trace / prove / verify ms", "ms": [round(v, 3) for v in res[1]]}))
