@@ -167,3 +167,32 @@ def test_emu_random_pies_match_oracle(root, seed):
     got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts)
     want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED, luts=luts))
     assert got == want, [k for k, _ in tabs]
+
+
+def test_emu_trace_generation_error_paths(emu_ctx):
+    """lmn_trace_*: argument validation mirrors the reference's failure modes (empty tensors -> EmptyTrace)."""
+    a = emu_ctx.upload(np.arange(1, 9, dtype=np.int32))
+    with pytest.raises(backend.LuminairBackendError) as e:     # view shape does not match the element count
+        emu_ctx.trace_elementwise(0, a, a, 8, node_id=1, input_ids=(0, 0), num_consumers=0,
+                                  lhs_view=backend.LmnView.make((3, 2), (2, 1)))
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    with pytest.raises(backend.LuminairBackendError) as e:     # zero elements
+        emu_ctx.trace_elementwise(0, a, a, 0, node_id=1, input_ids=(0, 0), num_consumers=0)
+    assert e.value.code == backend.ERR_EMPTY_TRACE
+    with pytest.raises(backend.LuminairBackendError) as e:     # SumReduce is not an elementwise kind
+        emu_ctx.trace_elementwise(5, a, a, 8, node_id=1, input_ids=(0, 0), num_consumers=0)
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    with pytest.raises(backend.LuminairBackendError) as e:     # binary op without a right operand
+        emu_ctx.trace_elementwise(1, a, None, 8, node_id=1, input_ids=(0, 0), num_consumers=0)
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    lut = syn.make_lut("exp2", -4, 4)
+    c1, mult = emu_ctx.upload(lut[1]), emu_ctx.upload(np.zeros(len(lut[0]), dtype=np.uint32))
+    with pytest.raises(backend.LuminairBackendError) as e:     # inputs 5..8 lie outside the LUT range [-4, 4]
+        emu_ctx.trace_lut(9, a, 8, node_id=2, input_id=0, num_consumers=0, lut_col1=c1, lo=-4, lut_len=9, mult=mult)
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    # an expanded view: every row reads element r % 2 of a two-element tensor
+    rows, out = emu_ctx.trace_elementwise(16, a, None, 6, node_id=3, input_ids=(0,), num_consumers=1, input_mults=(-1,),
+                                          lhs_view=backend.LmnView.make((3, 2), (0, 1)))
+    assert emu_ctx.download(out, np.int32).tolist() == [1, 2, 1, 2, 1, 2]
+    for b in (a, c1, mult, rows, out):
+        b.free()
