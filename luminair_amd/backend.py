@@ -81,7 +81,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce"]
+           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -130,6 +130,7 @@ class Library:
         lib.lmn_op_grind.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.lmn_upload_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.lmn_trace_elementwise_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_void_p,
                                                 C.POINTER(LmnView), C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p,
                                                 C.c_uint64, C.c_void_p]
@@ -181,13 +182,19 @@ def default_library() -> Library:
 
 
 class DeviceBuffer:
-    def __init__(self, ctx: "Context", ptr: int, nbytes: int):
-        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+    def __init__(self, ctx: "Context", ptr: int, nbytes: int, owned: bool = True):
+        self.ctx, self.ptr, self.nbytes, self.owned = ctx, ptr, nbytes, owned
+
+    def view(self, offset: int, nbytes: int) -> "DeviceBuffer":
+        """A sub-range of this allocation (not owned: freeing it is a no-op)."""
+        if offset < 0 or offset + nbytes > self.nbytes:
+            raise ValueError("view outside the allocation")
+        return DeviceBuffer(self.ctx, self.ptr + offset, nbytes, owned=False)
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.owned:
             self.ctx.lib.lib.lmn_device_free(self.ctx.handle, self.ptr)
-            self.ptr = 0
+        self.ptr = 0
 
 
 class Context:
@@ -230,6 +237,13 @@ class Context:
         self._check(self.lib.lib.lmn_device_alloc(self.handle, nbytes, C.byref(out)))
         return DeviceBuffer(self, out.value, nbytes)
 
+    def upload_to(self, buf: DeviceBuffer, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > buf.nbytes:
+            raise ValueError("destination too small")
+        self._check(self.lib.lib.lmn_upload_to(self.handle, arr.ctypes.data, arr.nbytes, buf.ptr))
+        return buf
+
     def download(self, buf: DeviceBuffer, dtype=np.uint32) -> np.ndarray:
         host = np.empty(buf.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
         self._check(self.lib.lib.lmn_download(self.handle, buf.ptr, host.ctypes.data, buf.nbytes))
@@ -238,13 +252,14 @@ class Context:
     def trace_elementwise(self, kind: int, lhs: DeviceBuffer, rhs: Optional[DeviceBuffer], n: int, node_id: int,
                           input_ids, num_consumers: int, is_final_output: bool = False, input_mults=(-1, -1),
                           rows: Optional[DeviceBuffer] = None, row_offset: int = 0,
-                          lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None):
+                          lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None,
+                          out: Optional[DeviceBuffer] = None):
         """`process_trace` of one Add / Mul / Recip node on device tensors (int32 Fixed<12> values).
         Returns (rows DeviceBuffer, out DeviceBuffer)."""
         ncols = self.lib.kind_columns(kind)
         if rows is None:
             rows = self.alloc((row_offset + n) * ncols * 4)
-        out = self.alloc(n * 4)
+        out = out or self.alloc(n * 4)
         ids = list(input_ids) + [0] * (2 - len(input_ids))
         mults = list(input_mults) + [0] * (2 - len(input_mults))
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(*ids), num_consumers, 1 if is_final_output else 0,
@@ -262,11 +277,11 @@ class Context:
     def trace_lut(self, kind: int, inp: DeviceBuffer, n: int, node_id: int, input_id: int, num_consumers: int,
                   lut_col1: DeviceBuffer, lo: int, lut_len: int, mult: DeviceBuffer, is_final_output: bool = False,
                   input_mult: int = -1, view: Optional[LmnView] = None, rows: Optional[DeviceBuffer] = None,
-                  row_offset: int = 0):
+                  row_offset: int = 0, out: Optional[DeviceBuffer] = None):
         """`process_trace` of a Sin / Exp2 / Log2 node; `mult` (the lookup component's table) is updated in place."""
         if rows is None:
             rows = self.alloc((row_offset + n) * 12 * 4)
-        out = self.alloc(n * 4)
+        out = out or self.alloc(n * 4)
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(input_mult, 0))
         self._check(self.lib.lib.lmn_trace_lut(self.handle, kind, inp.ptr, C.byref(view) if view is not None else None, n,
@@ -276,13 +291,14 @@ class Context:
 
     def trace_sum_reduce(self, inp: DeviceBuffer, front: int, dim: int, back: int, node_id: int, input_id: int,
                          num_consumers: int, is_final_output: bool = False, input_mult: int = -1,
-                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0, maximum: bool = False):
+                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0, maximum: bool = False,
+                         out: Optional[DeviceBuffer] = None):
         """`LuminairSumReduce::process_trace` (or MaxReduce with maximum=True) on a contiguous
         (front, dim, back) int32 device tensor."""
         n_rows, n_out = front * dim * back, front * back
         if rows is None:
             rows = self.alloc((row_offset + n_rows) * (15 if maximum else 14) * 4)
-        out = self.alloc(n_out * 4)
+        out = out or self.alloc(n_out * 4)
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(input_mult, 0))
         fn = self.lib.lib.lmn_trace_max_reduce if maximum else self.lib.lib.lmn_trace_sum_reduce
@@ -292,11 +308,12 @@ class Context:
     def trace_less_than(self, lhs: DeviceBuffer, rhs: DeviceBuffer, n: int, node_id: int, input_ids, num_consumers: int,
                         range_check_mult: DeviceBuffer, is_final_output: bool = False, input_mults=(-1, -1),
                         rows: Optional[DeviceBuffer] = None, row_offset: int = 0,
-                        lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None):
+                        lhs_view: Optional[LmnView] = None, rhs_view: Optional[LmnView] = None,
+                        out: Optional[DeviceBuffer] = None):
         """`LuminairLessThan::process_trace`; `range_check_mult` (256 words) is the RangeCheckLookup table."""
         if rows is None:
             rows = self.alloc((row_offset + n) * 22 * 4)
-        out = self.alloc(n * 4)
+        out = out or self.alloc(n * 4)
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(*input_ids), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(*input_mults))
         self._check(self.lib.lib.lmn_trace_less_than(

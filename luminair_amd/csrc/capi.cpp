@@ -256,3 +256,8 @@ int lmn_trace_max_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front,
   if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->trace_reduce(true, input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
 }
+
+int lmn_upload_to(lmn_ctx* ctx, const void* host, size_t bytes, void* device_dst) {
+  if (!ctx || !host || !device_dst) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->upload_to(host, bytes, device_dst); });
+}

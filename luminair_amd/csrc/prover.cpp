@@ -242,6 +242,13 @@ void* Context::device_alloc(size_t bytes) {
 #endif
   return lmn_dev_malloc(bytes ? bytes : 4);
 }
+void Context::upload_to(const void* host, size_t bytes, void* dst) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  lmn_h2d(dst, host, bytes, stream_);
+  lmn_sync(stream_);  // the host buffer is borrowed only for the duration of the call
+}
 void Context::download(const void* device, void* host, size_t bytes) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
@@ -271,8 +278,7 @@ void Context::trace_reduce(bool is_max, const int32_t* input, uint64_t front, ui
   if (front == 0 || dim == 0 || back == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (front * back * dim >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
   launch_trace_reduce(is_max, input, front, dim, back, trace_node(info), rows + row_offset * (is_max ? 15ull : 14ull), out,
-                      stream_);
-  lmn_sync(stream_);
+                      stream_);  // stream-ordered with every later call on this context (lmn_prove, lmn_download)
 }
 
 // `process_trace` of one Add / Mul / Recip node on device tensors (prim.rs:967-1013, :1090-1139, :388-431)
@@ -335,8 +341,7 @@ void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_vie
   const TraceNode nd = trace_node(info);
   const TraceView tlv = trace_view(lv, n), trv = trace_view(rv, n);
   launch_trace_elementwise((int)kind, lhs, tlv, rhs, trv, n, nd, rows + row_offset * (uint64_t)sp->n_cols, out, aux,
-                           stream_);
-  lmn_sync(stream_);
+                           stream_);  // stream-ordered with every later call on this context
 }
 
 // Twiddle tables for every canonic domain up to 2^max_domain_log (computed

@@ -208,9 +208,22 @@ class DeviceGraph:
         total: Dict[int, int] = {}
         for n in self.nodes:
             total[n.kind] = total.get(n.kind, 0) + rows_of(n)
-        tables = {k: ctx.alloc(total[k] * _NCOLS[k] * 4) for k in total}
+        # one allocation for all tables and tensors (hipMalloc per node would dominate small graphs); the trace
+        # calls are stream-ordered, so nothing waits until the tables are proved or a tensor is read back
+        al = lambda nbytes: (nbytes + 255) & ~255
+        need = sum(al(total[k] * _NCOLS[k] * 4) for k in total) + sum(al(n.out.size * 4) for n in self.nodes) + \
+            sum(al(n.host.size * 4) for n in self.nodes if n.host is not None)
+        slab = ctx.alloc(need)
+        cursor = [0]
+
+        def carve(nbytes):
+            v = slab.view(cursor[0], nbytes)
+            cursor[0] += al(nbytes)
+            return v
+
+        tables = {k: carve(total[k] * _NCOLS[k] * 4) for k in total}
         offset = {k: 0 for k in total}
-        bufs = list(tables.values())
+        bufs = [slab]
         lut_dev, lut_tables, luts_out = {}, {}, {}
         for kind in sorted(total):
             if kind in _LUT_OF:
@@ -228,10 +241,9 @@ class DeviceGraph:
         for n in self.nodes:
             t = n.out
             common = dict(num_consumers=t.consumers, is_final_output=t.is_output, rows=tables[n.kind],
-                          row_offset=offset[n.kind])
+                          row_offset=offset[n.kind], out=carve(t.size * 4))
             if n.kind == int(K.Inputs):
-                src = ctx.upload(n.host.reshape(-1))
-                bufs.append(src)
+                src = ctx.upload_to(carve(n.host.size * 4), n.host.reshape(-1))
                 _, t.buf = ctx.trace_elementwise(n.kind, src, None, t.size, node_id=t.node_id, input_ids=(),
                                                  input_mults=(), **common)
             elif n.kind in reduces:
@@ -258,7 +270,6 @@ class DeviceGraph:
                     n.kind, ins[0].base.buf, ins[1].base.buf if len(ins) > 1 else None, t.size, node_id=t.node_id,
                     input_ids=tuple(i.base.node_id for i in ins), input_mults=tuple(-1 for _ in ins),
                     lhs_view=view_of(ins[0]), rhs_view=view_of(ins[1]) if len(ins) > 1 else None, **common)
-            bufs.append(t.buf)
             offset[n.kind] += rows_of(n)
         out = [(k, tables[k], total[k]) for k in tables] + [(k, b, n) for k, (b, n) in lut_tables.items()]
         return sorted(out, key=lambda e: e[0]), luts_out, bufs
