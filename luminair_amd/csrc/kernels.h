@@ -18,7 +18,7 @@ struct PadRow {
   uint32_t v[32];  // the component's padding row (e.g. add/table.rs:40-58)
 };
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
-                          const PadRow& pad, lmn_stream_t s);
+                          const PadRow& pad, uint32_t* bad_flag /* device word, set when a value >= P */, lmn_stream_t s);
 
 // ---- a4: circle FFT passes.  data = ncols columns of 2^log_n words at stride col_stride.
 // dst may equal src (in place).  launch_fft zero-extends src (2^log_src words) to 2^log_n (LDE).

@@ -17,7 +17,7 @@ static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b -
 // =============================================================================================
 constexpr int TR_ROWS = 64;
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
-                           uint32_t* __restrict__ cols, PadRow pad) {
+                           uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag) {
   LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
   const int stride = ncols + 1;
   const uint64_t row0 = (uint64_t)blockIdx.x * TR_ROWS;
@@ -30,6 +30,7 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
       v = rows[gr * (uint64_t)ncols + c];
     else
       v = pad.v[c];
+    if (v >= P31) *bad_flag = 1u;  // the boundary takes raw u32 words: reject non-canonical M31 values
     tile[r * stride + c] = v;
   }
   __syncthreads();
@@ -40,12 +41,12 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
 }
 
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
-                          const PadRow& pad, lmn_stream_t s) {
+                          const PadRow& pad, uint32_t* bad_flag, lmn_stream_t s) {
   uint64_t size = 1ull << log_size;
   unsigned grid = cdiv(size, TR_ROWS);
   size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
   if (ncols > 32) throw LmnError(-100, "transpose: too many columns");
-  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad);
+  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad, bad_flag);
 }
 
 // =============================================================================================

@@ -180,6 +180,12 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
   event_log = new EventLog();
   pin_cap_ = 32u << 20;
   pin_base_ = (char*)lmn_host_alloc_pinned(pin_cap_);
+  {
+    const uint32_t zero = 0u;
+    bad_flag_ = (uint32_t*)lmn_dev_malloc(4);
+    lmn_h2d(bad_flag_, &zero, 4, stream_);
+    lmn_sync(stream_);
+  }
   if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
   if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
   if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
@@ -196,6 +202,7 @@ Context::~Context() {
   delete static_cast<EventLog*>(event_log);
   event_log = nullptr;
   for (void* p : tw_allocs_) lmn_dev_free(p);
+  if (bad_flag_) lmn_dev_free(bad_flag_);
   if (pin_base_) lmn_host_free_pinned(pin_base_);
 #ifndef LMN_EMU
   (void)hipStreamDestroy(stream_);
@@ -999,6 +1006,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
 
   // ---- PHASE 1: main trace (prover.rs:70-179)
   DevTree tree1;
+  uint32_t* d_bad = bad_flag_;  // persistent device word (zero between proofs), set by the transposes
+  const uint32_t* h_bad = nullptr;
   {
     StageTimer st(this, log, stream_, C_TRANSPOSE);
     for (size_t t = 0; t < infos.size(); ++t) {
@@ -1014,7 +1023,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       PadRow pad{};
       if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
       for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
-      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, pad, stream_);
+      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, pad, d_bad, stream_);
       inst[t].trace_evals = evals;
       proof.claim[ti.spec->kind] = ti.log_size;
     }
@@ -1039,7 +1048,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
     lde_and_merkle(tree1);
+    h_bad = (const uint32_t*)stage_download(d_bad, 4);
     lmn_sync(stream_);
+    if (*h_bad) {
+      const uint32_t zero = 0u;
+      lmn_h2d(d_bad, &zero, 4, stream_);
+      lmn_sync(stream_);
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace table holds a word that is not a canonical M31 (>= 2^31-1)");
+    }
     tree1.merkle.finish_root();
     channel.mix_root(tree1.merkle.root);
   }

@@ -161,6 +161,7 @@ class Context {
     return (T*)stage_upload(v.data(), v.size() * sizeof(T));
   }
   void fetch_root_async(DevMerkle& m);   // m.root_pinned valid after the next sync
+  uint32_t* bad_flag_ = nullptr;  // device word set when a trace table holds a non-canonical M31 word
   char* pin_base_ = nullptr;
   size_t pin_cap_ = 0, pin_off_ = 0;
 

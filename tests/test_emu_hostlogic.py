@@ -56,6 +56,11 @@ def test_emu_error_codes(emu_ctx):
     with pytest.raises(backend.LuminairBackendError) as e:
         emu_ctx.prove_tables([(0, bad, len(bad))])
     assert e.value.code == backend.ERR_CONSTRAINTS
+    bad = syn.config2_add_only(64, 9)[0][1].copy()
+    bad[5, 9] = 0x7fffffff                                    # P itself is not a canonical M31 value
+    with pytest.raises(backend.LuminairBackendError) as e:
+        emu_ctx.prove_tables([(0, bad, len(bad))])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
     with pytest.raises(backend.LuminairBackendError) as e:   # no such TraceTable variant
         emu_ctx.prove_tables([(17, np.zeros((4, 12), np.uint32), 4)])
     assert e.value.code == backend.ERR_INVALID_ARGUMENT

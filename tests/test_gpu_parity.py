@@ -154,6 +154,10 @@ def test_gpu_error_behaviour(gpu_prover):
     with pytest.raises(luminair_amd.LuminairError) as e:
         gpu_prover.prove(luminair_amd.LuminairPie.from_tables([(0, bad)]))
     assert e.value.variant == "ProverError(ConstraintsNotSatisfied)"
+    bad = syn.config2_add_only(1 << 12, 9)[0][1].copy()
+    bad[77, 10] = 0x7fffffff                                  # P itself is not a canonical M31 word
+    with pytest.raises(luminair_amd.LuminairError):
+        gpu_prover.prove(luminair_amd.LuminairPie.from_tables([(0, bad)]))
     # the context stays usable after an error
     assert len(_gpu_bytes(gpu_prover, syn.config2_add_only(64, 9))) > 1000
 
