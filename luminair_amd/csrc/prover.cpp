@@ -317,16 +317,18 @@ void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* vie
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
   if (n >= (1ull << 31) || lut_len == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad sizes");
   const TraceView tv = trace_view(view, n);
-  uint32_t zero = 0u;
-  uint32_t* d_err = (uint32_t*)lmn_dev_malloc(4);
-  lmn_h2d(d_err, &zero, 4, stream_);
-  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, lo, lut_len, mult, rows + row_offset * 12ull, out, d_err,
+  // bad_flag_ is zero between calls; the kernel sets it when an input misses the LUT range
+  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, lo, lut_len, mult, rows + row_offset * 12ull, out, bad_flag_,
                    stream_);
   uint32_t err = 0;
-  lmn_d2h(&err, d_err, 4, stream_);
+  lmn_d2h(&err, bad_flag_, 4, stream_);
   lmn_sync(stream_);
-  lmn_dev_free(d_err);
-  if (err) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: an input value lies outside the LUT's range");
+  if (err) {
+    const uint32_t zero = 0u;
+    lmn_h2d(bad_flag_, &zero, 4, stream_);
+    lmn_sync(stream_);
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: an input value lies outside the LUT's range");
+  }
 }
 
 void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_view* lv, const int32_t* rhs,
