@@ -30,8 +30,8 @@ BUTTERFLY_PEAK_G = 1.0 / (1.0 / 6326.0 + 2.0 / 12800.0)    # G butterflies/s = 1
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 rows of the Add trace (default 20 = BASELINE config 2)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent proofs in flight per GPU (one prover context + HIP stream each)")
