@@ -1061,6 +1061,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     tree1.merkle.finish_root();
     channel.mix_root(tree1.merkle.root);
   }
+  hm.mark("sync1: root1 mixed");
 
   // ---- PHASE 2: interaction trace (prover.rs:186-298)
   const RelElems elems = draw_relation_elements(channel, cfg.protocol_variant);
@@ -1131,6 +1132,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   for (int k = 0; k < n_slots; ++k)
     if (proof.interaction_claim[k].first) channel.mix_felts({proof.interaction_claim[k].second});
   channel.mix_root(tree2.merkle.root);
+  hm.mark("sync2: claims+root2 mixed");
 
   // ---- stwo::prover::prove (prover.rs:312): composition polynomial
   const QM31 comp_alpha = channel.draw_felt();
@@ -1212,6 +1214,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     tree3.merkle.finish_root();
     channel.mix_root(tree3.merkle.root);
   }
+  hm.mark("sync3: root3 mixed");
   DevTree* trees[4] = {&tree0, &tree1, &tree2, &tree3};
   for (auto* t : trees) proof.commitments.push_back(t->merkle.root);
 
@@ -1254,6 +1257,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     }
   }
   proof.sampled_values = sampled;
+  hm.mark("sync4: oods values on host");
   {
     std::vector<QM31> flat;
     for (auto& t : sampled)
@@ -1270,6 +1274,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
 
   // ---- FRI quotients, one secure column per LDE size (descending)
   const QM31 quot_alpha = channel.draw_felt();
+  hm.mark("sampled mixed, oods check, alpha drawn");
   struct FlatCol {
     const uint32_t* lde;
     int lde_log;
@@ -1308,6 +1313,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     }
   }
 
+  hm.mark("quotients enqueued");
   // ---- FRI commit
   struct FriLayer {
     int log;
@@ -1488,11 +1494,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     StageTimer st(this, log, stream_, C_DECOMMIT);
     struct Plan {
       std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
-      Plan() {
-        fri_wit.reserve(64);
-        queried.reserve(256);
-        hash_wit.reserve(128);
-        col_wit.reserve(256);
+      Plan() {  // small reserves only: large ones cost more in page faults than the regrowth they avoid
+        fri_wit.reserve(16);
+        queried.reserve(32);
+        hash_wit.reserve(64);
+        col_wit.reserve(32);
       }
     };
     std::vector<Plan> plans;  // [first, inner..., tree0..3]
@@ -1531,7 +1537,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       plans.push_back(std::move(p));
     }
     std::vector<GatherEntry> entries;
-    entries.reserve(8192);
+    entries.reserve(1024);
     uint32_t out_words = 0;
     auto add_refs = [&](const std::vector<Ref>& refs) {
       for (auto& r : refs) {
@@ -1547,7 +1553,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     }
     const uint32_t* gathered = nullptr;
     if (!entries.empty()) {
-      GatherEntry* d_e = upload_vec(entries);
+      // the entry table is read once, one entry per lane: the kernel takes it straight from pinned host memory
+      GatherEntry* d_e = (GatherEntry*)pin_alloc(entries.size() * sizeof(GatherEntry));
+      memcpy(d_e, entries.data(), entries.size() * sizeof(GatherEntry));
       uint32_t* d_o = arena_.alloc_words(out_words);
       hm.mark("decommit planned");
       launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
