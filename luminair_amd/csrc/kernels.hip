@@ -861,7 +861,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   // lanes swap one hash with lane^1 and ALL 64 lanes compress one level-1 parent (even lanes for the
   // older batch, odd lanes for the newer one); after every fourth batch the same with lane^2, etc.
   // Each lane keeps its pending hash per level in private LDS slots (word 8 = node index).
-  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 9 * TPB];  // [level][word][thread]
+  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 8 * TPB];  // [level][word][thread]
   uint32_t* sh = stack;  // the climb buffer reuses the stack storage once the batch loop is over
   const uint32_t per = 1u << sub;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -889,13 +889,13 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
       uint32_t m[16];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t st = stack[(lvl * 9 + k) * TPB + threadIdx.x];
+        const uint32_t st = stack[(lvl * 8 + k) * TPB + threadIdx.x];
         const uint32_t recv = lmn_shfl_xor(b ? st : cur[k], 1 << lvl);
         m[k] = b ? recv : st;
         m[8 + k] = b ? cur[k] : recv;
       }
-      const uint32_t sidx = stack[(lvl * 9 + 8) * TPB + threadIdx.x];
-      cur_idx = (b ? cur_idx : sidx) >> 1;
+      // the pending (older) node of this lane sits exactly 64 nodes before the newer one at every level
+      cur_idx = (b ? cur_idx : cur_idx - 64u) >> 1;
       b2_init(cur);
       b2_compress(cur, m, 64u, 0xffffffffu);
       jj >>= 1;
@@ -904,8 +904,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     }
     if (lvl < sub) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) stack[(lvl * 9 + k) * TPB + threadIdx.x] = cur[k];
-      stack[(lvl * 9 + 8) * TPB + threadIdx.x] = cur_idx;
+      for (int k = 0; k < 8; ++k) stack[(lvl * 8 + k) * TPB + threadIdx.x] = cur[k];
     }
   }
   __syncthreads();  // every lane is done with its stack slots before they are overwritten
