@@ -17,13 +17,14 @@ static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b -
 // =============================================================================================
 constexpr int TR_ROWS = 64;
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
-                           uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag) {
+                           uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic) {
   LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
   const int stride = ncols + 1;
   const uint64_t row0 = (uint64_t)blockIdx.x * TR_ROWS;
   const int total = TR_ROWS * ncols;
   for (int k = threadIdx.x; k < total; k += blockDim.x) {
-    int r = k / ncols, c = k - r * ncols;
+    // k / ncols by the precomputed reciprocal (exact for k < 2^16): a runtime integer division is ~30 VALU ops
+    const int r = magic ? (int)(((uint64_t)(uint32_t)k * magic) >> 32) : k, c = k - r * ncols;  // magic 0: one column
     uint64_t gr = row0 + r;
     uint32_t v;
     if (gr < n_rows)
@@ -45,8 +46,9 @@ void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int 
   uint64_t size = 1ull << log_size;
   unsigned grid = cdiv(size, TR_ROWS);
   size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
-  if (ncols > 32) throw LmnError(-100, "transpose: too many columns");
-  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad, bad_flag);
+  if (ncols > 32 || ncols < 1) throw LmnError(-100, "transpose: bad column count");
+  const uint32_t magic = ncols == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)ncols - 1) / (uint64_t)ncols);  // ceil(2^32 / ncols)
+  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad, bad_flag, magic);
 }
 
 // =============================================================================================
