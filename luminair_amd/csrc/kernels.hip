@@ -856,6 +856,42 @@ LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, i
   }
 }
 
+// MODE 1: leaf level of a single-size tree (no child layer, one contiguous run of <= 16 columns: one
+// compression per leaf); MODE 2: pure inner level (children only); MODE 0: anything else.  The special modes
+// drop the run selection and the multi-block loop from the hot loop.
+template <int MODE>
+LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16]) {
+  if (MODE == 1) {
+    const uint32_t* __restrict__ base = sg.base[0] + i;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = k < ncols ? base[(uint64_t)k * size] : 0u;
+  } else if (MODE == 2) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
+    uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+    m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+    m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+  } else {
+    merkle_load_first(prev, sg, ncols, size, i, m);
+  }
+}
+template <int MODE>
+LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16], uint32_t h[8]) {
+  if (MODE == 1) {
+    b2_init(h);
+    b2_compress(h, m, 4u * (uint32_t)ncols, 0xffffffffu);
+  } else if (MODE == 2) {
+    b2_init(h);
+    b2_compress(h, m, 64u, 0xffffffffu);
+  } else {
+    merkle_hash_from(prev, sg, ncols, size, i, m, h);
+  }
+}
+
+template <int MODE>
 LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
                           MerkleLevels outs, int sub, int nfused) {
   // Wave-cooperative subtree: in batch j lane l hashes start node W0 + 64*j + l (coalesced column
@@ -872,7 +908,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   uint32_t cur[8];
   uint32_t cur_idx = 0;
   uint32_t mnext[16];
-  merkle_load_first(prev, sg, ncols, size, W0 + lane, mnext);
+  merkle_load_mode<MODE>(prev, sg, ncols, size, W0 + lane, mnext);
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
@@ -881,8 +917,8 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     uint32_t mcur[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) mcur[k] = mnext[k];
-    if (j + 1 < per) merkle_load_first(prev, sg, ncols, size, node + 64u, mnext);
-    merkle_hash_from(prev, sg, ncols, size, node, mcur, cur);
+    if (j + 1 < per) merkle_load_mode<MODE>(prev, sg, ncols, size, node + 64u, mnext);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mcur, cur);
     store_hash(outs.p[0] + (uint64_t)node * 8, cur);
     uint32_t jj = j;
     int lvl = 0;
@@ -1045,7 +1081,13 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
   if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
       size % ((uint32_t)TPB << sub) != 0)
     throw LmnError(-100, "merkle_fused: bad arguments");
-  LMN_LAUNCH(k_merkle_fused, dim3(cdiv(size >> sub, TPB)), dim3(TPB), 0, s, prev, sg, ncols, size, outs, sub, nfused);
+  const dim3 g(cdiv(size >> sub, TPB)), b(TPB);
+  if (!prev && ncols <= 16 && sg.n[0] == ncols)
+    LMN_LAUNCH(k_merkle_fused<1>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
+  else if (prev && ncols == 0)
+    LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
+  else
+    LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
 }
 
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
