@@ -1,0 +1,49 @@
+"""Single-commitment sharding across GPUs: the one part of the path that partitions without moving column data
+(SURVEY.md §8e stage C/D).  Every rank hashes the aligned Merkle subtree over its block of rows on its own GPU;
+the only exchange is an all-gather of the subtree roots (32 bytes per rank, RCCL under the `nccl` backend), after
+which every rank hashes the top log2(world) levels itself (deterministic, identical everywhere).
+
+This is a level-2 building block (`lmn_op_merkle_root` per rank), not a sharded `prove`: DESIGN.md §6 says what a
+full single-proof sharding needs beyond it."""
+from __future__ import annotations
+
+import hashlib
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def _parent(left: bytes, right: bytes) -> bytes:
+    # Blake2sMerkleHasher::hash_node(children, no column values): blake2s(left || right), SURVEY.md Appendix A.4
+    return hashlib.blake2s(left + right, digest_size=32).digest()
+
+
+def row_block(cols: Sequence[np.ndarray], rank: int, world: int) -> List[np.ndarray]:
+    """Rank `rank`'s share of every column: rows [rank*n/world, (rank+1)*n/world) of a column of n rows (columns
+    are in bit-reversed domain order, where an aligned block of rows is an aligned Merkle subtree)."""
+    if world & (world - 1):
+        raise ValueError("world size must be a power of two")
+    out = []
+    for c in cols:
+        n = len(c)
+        if n < world or n & (n - 1):
+            raise ValueError("every column needs a power-of-two length of at least world_size rows")
+        out.append(c[rank * n // world:(rank + 1) * n // world])
+    return out
+
+
+def merkle_root_sharded(ctx, cols: Sequence[np.ndarray], group=None) -> bytes:
+    """Root of the mixed-size-column Merkle tree over `cols`, subtrees sharded over the ranks of `group`
+    (torch.distributed must be initialised; all ranks pass the same columns or at least their own rows)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sub = ctx.merkle_root(row_block(cols, rank, world))          # node `rank` of level log2(world), computed on the GPU
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.frombuffer(bytearray(sub), dtype=torch.uint8).to(dev)
+    parts = [torch.empty(32, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    nodes = [bytes(p.cpu().numpy().tobytes()) for p in parts]
+    while len(nodes) > 1:
+        nodes = [_parent(nodes[2 * i], nodes[2 * i + 1]) for i in range(len(nodes) // 2)]
+    return nodes[0]
