@@ -1059,13 +1059,16 @@ LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32
 
 // Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
 constexpr int MERKLE_SMALL_BLOCK = 1024;
+template <int MODE>
 LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
                           MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   const uint32_t i = threadIdx.x;
   uint32_t cur[8];
   if (i < size) {
-    merkle_hash_start(prev, sg, ncols, size, i, cur);
+    uint32_t m[16];
+    merkle_load_mode<MODE>(prev, sg, ncols, size, i, m);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, i, m, cur);
     store_hash(outs.p[0] + (uint64_t)i * 8, cur);
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
@@ -1095,8 +1098,13 @@ void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
                          lmn_stream_t s) {
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
   if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
-  LMN_LAUNCH(k_merkle_small, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, prev, sg, ncols, size, outs, nfused, ch,
-             alpha_out, root_copy);
+  const dim3 g(1), b(MERKLE_SMALL_BLOCK);
+  if (!prev && ncols <= 16 && sg.n[0] == ncols)
+    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+  else if (prev && ncols == 0)
+    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+  else
+    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
 }
 
 // =============================================================================================
