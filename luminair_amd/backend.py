@@ -81,7 +81,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to"]
+           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -118,6 +118,8 @@ class Library:
         lib.lmn_verify.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.c_uint32]
         lib.lmn_op_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.lmn_op_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.lmn_op_evaluate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_void_p]
         lib.lmn_op_merkle_root.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32,
                                            C.c_void_p]
         lib.lmn_op_eval_at_point.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -377,6 +379,16 @@ class Context:
         out = np.empty((ncols, 1 << log_domain), dtype=np.uint32)
         self._check(self.lib.lib.lmn_op_evaluate(self.handle, a.ctypes.data, ncols, n.bit_length() - 1, log_domain,
                                                  out.ctypes.data))
+        return out
+
+    def evaluate_block(self, coeffs: np.ndarray, log_domain: int, log_blocks: int, block: int) -> np.ndarray:
+        """Rows of block `block` (of 2^log_blocks equal row blocks) of the evaluation of (ncols, 2^k) coefficient
+        columns on the 2^log_domain domain."""
+        a = np.ascontiguousarray(coeffs, dtype=np.uint32)
+        ncols, n = a.shape
+        out = np.empty((ncols, 1 << (log_domain - log_blocks)), dtype=np.uint32)
+        self._check(self.lib.lib.lmn_op_evaluate_block(self.handle, a.ctypes.data, ncols, n.bit_length() - 1, log_domain,
+                                                       log_blocks, block, out.ctypes.data))
         return out
 
     def merkle_root(self, cols: List[np.ndarray]) -> bytes:

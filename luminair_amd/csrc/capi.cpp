@@ -261,3 +261,9 @@ int lmn_upload_to(lmn_ctx* ctx, const void* host, size_t bytes, void* device_dst
   if (!ctx || !host || !device_dst) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->upload_to(host, bytes, device_dst); });
 }
+
+int lmn_op_evaluate_block(lmn_ctx* ctx, const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
+                          uint32_t log_blocks, uint32_t block, uint32_t* evals_out) {
+  if (!ctx || !coeffs || !evals_out || ncols == 0) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->op_evaluate_block(coeffs, ncols, log_coeffs, log_domain, log_blocks, block, evals_out); });
+}

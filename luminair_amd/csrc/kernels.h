@@ -27,6 +27,10 @@ int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_
                 const TwPtrs& itw, lmn_stream_t s);
 int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
                int log_n, const TwPtrs& tw, lmn_stream_t s);
+// forward transform restricted to block `block` of 2^log_blocks equal row blocks of the 2^log_n domain (tw = the
+// twiddles of the whole domain); dst receives 2^(log_n - log_blocks) words per column
+int launch_fft_block(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
+                     int log_n, int log_blocks, uint32_t block, const TwPtrs& tw, lmn_stream_t s);
 // single-layer reference kernels (debug / self-test only)
 void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
                        lmn_stream_t s);

@@ -464,7 +464,8 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
 
 template <bool INV>
 LMN_KERNEL k_fft_staged(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride,
-                        uint64_t src_len, FftStagePlan pl, TwPtrs tw, uint32_t scale, int ncols, int cpb) {
+                        uint64_t src_len, FftStagePlan pl, TwPtrs tw, uint32_t scale, int ncols, int cpb,
+                        uint32_t h_off) {
   LMN_DYN_SMEM(uint32_t, sm);
   // XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8 XCDs (observed, used
   // for speed only), so give each XCD a contiguous run of tiles: neighbouring strided tiles share
@@ -472,8 +473,11 @@ LMN_KERNEL k_fft_staged(uint32_t* data, uint64_t col_stride, const uint32_t* src
   uint32_t tile = blockIdx.x;
   if (pl.xcd_swizzle && (gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint32_t q = tile & ((1u << (pl.lo - pl.cb)) - 1u);
-  const uint32_t H = tile >> (pl.lo - pl.cb);
-  const uint64_t base = ((uint64_t)H << pl.hi) + ((uint64_t)q << pl.cb);
+  const uint32_t Hl = tile >> (pl.lo - pl.cb);
+  const uint64_t base = ((uint64_t)Hl << pl.hi) + ((uint64_t)q << pl.cb);
+  // h_off != 0: the data is one aligned block of a larger domain (row-block sharding): addresses stay local, the
+  // twiddle index carries the block's position
+  const uint32_t H = Hl + h_off;
   for (int cc = 0; cc < cpb; ++cc) {
     const int c = blockIdx.y * cpb + cc;
     if (c >= ncols) break;
@@ -537,7 +541,7 @@ static void split_stages(FftStagePlan& pl) {
 
 template <bool INV>
 static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int log_src,
-                    int ncols, int log_n, const TwPtrs& tw, lmn_stream_t s) {
+                    int ncols, int log_n, const TwPtrs& tw, lmn_stream_t s, uint32_t block_index = 0) {
   if (log_n < 1) throw LmnError(-100, "fft: log_n < 1");
   static const bool use_v1 = getenv("LMN_FFT_V1") != nullptr;
   FftPass passes[8];
@@ -576,7 +580,7 @@ static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uin
     int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
     if (env_thr > 0) threads = env_thr;
     LMN_LAUNCH(k_fft_staged<INV>, dim3(tiles, gy), dim3(threads), smem, s, data, col_stride, psrc, pstride, plen, pl,
-               tw, scale, ncols, cpb);
+               tw, scale, ncols, cpb, block_index << (log_n - p.hi));
   }
   return np;
 }
@@ -588,6 +592,57 @@ int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_
 int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
                int log_n, const TwPtrs& tw, lmn_stream_t s) {
   return run_fft<false>(dst, dst_stride, src, src_stride, log_src, ncols, log_n, tw, s);
+}
+
+// Row-block LDE (single-commitment sharding): block `b` of 2^g equal blocks of the forward transform
+// onto a 2^n domain.  The top g layers pair indices that differ in the block bits only and their twiddle index
+// (idx >> (i+1)) depends on the block bits only, so element t of block b after those layers is a 2^g-point
+// transform across the blocks at fixed t - computed here from the (zero-extended) coefficients; the remaining
+// layers then run inside the block (k_fft_staged with the block's twiddle offset).
+template <int G>
+LMN_KERNEL k_fft_top_block(uint32_t* __restrict__ dst, uint64_t dst_stride, const uint32_t* __restrict__ src,
+                           uint64_t src_stride, uint64_t src_len, int log_n, uint32_t block, TwPtrs tw) {
+  const uint64_t S = 1ull << (log_n - G);
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= S) return;
+  const uint32_t* scol = src + (uint64_t)blockIdx.y * src_stride;
+  uint32_t v[1 << G];
+#pragma unroll
+  for (int c = 0; c < (1 << G); ++c) {
+    const uint64_t idx = (uint64_t)c * S + t;
+    v[c] = idx < src_len ? scol[idx] : 0u;
+  }
+#pragma unroll
+  for (int k = G - 1; k >= 0; --k) {
+    const uint32_t* __restrict__ tl = tw.l[log_n - G + k];
+#pragma unroll
+    for (int c = 0; c < (1 << G); ++c) {
+      if (c & (1 << k)) continue;
+      const uint32_t w = tl[c >> (k + 1)];
+      const uint32_t a = v[c], x = m_mul(v[c | (1 << k)], w);
+      v[c] = m_add(a, x);
+      v[c | (1 << k)] = m_sub(a, x);
+    }
+  }
+  uint32_t out = v[0];
+#pragma unroll
+  for (int c = 1; c < (1 << G); ++c) out = block == (uint32_t)c ? v[c] : out;
+  dst[(uint64_t)blockIdx.y * dst_stride + t] = out;
+}
+
+int launch_fft_block(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
+                     int log_n, int log_blocks, uint32_t block, const TwPtrs& tw, lmn_stream_t s) {
+  if (log_blocks < 1 || log_blocks > 3 || log_n - log_blocks < 1 || block >= (1u << log_blocks))
+    throw LmnError(-100, "fft_block: bad arguments");
+  const int lb = log_n - log_blocks;
+  dim3 g(cdiv(1ull << lb, TPB), ncols), b(TPB);
+  const uint64_t slen = 1ull << log_src;
+  switch (log_blocks) {
+    case 1: LMN_LAUNCH(k_fft_top_block<1>, g, b, 0, s, dst, dst_stride, src, src_stride, slen, log_n, block, tw); break;
+    case 2: LMN_LAUNCH(k_fft_top_block<2>, g, b, 0, s, dst, dst_stride, src, src_stride, slen, log_n, block, tw); break;
+    default: LMN_LAUNCH(k_fft_top_block<3>, g, b, 0, s, dst, dst_stride, src, src_stride, slen, log_n, block, tw); break;
+  }
+  return 1 + run_fft<false>(dst, dst_stride, dst, dst_stride, lb, ncols, lb, tw, s, block);
 }
 
 // one global-memory layer per launch: the obviously-correct reference used by the self-test

@@ -1660,6 +1660,25 @@ void Context::op_evaluate(const uint32_t* coeffs, uint32_t ncols, uint32_t log_c
   lmn_sync(stream_);
 }
 
+void Context::op_evaluate_block(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
+                                uint32_t log_blocks, uint32_t block, uint32_t* out) {
+  if (log_coeffs > log_domain) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "log_coeffs > log_domain");
+  if (log_blocks < 1 || log_blocks > 3 || log_blocks >= log_domain || block >= (1u << log_blocks))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad block specification");
+  ensure_twiddles((int)log_domain);
+  const uint32_t lb = log_domain - log_blocks;
+  size_t in_w = (size_t)ncols << log_coeffs, out_w = (size_t)ncols << lb;
+  arena_.reserve((in_w + out_w) * 4 + (1u << 20));
+  arena_.reset();
+  uint32_t* d_in = arena_.alloc_words(in_w);
+  uint32_t* d_out = arena_.alloc_words(out_w);
+  lmn_h2d(d_in, coeffs, in_w * 4, stream_);
+  launch_fft_block(d_out, 1ull << lb, d_in, 1ull << log_coeffs, (int)log_coeffs, (int)ncols, (int)log_domain,
+                   (int)log_blocks, block, tw((int)log_domain), stream_);
+  lmn_d2h(out, d_out, out_w * 4, stream_);
+  lmn_sync(stream_);
+}
+
 void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols, uint8_t root[32]) {
   size_t words = 0;
   uint32_t max_log = 0;

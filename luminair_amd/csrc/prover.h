@@ -110,6 +110,8 @@ class Context {
   // level-2 ops
   void op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size);
   void op_evaluate(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain, uint32_t* out);
+  void op_evaluate_block(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
+                         uint32_t log_blocks, uint32_t block, uint32_t* out);
   void op_merkle_root(const uint32_t* const* cols, const uint32_t* log_sizes, uint32_t ncols, uint8_t root[32]);
   void op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const uint32_t pt[8], uint32_t out[4]);
   void op_fft_selftest(uint32_t log_size, uint32_t ncols);

@@ -32,13 +32,39 @@ def row_block(cols: Sequence[np.ndarray], rank: int, world: int) -> List[np.ndar
     return out
 
 
+def commit_sharded(ctx, coeff_cols: Sequence[np.ndarray], log_blowup: int = 1, group=None) -> bytes:
+    """`tree_builder.extend_polys(..).commit()` sharded over the ranks of `group` with no bulk exchange
+    (DESIGN.md §6): every rank holds the coefficient columns, evaluates ONLY its block of rows of every column's LDE
+    (`lmn_op_evaluate_block`: the top log2(world) FFT layers reduce to a world-point combination at fixed row, the
+    rest runs inside the block), hashes the Merkle subtree over that block, and the subtree roots are all-gathered.
+    Returns the same root as a single-GPU commit of all columns (world sizes 1, 2, 4, 8)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world & (world - 1) or world > 8:
+        raise ValueError("world size must be 1, 2, 4 or 8")
+    g = world.bit_length() - 1
+    blocks = []
+    for c in coeff_cols:
+        c = np.ascontiguousarray(c, dtype=np.uint32).reshape(1, -1)
+        log_domain = c.shape[1].bit_length() - 1 + log_blowup
+        blocks.append(ctx.evaluate(c, log_domain)[0] if g == 0 else ctx.evaluate_block(c, log_domain, g, rank)[0])
+    return _gather_root(ctx.merkle_root(blocks), group)
+
+
 def merkle_root_sharded(ctx, cols: Sequence[np.ndarray], group=None) -> bytes:
     """Root of the mixed-size-column Merkle tree over `cols`, subtrees sharded over the ranks of `group`
     (torch.distributed must be initialised; all ranks pass the same columns or at least their own rows)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sub = ctx.merkle_root(row_block(cols, rank, world))          # node `rank` of level log2(world), computed on the GPU
+    return _gather_root(ctx.merkle_root(row_block(cols, rank, world)), group)   # node `rank` of level log2(world)
+
+
+def _gather_root(sub: bytes, group=None) -> bytes:
+    """All-gather the per-rank subtree roots and hash the top log2(world) levels (identically on every rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     mine = torch.frombuffer(bytearray(sub), dtype=torch.uint8).to(dev)
     parts = [torch.empty(32, dtype=torch.uint8, device=dev) for _ in range(world)]

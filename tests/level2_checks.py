@@ -340,3 +340,17 @@ def check_device_remaining_ops(lib, device=0):
     for b in bufs:
         b.free()
     ctx.close()
+
+
+def check_evaluate_block(ctx, logs=((5, 6), (9, 10), (12, 13), (13, 14))):
+    """lmn_op_evaluate_block == the matching rows of the full evaluation, for 2 / 4 / 8 blocks."""
+    from oracle.field import P
+    rng = np.random.default_rng(23)
+    for log_coeffs, log_domain in logs:
+        co = rng.integers(0, P, size=(3, 1 << log_coeffs), dtype=np.uint64).astype(np.uint32)
+        full = ctx.evaluate(co, log_domain)
+        for g in (1, 2, 3):
+            S = 1 << (log_domain - g)
+            for b in range(1 << g):
+                got = ctx.evaluate_block(co, log_domain, g, b)
+                assert np.array_equal(got, full[:, b * S:(b + 1) * S]), (log_coeffs, log_domain, g, b)

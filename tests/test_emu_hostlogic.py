@@ -90,8 +90,9 @@ def test_emu_level2_ops(emu_ctx):
     want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
     assert emu_ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
     emu_ctx.fft_selftest(13, 1)
-    from level2_checks import check_quotient_fold_grind_ops
+    from level2_checks import check_evaluate_block, check_quotient_fold_grind_ops
     check_quotient_fold_grind_ops(emu_ctx, 7)
+    check_evaluate_block(emu_ctx)
 
 
 def test_emu_device_trace_generation(emu_ctx):

@@ -184,9 +184,10 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
         c = rng.integers(0, P, size=1 << log, dtype=np.uint64)
         want = fft.eval_at_point(c, (QM31(*pt[:4]), QM31(*pt[4:])))
         assert ctx.eval_at_point(c.astype(np.uint32), pt) == want.v
-    from level2_checks import check_quotient_fold_grind_ops
+    from level2_checks import check_evaluate_block, check_quotient_fold_grind_ops
     for log in (6, 13):
         check_quotient_fold_grind_ops(ctx, log)
+    check_evaluate_block(ctx, logs=((5, 6), (12, 13), (15, 16), (19, 20), (20, 21)))
 
 
 @pytest.mark.parametrize("seed,scale", [(0, 1), (1, 1), (2, 40), (3, 40), (4, 150), (5, 150)])

@@ -34,8 +34,9 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = backend.Context(0, None, backend.Library(os.path.join(ROOT, "tests", "emu", "libluminair_emu.so")))
+    from luminair_amd.sharded import commit_sharded
     root = merkle_root_sharded(ctx, _columns())
-    q.put((rank, root))
+    q.put((rank, root, commit_sharded(ctx, _columns(), 1)))
     ctx.close()
     dist.destroy_process_group()
 
@@ -47,7 +48,11 @@ def test_sharded_merkle_root_equals_oracle(world):
     if not os.path.exists(so):
         import subprocess
         subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True, capture_output=True)
+    from oracle import fft
     want = MerkleTree(_columns()).root()
+    # commit_sharded takes the columns as COEFFICIENTS: the tree is over their blow-up-2 evaluations
+    lde = [fft.evaluate(c.astype(np.uint64).reshape(1, -1), len(c).bit_length())[0].astype(np.uint32) for c in _columns()]
+    want_commit = MerkleTree(lde).root()
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -58,8 +63,9 @@ def test_sharded_merkle_root_equals_oracle(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r for r, _ in res] == list(range(world))
-    assert all(root == want for _, root in res)
+    assert [r for r, _, _ in res] == list(range(world))
+    assert all(root == want for _, root, _ in res)
+    assert all(commit == want_commit for _, _, commit in res)
 
 
 def test_row_block_validation():
@@ -86,6 +92,10 @@ def test_gpu_sharded_merkle_root_single_rank_over_rccl(hip_lib_path):
         ctx = backend.Context(0, None, backend.Library(hip_lib_path))
         cols = _columns() + [np.arange(1 << 16, dtype=np.uint32)]
         assert merkle_root_sharded(ctx, cols) == MerkleTree(cols).root()
+        from luminair_amd.sharded import commit_sharded
+        from oracle import fft
+        lde = [fft.evaluate(c.astype(np.uint64).reshape(1, -1), len(c).bit_length())[0].astype(np.uint32) for c in cols]
+        assert commit_sharded(ctx, cols, 1) == MerkleTree(lde).root()
         ctx.close()
     finally:
         dist.destroy_process_group()
