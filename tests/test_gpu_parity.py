@@ -144,6 +144,32 @@ def test_gpu_two_contexts_concurrently(hip_lib_path):
             assert got == want
 
 
+def test_gpu_four_contexts_full_size_soak(hip_lib_path):
+    """The bench's operating point: four contexts proving the 2^20-row trace concurrently from device-resident rows;
+    every one of 4 x 40 proofs has the same bytes (wave-cooperative hashing, device channel and arenas do not
+    interfere across contexts)."""
+    import hashlib
+    import threading
+    tabs = syn.config2_add_only(1 << 20, 42)
+    provers = [luminair_amd.Prover(0) for _ in range(4)]
+    bufs = [[(k, p.ctx.upload(r), len(r)) for k, r in tabs] for p in provers]
+    ref = hashlib.sha256(provers[0].ctx.prove_tables(bufs[0])).hexdigest()
+    bad = []
+
+    def work(i):
+        for it in range(40):
+            if hashlib.sha256(provers[i].ctx.prove_tables(bufs[i])).hexdigest() != ref:
+                bad.append((i, it))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad
+    for bl in bufs:
+        for _, b, _ in bl:
+            b.free()
+
+
 def test_gpu_error_behaviour(gpu_prover):
     with pytest.raises(luminair_amd.LuminairError) as e:
         gpu_prover.prove(luminair_amd.LuminairPie([luminair_amd.TraceTable(luminair_amd.TraceTableKind.Add,
