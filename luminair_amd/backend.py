@@ -63,6 +63,17 @@ class LmnNodeInfo(C.Structure):
                 ("is_final_output", C.c_uint32), ("input_mults", C.c_int32 * 2)]
 
 
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class LmnCollective(C.Structure):
+    """`lmn_collective`: the one exchange primitive of a sharded proof, an in-place all-gather on device memory."""
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN)]
+
+
+RCCL_ID_BYTES = 128
+
+
 class LmnTimings(C.Structure):
     _fields_ = [("total_ms", C.c_float)] + [(n, C.c_float) for n in (
         "transpose_ms", "main_commit_ms", "logup_ms", "interaction_commit_ms", "composition_ms",
@@ -81,7 +92,8 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block"]
+           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block",
+           "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -133,6 +145,10 @@ class Library:
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_upload_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.lmn_ctx_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(LmnCollective)]
+        lib.lmn_rccl_unique_id.argtypes = [C.c_void_p]
+        lib.lmn_ctx_set_shard_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.lmn_ctx_clear_shard.argtypes = [C.c_void_p]
         lib.lmn_trace_elementwise_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_void_p,
                                                 C.POINTER(LmnView), C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p,
                                                 C.c_uint64, C.c_void_p]
@@ -227,6 +243,40 @@ class Context:
         if rc != LMN_OK:
             msg = self.lib.lib.lmn_last_error(self.handle).decode() or self.lib.lib.lmn_strerror(rc).decode()
             raise LuminairBackendError(rc, msg)
+
+    # ---- single-proof sharding (lmn_ctx_set_shard*)
+    def set_shard(self, rank: int, world: int, all_gather, fri_min_log: int = 0):
+        """Shard every later `prove` over `world` contexts (one per GPU, one per process).  `all_gather(buf_ptr,
+        bytes_per_rank, stream)` is the in-place all-gather of `lmn_collective` (device pointer as an int)."""
+        def _cb(_user, buf, nbytes, stream):
+            try:
+                all_gather(buf, nbytes, stream)
+                return 0
+            except Exception:   # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._shard_cb = ALL_GATHER_FN(_cb)            # keep the trampoline alive as long as the context uses it
+        self._shard_coll = LmnCollective(None, self._shard_cb)
+        self._check(self.lib.lib.lmn_ctx_set_shard(self.handle, rank, world, fri_min_log, C.byref(self._shard_coll)))
+
+    def rccl_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * RCCL_ID_BYTES)()
+        rc = self.lib.lib.lmn_rccl_unique_id(buf)
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, self.lib.lib.lmn_last_error(None).decode() or "lmn_rccl_unique_id failed")
+        return bytes(buf)
+
+    def set_shard_rccl(self, rank: int, world: int, unique_id: bytes, fri_min_log: int = 0):
+        """Built-in transport: RCCL over xGMI on the prover's own stream (`unique_id` from rank 0's rccl_unique_id)."""
+        if len(unique_id) != RCCL_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % RCCL_ID_BYTES)
+        buf = (C.c_uint8 * RCCL_ID_BYTES)(*unique_id)
+        self._check(self.lib.lib.lmn_ctx_set_shard_rccl(self.handle, rank, world, fri_min_log, buf))
+
+    def clear_shard(self):
+        self._check(self.lib.lib.lmn_ctx_clear_shard(self.handle))
+        self._shard_cb = self._shard_coll = None
 
     def upload(self, arr: np.ndarray) -> DeviceBuffer:
         arr = np.ascontiguousarray(arr)

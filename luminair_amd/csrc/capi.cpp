@@ -257,6 +257,30 @@ int lmn_trace_max_reduce(lmn_ctx* ctx, const int32_t* input_dev, uint64_t front,
   return guard(ctx, [&] { ctx->impl->trace_reduce(true, input_dev, front, dim, back, *info, rows_dev, row_offset, out_dev); });
 }
 
+namespace lmn {
+void rccl_unique_id(uint8_t* out);
+}
+int lmn_ctx_set_shard(lmn_ctx* ctx, uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
+  if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->set_shard(rank, world, fri_min_log, coll); });
+}
+int lmn_rccl_unique_id(uint8_t id_out[LMN_RCCL_ID_BYTES]) {
+  if (!id_out) return LMN_ERR_INVALID_ARGUMENT;
+  lmn_ctx tmp{nullptr, {}};
+  int rc = guard(&tmp, [&] { lmn::rccl_unique_id(id_out); });
+  g_create_error = tmp.last_error;
+  return rc;
+}
+int lmn_ctx_set_shard_rccl(lmn_ctx* ctx, uint32_t rank, uint32_t world, uint32_t fri_min_log,
+                           const uint8_t id[LMN_RCCL_ID_BYTES]) {
+  if (!ctx || !id) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->set_shard_rccl(rank, world, fri_min_log, id); });
+}
+int lmn_ctx_clear_shard(lmn_ctx* ctx) {
+  if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->clear_shard(); });
+}
+
 int lmn_upload_to(lmn_ctx* ctx, const void* host, size_t bytes, void* device_dst) {
   if (!ctx || !host || !device_dst) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->upload_to(host, bytes, device_dst); });

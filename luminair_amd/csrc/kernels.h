@@ -141,8 +141,14 @@ struct CompositionArgs {
   int kind;                    // TraceTable kind (LMN_KIND_*)
   int log_size;                // trace log size
   int eval_log;                // eval domain log size
-  const uint32_t* main;        // main columns on the eval domain, stride 2^eval_log
+  // Rows [row0, row0 + n_rows) of the eval domain are evaluated (the whole domain, or one rank's block of a
+  // sharded proof).  main / inter / pre / pre2 hold exactly those rows, columns `stride` words apart; `out` and
+  // `prev_last` span the whole domain (stride 2^eval_log, indexed by the global storage index).
+  uint32_t row0, n_rows;
+  uint64_t stride;
+  const uint32_t* main;        // main columns on the eval domain
   const uint32_t* inter;       // interaction columns on the eval domain
+  const uint32_t* prev_last;   // last 4 interaction columns where the mask offset -1 reads them (other row blocks)
   uint32_t* out;               // 4 coordinate columns, stride 2^eval_log
   int accumulate;              // out += instead of out =
   int zero_slot;               // 1: Mul's second eval_fixed_mul slot contributes zero (KAT form)
@@ -182,7 +188,11 @@ struct QuotEntry {
   QM31 c;                      // alpha^k * c for this (batch, column) sample
 };
 struct QuotientArgs {
-  int log_size;
+  int log_size;                // log size of the whole LDE domain
+  // rows [row0, row0 + 2^log_rows) are computed; entries[].col and out hold exactly those rows
+  uint32_t row0;
+  int log_rows;
+  uint64_t out_stride;         // words between the 4 coordinate columns of out
   int nbatch;
   int batch_start[QUOT_MAX_BATCH + 1];  // range into entries
   const QuotEntry* entries;    // device
@@ -196,9 +206,11 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s);
 
 // ---- a9: FRI folds.  Secure columns are 4 coordinate arrays at stride = length.
 // alpha is read from device memory (written by the device-resident channel).
+// src holds src_len rows (a whole layer or one rank's block; itw_* then points at the block's first twiddle);
+// dst_stride = words between dst's coordinate columns (0: src_len / 2, i.e. dst is exactly the folded rows).
 void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
-                                  const QM31* alpha, int accumulate, lmn_stream_t s);
+                                  const QM31* alpha, int accumulate, lmn_stream_t s, uint64_t dst_stride = 0);
 void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, const QM31* alpha,
-                      lmn_stream_t s);
+                      lmn_stream_t s, uint64_t dst_stride = 0);
 
 }  // namespace lmn

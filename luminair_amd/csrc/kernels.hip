@@ -1486,11 +1486,11 @@ LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint3
 template <int NREL>
 LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t (&mult)[NREL],
                              const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], const int (&rc)[NREL], bool neg,
-                             uint32_t s, uint64_t E) {
+                             uint32_t s, uint32_t t, uint64_t E) {
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
-    QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * E, E, s);
+    QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * a.stride, a.stride, t);
     QM31 den = rc[j] == 1   ? q_sub(q_from_m(val[j]), a.z2)
                : rc[j] == 2 ? q_sub(q_add_m(q_mul_m(a.alpha2, id[j]), val[j]), a.z2)
                             : q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
@@ -1499,7 +1499,7 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32
       diff = q_sub(cur, prev);
     } else {
       uint32_t ps = prev_row_storage(s, a.eval_log, a.log_size);
-      QM31 pr = load_secure(a.inter + (uint64_t)(4 * j) * E, E, ps);
+      QM31 pr = load_secure(a.prev_last, E, ps);
       diff = q_add(q_sub(q_sub(cur, pr), prev), a.claimed_shift[1]);
     }
     ca.add_q(q_sub_m(q_mul(diff, den), neg ? m_neg(mult[j]) : mult[j]));
@@ -1510,11 +1510,13 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32
 template <int KIND>
 LMN_KERNEL k_composition(CompositionArgs a) {
   const uint64_t E = 1ull << a.eval_log;
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= E) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // row inside the block handled by this launch
+  if (t >= a.n_rows) return;
+  const uint32_t s = a.row0 + t;                             // storage index on the whole eval domain
   ConsAcc ca{qacc_zero(), a.coeff, 0};
-  const uint32_t* __restrict__ mn = a.main + s;
-#define LMN_COL(k) mn[(uint64_t)(k) * E]
+  const uint32_t* __restrict__ mn = a.main + t;
+  const uint64_t cstride = a.stride;
+#define LMN_COL(k) mn[(uint64_t)(k) * cstride]
   if (KIND == 0 || KIND == 1) {
     // Add (15 cols) / Mul (16 cols: rem inserted at 12)
     constexpr bool mul = KIND == 1;
@@ -1538,7 +1540,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
     const int rc[3] = {0, 0, 0};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 2 || KIND == 7) {
     // Recip / Sqrt (13 cols; the eval_fixed_* forms are unpinned natural identities)
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -1556,7 +1558,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     const int rc[2] = {0, 0};
-    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 8) {
     // Rem (16 cols): lhs = rhs*quotient + rem (unpinned form); the out relation carries `rem`
     const uint32_t node = LMN_COL(0), lhs_id = LMN_COL(1), rhs_id = LMN_COL(2), idx = LMN_COL(3), is_last = LMN_COL(4);
@@ -1572,7 +1574,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, rem}, ri[3] = {lhs_id, rhs_id, node};
     const int rc[3] = {0, 0, 0};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 13) {
     // LessThan (22 cols; less_than/component.rs:48-185): 9 local constraints, 3 node relations +
     // 4 range-check relations on the 8-bit limbs of diff
@@ -1594,18 +1596,18 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     const uint32_t rm[7] = {m0, m1, m2, md, md, md, md}, rv[7] = {lhs, rhs, out, l0, l1, l2, l3};
     const uint32_t ri[7] = {lhs_id, rhs_id, node, 0u, 0u, 0u, 0u};
     const int rc[7] = {0, 0, 0, 1, 1, 1, 1};
-    logup_constraints<7>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<7>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 14) {
     // RangeCheckLookup: multiplicity column + preprocessed LUT column, relation (-multiplicity, [lut])
-    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[s]}, ri[1] = {0u};
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {0u};
     const int rc[1] = {1};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, E);
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 4) {
     // SinLookup / Exp2Lookup / Log2Lookup (lookups/sin/component.rs:40-59): multiplicity column + the two
     // preprocessed LUT columns, relation (-multiplicity, [lut_0, lut_1])
-    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[s]}, ri[1] = {a.pre2[s]};
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {a.pre2[t]};
     const int rc[1] = {2};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, E);
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 3) {
     // Sin / Exp2 / Log2 (12 cols; sin/component.rs:50-122): the function value is enforced by the LUT
     // relation (lookup_mult, [input, out]) only
@@ -1620,7 +1622,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {inp, out, inp}, ri[3] = {in_id, node, out};
     const int rc[3] = {0, 0, 2};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 5 || KIND == 6 || KIND == 16) {
     // SumReduce (14 cols) / MaxReduce (15) / Contiguous (11): shared id/idx prefix, 2 relations
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -1648,7 +1650,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     const int rc[2] = {0, 0};
-    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, t, E);
   } else {
     const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
     const uint32_t val = LMN_COL(5), mult = LMN_COL(6);
@@ -1658,7 +1660,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[1] = {mult}, rv[1] = {val}, ri[1] = {node};
     const int rc[1] = {0};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, E);
+    logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, t, E);
   }
 #undef LMN_COL
   QM31 r = q_mul_m(qacc_reduce(ca.acc), a.zinv[(s >> a.log_size) & 1u]);
@@ -1677,7 +1679,9 @@ LMN_KERNEL k_composition(CompositionArgs a) {
 
 void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
   if (a.eval_log != a.log_size + 1) throw LmnError(-100, "composition: eval domain must be log_size+1");
-  dim3 g(cdiv(1ull << a.eval_log, TPB)), b(TPB);
+  if (a.n_rows == 0 || (uint64_t)a.row0 + a.n_rows > (1ull << a.eval_log) || a.stride < a.n_rows || !a.prev_last)
+    throw LmnError(-100, "composition: bad row block");
+  dim3 g(cdiv(a.n_rows, TPB)), b(TPB);
   switch (a.kind) {
     case 0: LMN_LAUNCH(k_composition<0>, g, b, 0, s, a); break;
     case 1: LMN_LAUNCH(k_composition<1>, g, b, 0, s, a); break;
@@ -1863,16 +1867,15 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
   const int nent = a.batch_start[NB];
   for (int e = threadIdx.x; e < nent; e += blockDim.x) tab[e] = a.entries[e];
   __syncthreads();
-  const uint32_t L = 1u << a.log_size;
-  const uint32_t Q = L / QUOT_ROWS;
-  const uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t Q = (1u << a.log_rows) / QUOT_ROWS;
+  const uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x;  // row inside the block handled by this launch
   if (s0 >= Q) return;
   constexpr int NE = QUOT_ROWS * NB;
   CM31 den[NE];
   uint32_t nrm[NE], pre[NE], ys[QUOT_ROWS];
 #pragma unroll
   for (int k = 0; k < QUOT_ROWS; ++k) {
-    const uint32_t s = s0 + (uint32_t)k * Q;
+    const uint32_t s = a.row0 + s0 + (uint32_t)k * Q;  // storage index on the whole domain
     const uint32_t x = a.log_size >= 2 ? domain_x(a.tw_x, s) : 0u;
     const uint32_t y = domain_y(a.tw_y, s);
     ys[k] = y;
@@ -1927,17 +1930,19 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
     }
     uint32_t* o = a.out + s;
     o[0] = row.a;
-    o[L] = row.b;
-    o[2ull * L] = row.c;
-    o[3ull * L] = row.d;
+    o[a.out_stride] = row.b;
+    o[2ull * a.out_stride] = row.c;
+    o[3ull * a.out_stride] = row.d;
   }
 }
 
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
   if (a.nbatch < 1 || a.nbatch > QUOT_MAX_BATCH) throw LmnError(-100, "quotients: bad batch count");
   if (a.batch_start[a.nbatch] > QUOT_MAX_ENTRIES) throw LmnError(-100, "quotients: too many column samples");
-  if (a.log_size < 2) throw LmnError(-100, "quotients: domain too small");
-  dim3 g(cdiv((1ull << a.log_size) / QUOT_ROWS, TPB)), b(TPB);
+  if (a.log_size < 2 || a.log_rows < 2 || a.log_rows > a.log_size || (a.row0 & ((1u << a.log_rows) - 1u)) ||
+      a.out_stride < (1ull << a.log_rows))
+    throw LmnError(-100, "quotients: bad row block");
+  dim3 g(cdiv((1ull << a.log_rows) / QUOT_ROWS, TPB)), b(TPB);
   switch (a.nbatch) {
     case 1: LMN_LAUNCH(k_quotients<1>, g, b, 0, s, a); break;
     case 2: LMN_LAUNCH(k_quotients<2>, g, b, 0, s, a); break;
@@ -1950,10 +1955,11 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
 // a9  FRI folds
 // =============================================================================================
 LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t src_len,
-                  const uint32_t* __restrict__ itw, const QM31* __restrict__ alpha_ptr, int accumulate) {
+                  const uint32_t* __restrict__ itw, const QM31* __restrict__ alpha_ptr, int accumulate,
+                  uint64_t dst_stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = src_len >> 1;
-  if (i >= n) return;
+  if (i >= (src_len >> 1)) return;
+  const uint64_t n = dst_stride;
   const QM31 alpha = *alpha_ptr;
   const uint64_t L = src_len;
   QM31 a{src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
@@ -1962,22 +1968,24 @@ LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, 
   QM31 f1 = q_mul_m(q_sub(a, b), itw[i]);
   QM31 r = q_add(f0, q_mul(alpha, f1));
   if (accumulate) {
-    QM31 d{dst[i], dst[(uint64_t)n + i], dst[2ull * n + i], dst[3ull * n + i]};
+    QM31 d{dst[i], dst[n + i], dst[2ull * n + i], dst[3ull * n + i]};
     r = q_add(q_mul(d, q_mul(alpha, alpha)), r);
   }
   dst[i] = r.a;
-  dst[(uint64_t)n + i] = r.b;
+  dst[n + i] = r.b;
   dst[2ull * n + i] = r.c;
   dst[3ull * n + i] = r.d;
 }
 
 void launch_fold_circle_into_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_y,
-                                  const QM31* alpha, int accumulate, lmn_stream_t s) {
-  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_y, alpha, accumulate);
+                                  const QM31* alpha, int accumulate, lmn_stream_t s, uint64_t dst_stride) {
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_y, alpha, accumulate,
+             dst_stride ? dst_stride : (uint64_t)(src_len / 2));
 }
 void launch_fold_line(uint32_t* dst, const uint32_t* src, uint32_t src_len, const uint32_t* itw_x, const QM31* alpha,
-                      lmn_stream_t s) {
-  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_x, alpha, 0);
+                      lmn_stream_t s, uint64_t dst_stride) {
+  LMN_LAUNCH(k_fold, dim3(cdiv(src_len / 2, TPB)), dim3(TPB), 0, s, dst, src, src_len, itw_x, alpha, 0,
+             dst_stride ? dst_stride : (uint64_t)(src_len / 2));
 }
 
 }  // namespace lmn

@@ -165,6 +165,9 @@ struct StageTimer {
 static EventLog* g_log(Context* c) { return static_cast<EventLog*>(c->event_log); }
 
 // ------------------------------------------------------------------------------------ context
+static void rccl_release(void* transport);  // single-proof sharding section below
+void rccl_unique_id(uint8_t* out);
+
 Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
 #ifndef LMN_EMU
   int n = 0;
@@ -201,6 +204,8 @@ Context::~Context() {
 #endif
   delete static_cast<EventLog*>(event_log);
   event_log = nullptr;
+  if (shard_.rccl) rccl_release(shard_.rccl);
+  shard_.rccl = nullptr;
   for (void* p : tw_allocs_) lmn_dev_free(p);
   if (bad_flag_) lmn_dev_free(bad_flag_);
   if (pin_base_) lmn_host_free_pinned(pin_base_);
@@ -438,23 +443,14 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
 // Merkle tree over columns sorted by size (descending, stable): SURVEY.md Appendix A.4.
 // Levels are produced by fused subtree launches: a start level (children hashes and/or its own
 // columns) plus up to 8 following levels that have no columns of their own.
-void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
-                           DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
-  m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].second;
-  m.layers.assign(m.max_log + 1, nullptr);
-  if (cols_sorted.empty()) {
-    m.root = b2_hash_words(nullptr, 0);
-    return;
-  }
-  for (int log = m.max_log; log >= 0; --log) m.layers[log] = arena_.alloc_words((size_t)8 << log);
-  // columns per level
-  std::vector<std::vector<const uint32_t*>> per_level(m.max_log + 1);
-  for (auto& c : cols_sorted) per_level[c.second].push_back(c.first);
+void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
+                                  const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch,
+                                  QM31* alpha_out, uint32_t* root_copy) {
   bool chan_done = false;
   {
     StageTimer t(this, g_log(this), stream_, C_MERKLE);
     const uint32_t* prev = nullptr;
-    int level = m.max_log;
+    int level = max_log;
     while (level >= 0) {
       auto& lc = per_level[level];
       // runs of contiguous equal-size columns
@@ -476,8 +472,8 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
       if (!seg_ok) {
         // rare scattered level: pointer-table kernel, one level per launch
         const uint32_t** dptrs = (const uint32_t**)stage_upload(lc.data(), lc.size() * sizeof(void*));
-        merkle_layer_timed(prev, dptrs, (int)lc.size(), 1u << level, m.layers[level]);
-        prev = m.layers[level];
+        merkle_layer_timed(prev, dptrs, (int)lc.size(), 1u << level, layers[level]);
+        prev = layers[level];
         level -= 1;
         continue;
       }
@@ -487,7 +483,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
       int nfused;
       if (level <= 10) {
         nfused = std::min(plain, 10);
-        for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
+        for (int l = 0; l <= nfused; ++l) outs.p[l] = layers[level - l];
         bool to_root = level - nfused == 0;
         launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, to_root ? ch : nullptr, alpha_out,
                             root_copy, stream_);
@@ -498,7 +494,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
         int sub = std::max(0, std::min(std::min(MERKLE_MAX_SUB, nfused), level - 17));
         if (const char* e = getenv("LMN_MERKLE_SUB")) sub = std::min(std::min(atoi(e), nfused), MERKLE_MAX_SUB);
         nfused = std::min(nfused, sub + 8);
-        for (int l = 0; l <= nfused; ++l) outs.p[l] = m.layers[level - l];
+        for (int l = 0; l <= nfused; ++l) outs.p[l] = layers[level - l];
         StageTimer tf(this, g_log(this), stream_, C_MERKLE_FUSED);
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_);
         timings.merkle_fused_launches++;
@@ -518,16 +514,83 @@ void Context::build_merkle(DevMerkle& m, const std::vector<std::pair<const uint3
         timings.merkle_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
         for (int l = 1; l <= nfused; ++l) timings.merkle_compressions += (uint64_t)1 << (level - l);
       }
-      prev = m.layers[level - nfused];
+      prev = layers[level - nfused];
       level -= nfused + 1;
     }
   }
-  if (ch && !chan_done) launch_chan_mix_root_draw(ch, m.layers[0], alpha_out, root_copy, stream_);
+  if (ch && !chan_done) launch_chan_mix_root_draw(ch, layers[0], alpha_out, root_copy, stream_);
 }
 
-// columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches)
+void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch, QM31* alpha_out,
+                           uint32_t* root_copy, bool sharded) {
+  m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].log;
+  m.layers.assign(m.max_log + 1, nullptr);
+  m.g = 0;
+  if (cols_sorted.empty()) {
+    m.root = b2_hash_words(nullptr, 0);
+    return;
+  }
+  if (!sharded) {
+    for (int log = m.max_log; log >= 0; --log) m.layers[log] = arena_.alloc_words((size_t)8 << log);
+    std::vector<std::vector<const uint32_t*>> per_level(m.max_log + 1);
+    for (auto& c : cols_sorted) {
+      if (c.sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: sharded column in a replicated tree");
+      per_level[c.log].push_back(c.ptr);
+    }
+    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy);
+    return;
+  }
+  // Sharded tree (SURVEY.md §8e stage C/D): the aligned block of rows [rank * 2^(k-g), (rank+1) * 2^(k-g)) of every
+  // column of log size k is the leaf data of subtree `rank` below level g.  Hash that subtree here, all-gather the
+  // world subtree roots (32 B each) and hash the top g levels identically on every rank.
+  const int g = shard_.g;
+  m.g = g;
+  const int loc_log = m.max_log - g;
+  if (loc_log < 0) throw LmnError(LMN_ERR_INTERNAL, "merkle: tree smaller than the shard count");
+  std::vector<std::vector<const uint32_t*>> per_level(loc_log + 1);
+  for (auto& c : cols_sorted) {
+    if (c.log < g) throw LmnError(LMN_ERR_INTERNAL, "merkle: column smaller than the shard count");
+    per_level[c.log - g].push_back(c.sharded ? c.ptr : c.ptr + ((uint64_t)shard_.rank << (c.log - g)));
+  }
+  uint32_t* level_g = arena_.alloc_words((size_t)8 << g);  // node r = root of rank r's subtree
+  std::vector<uint32_t*> loc(loc_log + 1, nullptr);
+  loc[0] = level_g + 8ull * shard_.rank;
+  for (int l = loc_log; l >= 1; --l) loc[l] = arena_.alloc_words((size_t)8 << l);
+  build_merkle_levels(loc, loc_log, per_level, nullptr, nullptr, nullptr);
+  for (int l = 1; l <= loc_log; ++l) m.layers[l + g] = loc[l];
+  m.layers[g] = level_g;
+  gather_columns(level_g, 0, 1, 8);
+  if (g == 0) {
+    if (ch) launch_chan_mix_root_draw(ch, level_g, alpha_out, root_copy, stream_);
+    return;
+  }
+  for (int l = g - 1; l >= 0; --l) m.layers[l] = arena_.alloc_words((size_t)8 << l);
+  MerkleLevels outs{};
+  for (int l = 0; l <= g - 1; ++l) outs.p[l] = m.layers[g - 1 - l];
+  MerkleSegs none{};
+  StageTimer t(this, g_log(this), stream_, C_MERKLE);
+  launch_merkle_small(level_g, none, 0, 1u << (g - 1), outs, g - 1, ch, alpha_out, root_copy, stream_);
+  timings.merkle_launches++;
+  timings.merkle_compressions += (1ull << g) - 1;
+}
+
+// In-place all-gather of column blocks through the shard's collective (RCCL over xGMI, or the caller's callback).
+void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank) {
+  if (!shard_.active) throw LmnError(LMN_ERR_INTERNAL, "gather without a shard");
+  for (int c = 0; c < ncols; ++c) {
+    int rc = shard_.coll.all_gather(shard_.coll.user, base + (uint64_t)c * col_stride, (size_t)words_per_rank * 4,
+                                    (void*)(uintptr_t)stream_);
+    if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
+  }
+}
+
+// columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
+// shard set, only this rank's aligned block of rows of every LDE is evaluated (launch_fft_block: the top
+// log2(world) layers collapse to a world-point combination at fixed row, the rest runs inside the block).
 void Context::lde_and_merkle(DevTree& tree) {
   const int lb = (int)cfg.log_blowup;
+  const bool sh = shard_.active;
+  const int g = sh ? shard_.g : 0;
   size_t i = 0;
   while (i < tree.cols.size()) {
     size_t j = i;
@@ -536,21 +599,28 @@ void Context::lde_and_merkle(DevTree& tree) {
     while (j < tree.cols.size() && tree.cols[j].log_size == log && tree.cols[j].coeffs == tree.cols[i].coeffs + (j - i) * n)
       ++j;
     int ncols = (int)(j - i);
-    uint64_t L = n << lb;
+    uint64_t L = (n << lb) >> g;  // rows held here
     uint32_t* lde = arena_.alloc_words((size_t)ncols * L);
     {
       StageTimer t(this, g_log(this), stream_, C_FFT);
-      timings.fft_launches += launch_fft(lde, L, tree.cols[i].coeffs, n, log, ncols, log + lb, tw(log + lb), stream_);
+      if (g == 0)
+        timings.fft_launches += launch_fft(lde, L, tree.cols[i].coeffs, n, log, ncols, log + lb, tw(log + lb), stream_);
+      else
+        timings.fft_launches += launch_fft_block(lde, L, tree.cols[i].coeffs, n, log, ncols, log + lb, g, shard_.rank,
+                                                 tw(log + lb), stream_);
       timings.fft_bytes += (uint64_t)ncols * (4ull * n + 4ull * L);
       timings.fft_butterflies += (uint64_t)ncols * (L / 2) * (uint64_t)(log + lb);
     }
-    for (int c = 0; c < ncols; ++c) tree.cols[i + c].lde = lde + (uint64_t)c * L;
+    for (int c = 0; c < ncols; ++c) {
+      tree.cols[i + c].lde = lde + (uint64_t)c * L;
+      tree.cols[i + c].sharded = sh;
+    }
     i = j;
   }
-  std::vector<std::pair<const uint32_t*, int>> sorted;
-  for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb});
-  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
-  build_merkle(tree.merkle, sorted);
+  std::vector<ColRef> sorted;
+  for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb, c.sharded});
+  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
+  build_merkle(tree.merkle, sorted, nullptr, nullptr, nullptr, sh);
   fetch_root_async(tree.merkle);
 }
 
@@ -713,13 +783,26 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
 }
 
 // ------------------------------------------------------------------------------------ decommit planning
+// A run of device words to fetch.  owner < 0: every rank holds it; otherwise only rank `owner` does (row-block
+// sharded column or Merkle layer) and ptr is meaningful on that rank alone.
 struct Ref {
   const uint32_t* ptr;
   uint32_t len;
+  int owner;
 };
+static Ref col_ref(const ColRef& c, uint64_t row, int g) {
+  if (!c.sharded) return {c.ptr + row, 1, -1};
+  const int sh = c.log - g;
+  return {c.ptr + (row & ((1ull << sh) - 1)), 1, (int)(row >> sh)};
+}
+static Ref node_ref(const DevMerkle& m, int layer, uint64_t node) {
+  if (m.g == 0 || layer <= m.g) return {m.layers[layer] + node * 8, 8, -1};
+  const int sh = layer - m.g;
+  return {m.layers[layer] + (node & ((1ull << sh) - 1)) * 8, 8, (int)(node >> sh)};
+}
 
 // MerkleProver::decommit: emits device references in output order
-static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
+static void plan_merkle_decommit(const DevMerkle& m, const std::vector<ColRef>& cols_sorted, int g,
                                  const std::map<int, std::vector<uint32_t>>& queries, std::vector<Ref>& queried,
                                  std::vector<Ref>& hash_wit, std::vector<Ref>& col_wit) {
   size_t pos = 0;
@@ -728,7 +811,7 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair
   total.reserve(16);
   for (int log = m.max_log; log >= 0; --log) {
     size_t start = pos;
-    while (pos < cols_sorted.size() && cols_sorted[pos].second == log) ++pos;
+    while (pos < cols_sorted.size() && cols_sorted[pos].log == log) ++pos;
     bool have_prev = log < m.max_log;
     static const std::vector<uint32_t> kNone;
     auto it = queries.find(log);
@@ -747,15 +830,15 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<std::pair
         if (pi < last.size() && last[pi] == 2 * node)
           ++pi;
         else
-          hash_wit.push_back({m.layers[log + 1] + (uint64_t)(2 * node) * 8, 8});
+          hash_wit.push_back(node_ref(m, log + 1, 2ull * node));
         if (pi < last.size() && last[pi] == 2 * node + 1)
           ++pi;
         else
-          hash_wit.push_back({m.layers[log + 1] + (uint64_t)(2 * node + 1) * 8, 8});
+          hash_wit.push_back(node_ref(m, log + 1, 2ull * node + 1));
       }
       bool is_q = ci < colq.size() && colq[ci] == node;
       if (is_q) ++ci;
-      for (size_t c = start; c < pos; ++c) (is_q ? queried : col_wit).push_back({cols_sorted[c].first + node, 1});
+      for (size_t c = start; c < pos; ++c) (is_q ? queried : col_wit).push_back(col_ref(cols_sorted[c], node, g));
       total.push_back(node);
     }
     last.swap(total);
@@ -771,8 +854,8 @@ static std::vector<uint32_t> fold_positions(const std::vector<uint32_t>& p, int 
   return out;
 }
 
-// compute_decommitment_positions_and_witness_evals with fold_step = 1; `col` = 4 coordinate arrays
-static void plan_fri_witness(const uint32_t* col, uint64_t len, const std::vector<uint32_t>& qpos,
+// compute_decommitment_positions_and_witness_evals with fold_step = 1; `cols` = the 4 coordinate columns
+static void plan_fri_witness(const ColRef (&cols)[4], int g, const std::vector<uint32_t>& qpos,
                              std::vector<uint32_t>& dec_pos, std::vector<Ref>& wit) {
   size_t i = 0;
   while (i < qpos.size()) {
@@ -782,7 +865,7 @@ static void plan_fri_witness(const uint32_t* col, uint64_t len, const std::vecto
     for (uint32_t pos = start; pos < start + 2; ++pos) {
       dec_pos.push_back(pos);
       if (std::find(subset.begin(), subset.end(), pos) != subset.end()) continue;
-      for (int k = 0; k < 4; ++k) wit.push_back({col + (uint64_t)k * len + pos, 1});
+      for (int k = 0; k < 4; ++k) wit.push_back(col_ref(cols[k], pos, g));
     }
   }
 }
@@ -807,7 +890,7 @@ struct HostMarks {
 // (p.y, v) and (conj p.y, conj v) gives coefficients a, b, c scaled by alpha^k.
 QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                          const std::vector<std::vector<std::pair<int, QM31>>>& samples,
-                                         const std::vector<QPt>& points, QM31 quot_alpha) {
+                                         const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out) {
   std::vector<int> batch_point;
   std::vector<std::vector<std::pair<int, QM31>>> batch_cols;
   for (size_t c = 0; c < cols.size(); ++c)
@@ -856,7 +939,10 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
   a.entries = upload_vec(entries);
   a.tw_y = twY_[ls];
   a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
-  a.out = arena_.alloc_words(4ull << ls);
+  a.row0 = 0;
+  a.log_rows = ls;
+  a.out_stride = 1ull << ls;
+  a.out = alloc_out ? arena_.alloc_words(4ull << ls) : nullptr;
   return a;
 }
 
@@ -909,6 +995,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     words += (uint64_t)sp->n_pre * (4ull << ls);               // preprocessed columns: evals + coeffs + lde
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
+    if (shard_.active) words += (4ull << (ls + 1)) + 4096;     // halo rows of the last logup column group
   }
   const int comp_log = max_log + 1;
   const int max_lde = comp_log + lb;
@@ -1145,6 +1232,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   {
     StageTimer st(this, log, stream_, C_COMPOSITION);
     std::map<int, uint32_t*> sub;  // eval log -> 4 x 2^e accumulation buffer
+    const int sg = shard_.active ? shard_.g : 0;
     int k0 = 0;
     for (auto& ci : inst) {
       int e = ci.log_size + 1;
@@ -1157,6 +1245,27 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       a.eval_log = e;
       a.main = tree1.cols[ci.main_start].lde;
       a.inter = tree2.cols[ci.inter_start].lde;
+      a.row0 = shard_.rank << (e - sg);
+      a.n_rows = (uint32_t)(E >> sg);
+      a.stride = E >> sg;
+      const int last_group = 4 * (ci.spec->n_rel - 1);
+      if (sg == 0) {
+        a.prev_last = a.inter + (uint64_t)last_group * E;
+      } else {
+        // The mask offset -1 of the last logup column group reads other row blocks: under bit reversal the previous
+        // row of block b lies in block rev(rev(b)+1) (odd storage indices) or rev(rev(b)-1) (even ones).  Evaluate
+        // those two blocks of the group's 4 columns here as well, straight from the coefficients.
+        uint32_t* halo = arena_.alloc_words(4 * E);
+        const uint32_t G = 1u << sg, rb = bit_reverse(shard_.rank, sg);
+        const uint32_t nb[2] = {bit_reverse((rb + 1) & (G - 1), sg), bit_reverse((rb + G - 1) & (G - 1), sg)};
+        for (int h = 0; h < (nb[0] == nb[1] ? 1 : 2); ++h) {
+          StageTimer t(this, log, stream_, C_FFT);
+          timings.fft_launches += launch_fft_block(halo + (uint64_t)nb[h] * (E >> sg), E,
+                                                   tree2.cols[ci.inter_start + last_group].coeffs, 1ull << ci.log_size,
+                                                   ci.log_size, 4, e, sg, nb[h], tw(e), stream_);
+        }
+        a.prev_last = halo;
+      }
       a.out = sub[e];
       a.accumulate = first ? 0 : 1;
       a.z = elems.z[ELEMS_NODE];
@@ -1180,6 +1289,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       }
       launch_composition(a, stream_);
     }
+    // sharded: every rank evaluated its row block of each per-size accumulator; make them whole everywhere (the
+    // one bulk exchange of the proof: 16 B per eval-domain row in total) before the interpolation
+    if (shard_.active)
+      for (auto& kv : sub) gather_columns(kv.second, 1ull << kv.first, 4, (1ull << kv.first) >> sg);
     // DomainEvaluationAccumulator::finalize: fold smaller sizes into larger ones
     uint32_t* cur = nullptr;  // coefficients, 4 x 2^cur_log
     int cur_log = 0;
@@ -1275,8 +1388,15 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // ---- FRI quotients, one secure column per LDE size (descending)
   const QM31 quot_alpha = channel.draw_felt();
   hm.mark("sampled mixed, oods check, alpha drawn");
+  // sharding of the FRI part: a quotient column / FRI layer of more than 2^fri_T rows is split into row blocks
+  // (pair folds stay inside a block: rows 2i and 2i+1 are adjacent in bit-reversed order); smaller ones are
+  // all-gathered once and finished identically on every rank
+  const bool sh = shard_.active;
+  const int g = sh ? shard_.g : 0;
+  const int fri_T = std::max(shard_.fri_min_log, (int)cfg.log_last_layer + lb);
+  auto sharded_log = [&](int lg) { return sh && lg > fri_T; };
   struct FlatCol {
-    const uint32_t* lde;
+    const uint32_t* lde;  // all rows, or this rank's block of them (sharded proof)
     int lde_log;
     std::vector<std::pair<int, QM31>> samples;  // (point index, value)
   };
@@ -1292,7 +1412,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   std::vector<int> sizes(size_set.begin(), size_set.end());
   struct Quot {
     int log;
-    uint32_t* vals;  // 4 x 2^log
+    uint32_t* vals;  // 4 x 2^log, or 4 x 2^(log-g) (this rank's rows) when sharded
+    bool sharded;
   };
   std::vector<Quot> quots;
   {
@@ -1307,9 +1428,26 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         ptrs.push_back(c->lde);
         smp.push_back(c->samples);
       }
-      QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha);
+      QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha, !sh);
+      uint32_t* vals = a.out;
+      const bool qs = sharded_log(ls);
+      const uint64_t L = 1ull << ls, Lb = L >> g;
+      if (sh) {
+        a.row0 = shard_.rank << (ls - g);
+        a.log_rows = ls - g;
+        if (qs) {
+          vals = arena_.alloc_words(4 * Lb);
+          a.out = vals;
+          a.out_stride = Lb;
+        } else {
+          vals = arena_.alloc_words(4 * L);
+          a.out = vals + a.row0;
+          a.out_stride = L;
+        }
+      }
       launch_quotients(a, stream_);
-      quots.push_back({ls, a.out});
+      if (sh && !qs) gather_columns(vals, L, 4, Lb);
+      quots.push_back({ls, vals, qs});
     }
   }
 
@@ -1317,18 +1455,22 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // ---- FRI commit
   struct FriLayer {
     int log;
-    uint32_t* vals;  // 4 x 2^log (line evaluation)
+    uint32_t* vals;  // 4 x 2^log (line evaluation), or this rank's 4 x 2^(log-g) rows when sharded
+    bool sharded;
     DevMerkle merkle;
   };
+  auto secure_cols = [&](const uint32_t* vals, int lg, bool s, std::vector<ColRef>& out) {
+    const uint64_t stride = s ? (1ull << (lg - g)) : (1ull << lg);
+    for (int k = 0; k < 4; ++k) out.push_back({vals + (uint64_t)k * stride, lg, s});
+  };
   DevMerkle first_merkle;
-  std::vector<std::pair<const uint32_t*, int>> first_cols;
+  std::vector<ColRef> first_cols;
   std::vector<FriLayer> inner;
   std::vector<QM31> last_vals;
   int last_log = 0;
   {
     StageTimer st(this, log, stream_, C_FRI);
-    for (auto& q : quots)
-      for (int k = 0; k < 4; ++k) first_cols.push_back({q.vals + ((uint64_t)k << q.log), q.log});
+    for (auto& q : quots) secure_cols(q.vals, q.log, q.sharded, first_cols);
     // The FRI commit loop runs without host round trips: a device-resident copy of the channel
     // mixes each layer root and draws the folding alpha; the host replays the same steps afterwards.
     int ls0 = quots[0].log;
@@ -1342,14 +1484,39 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
     uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);
     int n_roots = 0;
-    build_merkle(first_merkle, first_cols, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots);
+    build_merkle(first_merkle, first_cols, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, sharded_log(ls0));
     ++n_roots;
+    // fold of a (whole or row-block) source into a (whole or row-block) destination one size smaller; a sharded
+    // source folds its own pairs only: into its own block of a sharded destination, or into its rows of a whole
+    // one (all-gathered by the caller afterwards).  Line domain of log L: x-coordinates of CanonicCoset(L+1)'s half coset.
+    auto fold = [&](bool circle, uint32_t* dst, bool dst_s, const uint32_t* src, int src_log, bool src_s, const QM31* alpha,
+                    int accumulate) {
+      const uint32_t* itw = circle ? itwY_[src_log] : itwX_[src_log + 1];
+      if (!src_s) {
+        if (circle)
+          launch_fold_circle_into_line(dst, src, 1u << src_log, itw, alpha, accumulate, stream_);
+        else
+          launch_fold_line(dst, src, 1u << src_log, itw, alpha, stream_);
+        return;
+      }
+      const uint32_t src_len = 1u << (src_log - g);
+      const uint32_t off = shard_.rank << (src_log - 1 - g);  // first folded row (= first twiddle) of this block
+      uint32_t* d = dst_s ? dst : dst + off;
+      const uint64_t dstride = dst_s ? 0 : (1ull << (src_log - 1));
+      if (circle)
+        launch_fold_circle_into_line(d, src, src_len, itw + off, alpha, accumulate, stream_, dstride);
+      else
+        launch_fold_line(d, src, src_len, itw + off, alpha, stream_, dstride);
+    };
+    auto layer_alloc = [&](int lg, bool s) { return arena_.alloc_words(s ? (4ull << (lg - g)) : (4ull << lg)); };
     int layer_log = ls0 - 1;
-    uint32_t* layer = arena_.alloc_words(4ull << layer_log);
-    launch_fold_circle_into_line(layer, quots[0].vals, 1u << ls0, itwY_[ls0], d_alphas + (n_roots - 1), 0, stream_);
+    bool lay_sh = sharded_log(layer_log);
+    uint32_t* layer = layer_alloc(layer_log, lay_sh);
+    fold(true, layer, lay_sh, quots[0].vals, ls0, quots[0].sharded, d_alphas + (n_roots - 1), 0);
+    if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
     size_t qi = 1;
     while (layer_log > last_size_log) {
-      if (layer_log <= 10 && qi == quots.size()) {
+      if (!lay_sh && layer_log <= 10 && qi == quots.size()) {
         // all remaining layers fit one block: commit + fold them in a single launch
         int n_tail = layer_log - last_size_log;
         std::vector<FriTailLayer> tl(n_tail);
@@ -1358,6 +1525,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
           FriLayer fl;
           fl.log = L;
           fl.vals = layer;
+          fl.sharded = false;
           fl.merkle.max_log = L;
           fl.merkle.layers.assign(L + 1, nullptr);
           for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
@@ -1382,22 +1550,26 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       FriLayer fl;
       fl.log = layer_log;
       fl.vals = layer;
-      std::vector<std::pair<const uint32_t*, int>> lc;
-      for (int k = 0; k < 4; ++k) lc.push_back({layer + ((uint64_t)k << layer_log), layer_log});
-      build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots);
+      fl.sharded = lay_sh;
+      std::vector<ColRef> lc;
+      secure_cols(layer, layer_log, lay_sh, lc);
+      build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, lay_sh);
       ++n_roots;
       const QM31* d_alpha = d_alphas + (n_roots - 1);
-      uint32_t* next = arena_.alloc_words(4ull << (layer_log - 1));
-      // line domain of log L has the x-coordinates of CanonicCoset(L+1)'s half coset
-      launch_fold_line(next, layer, 1u << layer_log, itwX_[layer_log + 1], d_alpha, stream_);
+      const int next_log = layer_log - 1;
+      const bool next_sh = sharded_log(next_log);
+      uint32_t* next = layer_alloc(next_log, next_sh);
+      fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
       inner.push_back(fl);
-      layer = next;
-      layer_log -= 1;
-      while (qi < quots.size() && quots[qi].log - 1 == layer_log) {
-        launch_fold_circle_into_line(layer, quots[qi].vals, 1u << quots[qi].log, itwY_[quots[qi].log], d_alpha, 1,
-                                     stream_);
+      while (qi < quots.size() && quots[qi].log - 1 == next_log) {
+        fold(true, next, next_sh, quots[qi].vals, quots[qi].log, quots[qi].sharded, d_alpha, 1);
         ++qi;
       }
+      // a quotient column of this size is sharded exactly when the layer is, so one test covers both sources
+      if (lay_sh && !next_sh) gather_columns(next, 1ull << next_log, 4, (1ull << next_log) >> g);
+      layer = next;
+      layer_log = next_log;
+      lay_sh = next_sh;
     }
     hm.mark("fri enqueued");
     // one sync: roots + alphas back, then replay the transcript on the host channel
@@ -1506,42 +1678,50 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     {
       Plan p;
       std::map<int, std::vector<uint32_t>> dec;
-      for (auto& q : quots) plan_fri_witness(q.vals, 1ull << q.log, pos_by_log[q.log], dec[q.log], p.fri_wit);
+      for (size_t qk = 0; qk < quots.size(); ++qk) {
+        const ColRef(&c4)[4] = *reinterpret_cast<const ColRef(*)[4]>(&first_cols[4 * qk]);
+        plan_fri_witness(c4, g, pos_by_log[quots[qk].log], dec[quots[qk].log], p.fri_wit);
+      }
       std::vector<Ref> dummy;
-      plan_merkle_decommit(first_merkle, first_cols, dec, dummy, p.hash_wit, p.col_wit);
+      plan_merkle_decommit(first_merkle, first_cols, g, dec, dummy, p.hash_wit, p.col_wit);
       plans.push_back(std::move(p));
     }
     std::vector<uint32_t> lq = fold_positions(queries, 1);
     for (auto& fl : inner) {
       Plan p;
       std::map<int, std::vector<uint32_t>> dec;
-      plan_fri_witness(fl.vals, 1ull << fl.log, lq, dec[fl.log], p.fri_wit);
-      std::vector<std::pair<const uint32_t*, int>> lc;
-      for (int k = 0; k < 4; ++k) lc.push_back({fl.vals + ((uint64_t)k << fl.log), fl.log});
+      std::vector<ColRef> lc;
+      secure_cols(fl.vals, fl.log, fl.sharded, lc);
+      const ColRef(&c4)[4] = *reinterpret_cast<const ColRef(*)[4]>(lc.data());
+      plan_fri_witness(c4, g, lq, dec[fl.log], p.fri_wit);
       std::vector<Ref> dummy;
-      plan_merkle_decommit(fl.merkle, lc, dec, dummy, p.hash_wit, p.col_wit);
+      plan_merkle_decommit(fl.merkle, lc, g, dec, dummy, p.hash_wit, p.col_wit);
       plans.push_back(std::move(p));
       lq = fold_positions(lq, 1);
     }
     for (auto* t : trees) {
       Plan p;
-      std::vector<std::pair<const uint32_t*, int>> sorted;
+      std::vector<ColRef> sorted;
       std::map<int, std::vector<uint32_t>> qmap;
       sorted.reserve(t->cols.size());
       for (auto& c : t->cols) {
-        sorted.push_back({c.lde, c.log_size + lb});
+        sorted.push_back({c.lde, c.log_size + lb, c.sharded});
         if (!qmap.count(c.log_size + lb)) qmap[c.log_size + lb] = pos_by_log[c.log_size + lb];
       }
-      std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
-      plan_merkle_decommit(t->merkle, sorted, qmap, p.queried, p.hash_wit, p.col_wit);
+      std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
+      plan_merkle_decommit(t->merkle, sorted, g, qmap, p.queried, p.hash_wit, p.col_wit);
       plans.push_back(std::move(p));
     }
+    // Every rank plans the same list; it fetches the runs it holds into its own slot of the output buffer, the
+    // slots are all-gathered (a few KB per rank) and each run is then read from its owner's slot.
     std::vector<GatherEntry> entries;
     entries.reserve(1024);
+    std::vector<std::pair<int, uint32_t>> runs;  // (owner, len) in output order
     uint32_t out_words = 0;
     auto add_refs = [&](const std::vector<Ref>& refs) {
       for (auto& r : refs) {
-        entries.push_back({arena_.word_offset(r.ptr), r.len, out_words});
+        if (r.owner < 0 || r.owner == (int)shard_.rank) entries.push_back({arena_.word_offset(r.ptr), r.len, out_words});
+        if (sh) runs.push_back({r.owner, r.len});
         out_words += r.len;
       }
     };
@@ -1552,15 +1732,29 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       add_refs(p.col_wit);
     }
     const uint32_t* gathered = nullptr;
-    if (!entries.empty()) {
+    std::vector<uint32_t> merged;
+    if (out_words) {
+      const uint32_t slots = sh ? shard_.world : 1u, mine = sh ? shard_.rank : 0u;
+      for (auto& e : entries) e.dst_off += mine * out_words;
       // the entry table is read once, one entry per lane: the kernel takes it straight from pinned host memory
-      GatherEntry* d_e = (GatherEntry*)pin_alloc(entries.size() * sizeof(GatherEntry));
+      GatherEntry* d_e = (GatherEntry*)pin_alloc((entries.size() + 1) * sizeof(GatherEntry));
       memcpy(d_e, entries.data(), entries.size() * sizeof(GatherEntry));
-      uint32_t* d_o = arena_.alloc_words(out_words);
+      uint32_t* d_o = arena_.alloc_words((size_t)slots * out_words);
       hm.mark("decommit planned");
       launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
-      gathered = (const uint32_t*)stage_download(d_o, (size_t)out_words * 4);
+      if (sh) gather_columns(d_o, 0, 1, out_words);
+      gathered = (const uint32_t*)stage_download(d_o, (size_t)slots * out_words * 4);
       lmn_sync(stream_);
+      if (sh) {
+        merged.resize(out_words);
+        uint32_t at = 0;
+        for (auto& r : runs) {
+          const uint32_t slot = r.first < 0 ? mine : (uint32_t)r.first;
+          memcpy(&merged[at], gathered + (size_t)slot * out_words + at, (size_t)r.second * 4);
+          at += r.second;
+        }
+        gathered = merged.data();
+      }
     }
     size_t g = 0;
     auto take_q = [&](size_t nrefs) {
@@ -1631,6 +1825,124 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   return proof_to_bincode(proof);
 }
 
+// ------------------------------------------------------------------------------------ single-proof sharding
+#ifndef LMN_EMU
+}  // namespace lmn
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace lmn {
+// Built-in transport: RCCL over xGMI, bound at run time (the library has no link-time dependency on librccl, so a
+// single-GPU deployment never loads it).  One communicator per context, collectives enqueued on the prover's stream.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  static RcclApi& get() {
+    static RcclApi api = [] {
+      RcclApi a;
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) break;
+      }
+      if (a.handle) {
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+      }
+      return a;
+    }();
+    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather)
+      throw LmnError(LMN_ERR_NO_DEVICE, "librccl could not be loaded (needed for lmn_ctx_set_shard_rccl)");
+    return api;
+  }
+};
+struct RcclTransport {
+  ncclComm_t comm = nullptr;
+  uint32_t rank = 0;
+  static int all_gather(void* user, void* buf, size_t bytes, void* stream) {
+    RcclTransport* t = (RcclTransport*)user;
+    ncclResult_t r = RcclApi::get().AllGather((const char*)buf + (size_t)t->rank * bytes, buf, bytes, ncclUint8, t->comm,
+                                              (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : (int)r;
+  }
+};
+void rccl_unique_id(uint8_t* out) {
+  static_assert(sizeof(ncclUniqueId) <= LMN_RCCL_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+  ncclUniqueId id;
+  ncclResult_t r = RcclApi::get().GetUniqueId(&id);
+  if (r != ncclSuccess) throw LmnError(LMN_ERR_INTERNAL, "ncclGetUniqueId failed");
+  memset(out, 0, LMN_RCCL_ID_BYTES);
+  memcpy(out, &id, sizeof id);
+}
+void Context::set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id_bytes) {
+  LMN_HIP_CHECK(hipSetDevice(device_));
+  clear_shard();
+  if (world == 0 || (world & (world - 1)) || world > 8 || rank >= world)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: world must be 1, 2, 4 or 8 and rank < world");
+  ncclUniqueId id;
+  memcpy(&id, id_bytes, sizeof id);
+  RcclTransport* t = new RcclTransport();
+  t->rank = rank;
+  ncclResult_t r = RcclApi::get().CommInitRank(&t->comm, (int)world, id, (int)rank);
+  if (r != ncclSuccess) {
+    delete t;
+    throw LmnError(LMN_ERR_INTERNAL, "ncclCommInitRank failed");
+  }
+  lmn_collective c{t, &RcclTransport::all_gather};
+  try {
+    set_shard(rank, world, fri_min_log, &c);
+  } catch (...) {
+    RcclApi::get().CommDestroy(t->comm);
+    delete t;
+    throw;
+  }
+  shard_.rccl = t;
+}
+static void rccl_release(void* p) {
+  RcclTransport* t = (RcclTransport*)p;
+  if (t->comm) RcclApi::get().CommDestroy(t->comm);
+  delete t;
+}
+#else
+void rccl_unique_id(uint8_t*) { throw LmnError(LMN_ERR_NO_DEVICE, "no RCCL in the emulation build"); }
+void Context::set_shard_rccl(uint32_t, uint32_t, uint32_t, const uint8_t*) {
+  throw LmnError(LMN_ERR_NO_DEVICE, "no RCCL in the emulation build");
+}
+static void rccl_release(void*) {}
+#endif
+
+void Context::set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
+  if (world == 0 || (world & (world - 1)) || world > 8 || rank >= world)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: world must be 1, 2, 4 or 8 and rank < world");
+  if (!coll || !coll->all_gather) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: missing all_gather");
+  int g = 0;
+  while ((1u << g) < world) ++g;
+  if (fri_min_log == 0) fri_min_log = 12;
+  // a split quotient column / FRI layer needs at least 4 rows per rank
+  if ((int)fri_min_log < g + 1 || fri_min_log > 30) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: bad fri_min_log");
+  lmn_sync(stream_);
+  void* keep = shard_.rccl;
+  shard_ = Shard{};
+  shard_.rccl = keep;
+  shard_.active = true;
+  shard_.rank = rank;
+  shard_.world = world;
+  shard_.g = g;
+  shard_.fri_min_log = (int)fri_min_log;
+  shard_.coll = *coll;
+}
+
+void Context::clear_shard() {
+  lmn_sync(stream_);
+  if (shard_.rccl) rccl_release(shard_.rccl);
+  shard_ = Shard{};
+}
+
 // ------------------------------------------------------------------------------------ level-2 ops
 void Context::op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size) {
   ensure_twiddles((int)log_size);
@@ -1688,13 +2000,13 @@ void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_si
   }
   arena_.reserve((words + (16ull << max_log)) * 4 + (1u << 20));
   arena_.reset();
-  std::vector<std::pair<const uint32_t*, int>> sorted;
+  std::vector<ColRef> sorted;
   for (uint32_t c = 0; c < ncols; ++c) {
     uint32_t* d = arena_.alloc_words(1ull << log_sizes[c]);
     lmn_h2d(d, cols[c], (4ull << log_sizes[c]), stream_);
-    sorted.push_back({d, (int)log_sizes[c]});
+    sorted.push_back({d, (int)log_sizes[c], false});
   }
-  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.second > b.second; });
+  std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
   g_log(this)->reset();
   DevMerkle m;
   build_merkle(m, sorted);

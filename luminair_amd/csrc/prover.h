@@ -81,11 +81,23 @@ struct DevColumn {
   int log_size;      // polynomial (coefficient) log size
   uint32_t* coeffs;  // 2^log_size
   uint32_t* lde;     // 2^(log_size + log_blowup), bit-reversed canonic-domain evaluations
+  bool sharded = false;  // lde holds only this rank's block of 2^(log_size + log_blowup - g) rows
+};
+
+// A column as the Merkle / decommitment code sees it.  sharded: ptr is this rank's aligned block of
+// 2^(log - g) rows (row r of the column lives on rank r >> (log - g)); otherwise ptr holds all 2^log rows.
+struct ColRef {
+  const uint32_t* ptr;
+  int log;
+  bool sharded;
 };
 
 struct DevMerkle {
   int max_log = -1;
-  std::vector<uint32_t*> layers;  // layers[k]: 2^k hashes of 8 words
+  // layers[k]: 2^k hashes of 8 words.  In a sharded tree (g > 0) the layers k > g hold only this rank's
+  // 2^(k-g) nodes (node n lives on rank n >> (k - g)); layers k <= g are complete on every rank.
+  std::vector<uint32_t*> layers;
+  int g = 0;
   Hash32 root;
   const uint32_t* root_pinned = nullptr;  // pending async download of layers[0]
   void finish_root() {
@@ -120,6 +132,11 @@ class Context {
                                const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4], uint32_t* out);
   void op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]);
 
+  // single-proof sharding (lmn_ctx_set_shard / lmn_ctx_set_shard_rccl)
+  void set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll);
+  void set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id);
+  void clear_shard();
+
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
   void upload_to(const void* host, size_t bytes, void* dst);
@@ -144,14 +161,21 @@ class Context {
   void ensure_twiddles(int max_domain_log);
   TwPtrs tw(int domain_log) const;
   TwPtrs itw(int domain_log) const;
-  // commit `cols` (coefficients already in place) -> LDE + Merkle
+  // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
   void lde_and_merkle(DevTree& tree);
-  void build_merkle(DevMerkle& m, const std::vector<std::pair<const uint32_t*, int>>& cols_sorted,
-                    DevChannel* ch = nullptr, QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr);
+  // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its
+  // row block, the subtree roots are all-gathered and the top log2(world) levels are hashed on every rank.
+  void build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch = nullptr,
+                    QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr, bool sharded = false);
+  void build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
+                           const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch, QM31* alpha_out,
+                           uint32_t* root_copy);
+  // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
+  void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
   QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                   const std::vector<std::vector<std::pair<int, QM31>>>& samples,
-                                  const std::vector<QPt>& points, QM31 quot_alpha);
+                                  const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
@@ -166,6 +190,16 @@ class Context {
   uint32_t* bad_flag_ = nullptr;  // device word set when a trace table holds a non-canonical M31 word
   char* pin_base_ = nullptr;
   size_t pin_cap_ = 0, pin_off_ = 0;
+
+  struct Shard {
+    bool active = false;
+    uint32_t rank = 0, world = 1;
+    int g = 0;             // log2(world)
+    int fri_min_log = 12;  // FRI layers / quotient columns of at most 2^fri_min_log rows are replicated
+    lmn_collective coll{};
+    void* rccl = nullptr;  // built-in RCCL transport (RcclTransport in prover.cpp)
+  } shard_;
+  uint32_t block_rows(int log) const { return 1u << (log - shard_.g); }  // rows of a 2^log column held per rank
 
   int device_;
   lmn_stream_t stream_{};

@@ -13,6 +13,35 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 
+def shard_context(ctx, group=None, fri_min_log: int = 0):
+    """Make `ctx.prove_tables` a single proof sharded over the ranks of `group` (torch.distributed must be
+    initialised; one context per rank; every rank passes the same tables and receives the same proof bytes).
+    `nccl` backend: the library's own RCCL communicator on the prover's stream (`lmn_ctx_set_shard_rccl`), the
+    128-byte unique id travels through a torch broadcast.  `gloo` backend (CPU tests over the emulation build, where
+    "device" pointers are host pointers): the `lmn_collective` callback form over `dist.all_gather`."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(ctx.rccl_unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(ident, 0, group=group)
+        ctx.set_shard_rccl(rank, world, bytes(ident.cpu().numpy().tobytes()), fri_min_log)
+        return
+
+    def all_gather(buf, nbytes, _stream):
+        whole = np.ctypeslib.as_array((C.c_uint8 * (nbytes * world)).from_address(buf))
+        t = torch.from_numpy(whole)
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, t[rank * nbytes:(rank + 1) * nbytes].clone(), group=group)
+        for r, part in enumerate(parts):
+            if r != rank:
+                t[r * nbytes:(r + 1) * nbytes] = part
+    ctx.set_shard(rank, world, all_gather, fri_min_log)
+
+
 def _parent(left: bytes, right: bytes) -> bytes:
     # Blake2sMerkleHasher::hash_node(children, no column values): blake2s(left || right), SURVEY.md Appendix A.4
     return hashlib.blake2s(left + right, digest_size=32).digest()

@@ -1,0 +1,139 @@
+"""Single-proof sharding (BASELINE configs 4/5): `lmn_prove` on world-2 and world-4 process groups
+(gloo, the TEST-ONLY emulation build, the `lmn_collective` callback as transport) must return, on every rank, exactly
+the bytes an unsharded context produces - for one table, mixed-size tables, a config-5-shaped pie and a pie with
+lookups, with the FRI sharding threshold low enough that split layers, the split -> replicated transition and the
+replicated tail are all exercised."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libluminair_emu.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cases():
+    """(name, tables, luts, pinned variant?)"""
+    sys.path.insert(0, ROOT)
+    from luminair_amd import synthetic as syn
+    act, luts = syn.activation_graph(40, 8, names=("sin", "exp2"))
+    return [
+        ("2a-small", syn.config2_add_only(300, 1), None, False),
+        ("config3-small", syn.config3_mixed(8, 7, 7, 2), None, False),
+        ("mixed-sizes", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])], None, False),
+        ("config5-small", syn.config5_linear_layers(3, 4, 5, 8), None, False),
+        ("2b-small (Inputs component)", syn.config2_graph_faithful(200, 3), None, True),
+        ("less-than + range-check LUT", syn.less_than_graph(40, 5), None, True),
+        ("sin/exp2 + LUT tree 0", act, luts, True),
+    ]
+
+
+def _prove_all(make_ctx):
+    out = []
+    ctxs = {}
+    for name, tabs, luts, pinned in _cases():
+        if pinned not in ctxs:
+            ctxs[pinned] = make_ctx(pinned)
+        proof = ctxs[pinned].prove_tables([(k, r, len(r)) for k, r in tabs], luts)
+        out.append((name, hashlib.sha256(proof).hexdigest(), len(proof)))
+    for c in ctxs.values():
+        c.close()
+    return out
+
+
+def _make_ctx(pinned):
+    from luminair_amd import backend
+    lib = backend.Library(EMU)
+    cfg = lib.default_config()
+    if pinned:
+        cfg.protocol_variant = backend.VARIANT_PINNED
+    return backend.Context(0, cfg, lib)
+
+
+def _worker(rank, world, port, fri_min_log, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from luminair_amd.sharded import shard_context
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def make(pinned):
+            ctx = _make_ctx(pinned)
+            shard_context(ctx, fri_min_log=fri_min_log)
+            return ctx
+        q.put((rank, _prove_all(make)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single():
+    return _prove_all(_make_ctx)
+
+
+@pytest.fixture(scope="module")
+def single_rank_proofs():
+    if not os.path.exists(EMU):
+        import subprocess
+        subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True, capture_output=True)
+    return _single()
+
+
+@pytest.mark.parametrize("world,fri_min_log", [(2, 4), (4, 5), (2, 0)])
+def test_sharded_prove_is_byte_identical(world, fri_min_log, single_rank_proofs):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fri_min_log, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r for r, _ in res] == list(range(world))
+    for _, out in res:
+        assert out == single_rank_proofs
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_prove_single_rank_over_rccl(hip_lib_path):
+    """The sharded code path on the real library with its built-in RCCL transport (librccl dlopen'ed,
+    `lmn_ctx_set_shard_rccl`, collectives on the prover's own stream) and one rank: row-block commits, the
+    all-gathers of subtree roots / composition evaluations / FRI layers / decommitted values all run (over a
+    1-rank communicator) and the proof must equal the unsharded one byte for byte, at two FRI thresholds."""
+    import torch.distributed as dist
+    from luminair_amd import backend, synthetic as syn
+    from luminair_amd.sharded import shard_context
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    except Exception as e:      # an environment without a usable RCCL transport is not a parity failure
+        pytest.skip("nccl process group unavailable: %s" % e)
+    try:
+        lib = backend.Library(hip_lib_path)
+        plain = backend.Context(0, None, lib)
+        cases = [syn.config2_add_only(1 << 14, 3), syn.config3_mixed(13, 12, 12, 4), syn.config5_linear_layers(4, 16, 32, 5)]
+        want = [plain.prove_tables([(k, r, len(r)) for k, r in tabs]) for tabs in cases]
+        for fri_min_log in (0, 6):
+            ctx = backend.Context(0, None, lib)
+            shard_context(ctx, fri_min_log=fri_min_log)
+            for tabs, w in zip(cases, want):
+                assert ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == w
+            ctx.clear_shard()
+            assert ctx.prove_tables([(k, r, len(r)) for k, r in cases[0]]) == want[0]
+            ctx.close()
+        plain.close()
+    finally:
+        dist.destroy_process_group()
