@@ -93,7 +93,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
            "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block",
-           "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
+           "lmn_verify_with_config", "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -128,6 +128,7 @@ class Library:
         lib.lmn_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_device_free.argtypes = [C.c_void_p, C.c_void_p]
         lib.lmn_verify.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.c_uint32]
+        lib.lmn_verify_with_config.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.POINTER(LmnConfig)]
         lib.lmn_op_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.lmn_op_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.lmn_op_evaluate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -181,9 +182,15 @@ class Library:
             raise LuminairBackendError(rc, self.lib.lmn_strerror(rc).decode())
         return int(out.value)
 
-    def verify(self, proof: bytes, variant: int = VARIANT_KAT) -> None:
-        """`verify(proof, settings)` on the host; raises LuminairBackendError on rejection."""
-        rc = self.lib.lmn_verify(proof, len(proof), None, variant)
+    def verify(self, proof: bytes, variant: int = VARIANT_KAT, config: Optional[LmnConfig] = None,
+               settings: Optional[LmnSettings] = None) -> None:
+        """`verify(proof, settings)` on the host; raises LuminairBackendError on rejection.  `config` = the
+        verifier's own PcsConfig (default: PcsConfig::default(), as the reference hard-codes)."""
+        sp = C.byref(settings) if settings is not None else None
+        if config is not None:
+            rc = self.lib.lmn_verify_with_config(proof, len(proof), sp, C.byref(config))
+        else:
+            rc = self.lib.lmn_verify(proof, len(proof), sp, variant)
         if rc != LMN_OK:
             msg = self.lib.lmn_last_error(None).decode() or self.lib.lmn_strerror(rc).decode()
             raise LuminairBackendError(rc, msg)

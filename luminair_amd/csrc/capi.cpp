@@ -121,13 +121,20 @@ int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out) {
   return LMN_OK;
 }
 
-int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant) {
-  if (!proof_bincode) return LMN_ERR_INVALID_ARGUMENT;
-  (void)settings;  // the tree-0 layout is implied by the claim (a LUT column has its lookup component's size)
+int lmn_verify_with_config(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings,
+                           const lmn_config* expected) {
+  if (!proof_bincode || !expected) return LMN_ERR_INVALID_ARGUMENT;
   lmn_ctx tmp{nullptr, {}};
-  int rc = guard(&tmp, [&] { lmn::verify_proof(proof_bincode, proof_len, protocol_variant); });
+  int rc = guard(&tmp, [&] { lmn::verify_proof(proof_bincode, proof_len, *expected, settings); });
   g_create_error = tmp.last_error;
   return rc;
+}
+
+int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant) {
+  lmn_config c;
+  lmn_default_config(&c);  // PcsConfig::default(), as the reference verifier hard-codes it
+  c.protocol_variant = protocol_variant;
+  return lmn_verify_with_config(proof_bincode, proof_len, settings, &c);
 }
 
 int lmn_upload(lmn_ctx* ctx, const void* host, size_t bytes, void** device_out) {

@@ -169,6 +169,13 @@ static void rccl_release(void* transport);  // single-proof sharding section bel
 void rccl_unique_id(uint8_t* out);
 
 Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
+  // validate before acquiring anything: a throwing constructor does not run the destructor
+  if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
+  if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
+  if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
+  if (cfg.pow_bits > 40) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad pow_bits");
+  if (cfg.protocol_variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  if (cfg.fp_scale != 12) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only fp_scale = 12 is supported");
 #ifndef LMN_EMU
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -189,12 +196,6 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
     lmn_h2d(bad_flag_, &zero, 4, stream_);
     lmn_sync(stream_);
   }
-  if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
-  if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
-  if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
-  if (cfg.pow_bits > 40) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad pow_bits");
-  if (cfg.protocol_variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
-  if (cfg.fp_scale != 12) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only fp_scale = 12 is supported");
 }
 
 Context::~Context() {
@@ -978,10 +979,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     if ((int)tb.kind >= n_slots)
       throw LmnError(LMN_ERR_INVALID_ARGUMENT, "component kind has no claim slot in this protocol variant");
     if ((int)tb.kind <= prev_kind)
-      throw LmnError(LMN_ERR_CONSTRAINTS, "tables must be in gen_trace order (ascending kind, no duplicates)");
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tables must be in gen_trace order (ascending kind, no duplicates)");
     prev_kind = (int)tb.kind;
     if (tb.n_rows == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
     if (!tb.rows) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null rows pointer");
+    if (tb.n_rows > (1ull << 26)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace table has more than 2^26 rows");
     uint64_t size = 16;
     while (size < tb.n_rows) size <<= 1;
     int ls = 0;
@@ -1944,11 +1946,25 @@ void Context::clear_shard() {
 }
 
 // ------------------------------------------------------------------------------------ level-2 ops
+constexpr uint32_t OP_MAX_LOG = 26;  // largest column a level-2 op accepts (as lmn_prove: 2^26 rows)
+static void check_op_log(uint32_t log_size, const char* what) {
+  if (log_size > OP_MAX_LOG) throw LmnError(LMN_ERR_INVALID_ARGUMENT, std::string(what) + ": log size above 26");
+}
+// every op starts from an empty device arena AND an empty pinned staging buffer
+void Context::begin_op() {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  arena_.reset();
+  pin_off_ = 0;
+}
+
 void Context::op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size) {
+  check_op_log(log_size, "interpolate");
   ensure_twiddles((int)log_size);
   size_t bytes = ((size_t)ncols << log_size) * 4;
   arena_.reserve(bytes + (1u << 20));
-  arena_.reset();
+  begin_op();
   uint32_t* d = arena_.alloc_words((size_t)ncols << log_size);
   lmn_h2d(d, cols, bytes, stream_);
   launch_ifft(d, 1ull << log_size, d, 1ull << log_size, (int)ncols, (int)log_size, itw((int)log_size), stream_);
@@ -1959,10 +1975,11 @@ void Context::op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size) 
 void Context::op_evaluate(const uint32_t* coeffs, uint32_t ncols, uint32_t log_coeffs, uint32_t log_domain,
                           uint32_t* out) {
   if (log_coeffs > log_domain) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "log_coeffs > log_domain");
+  check_op_log(log_domain, "evaluate");
   ensure_twiddles((int)log_domain);
   size_t in_w = (size_t)ncols << log_coeffs, out_w = (size_t)ncols << log_domain;
   arena_.reserve((in_w + out_w) * 4 + (1u << 20));
-  arena_.reset();
+  begin_op();
   uint32_t* d_in = arena_.alloc_words(in_w);
   uint32_t* d_out = arena_.alloc_words(out_w);
   lmn_h2d(d_in, coeffs, in_w * 4, stream_);
@@ -1977,11 +1994,12 @@ void Context::op_evaluate_block(const uint32_t* coeffs, uint32_t ncols, uint32_t
   if (log_coeffs > log_domain) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "log_coeffs > log_domain");
   if (log_blocks < 1 || log_blocks > 3 || log_blocks >= log_domain || block >= (1u << log_blocks))
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad block specification");
+  check_op_log(log_domain, "evaluate_block");
   ensure_twiddles((int)log_domain);
   const uint32_t lb = log_domain - log_blocks;
   size_t in_w = (size_t)ncols << log_coeffs, out_w = (size_t)ncols << lb;
   arena_.reserve((in_w + out_w) * 4 + (1u << 20));
-  arena_.reset();
+  begin_op();
   uint32_t* d_in = arena_.alloc_words(in_w);
   uint32_t* d_out = arena_.alloc_words(out_w);
   lmn_h2d(d_in, coeffs, in_w * 4, stream_);
@@ -1995,11 +2013,12 @@ void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_si
   size_t words = 0;
   uint32_t max_log = 0;
   for (uint32_t c = 0; c < ncols; ++c) {
+    check_op_log(log_sizes[c], "merkle_root");
     words += 1ull << log_sizes[c];
     max_log = std::max(max_log, log_sizes[c]);
   }
   arena_.reserve((words + (16ull << max_log)) * 4 + (1u << 20));
-  arena_.reset();
+  begin_op();
   std::vector<ColRef> sorted;
   for (uint32_t c = 0; c < ncols; ++c) {
     uint32_t* d = arena_.alloc_words(1ull << log_sizes[c]);
@@ -2017,8 +2036,9 @@ void Context::op_merkle_root(const uint32_t* const* cols, const uint32_t* log_si
 }
 
 void Context::op_eval_at_point(const uint32_t* coeffs, uint32_t log_size, const uint32_t pt[8], uint32_t out[4]) {
+  check_op_log(log_size, "eval_at_point");
   arena_.reserve((4ull << log_size) + (8u << 20));
-  arena_.reset();
+  begin_op();
   uint32_t* d = arena_.alloc_words(1ull << log_size);
   lmn_h2d(d, coeffs, 4ull << log_size, stream_);
   QPt p{{pt[0], pt[1], pt[2], pt[3]}, {pt[4], pt[5], pt[6], pt[7]}};
@@ -2038,8 +2058,7 @@ void Context::op_accumulate_quotients(uint32_t log_size, const uint32_t* const* 
   ensure_twiddles((int)log_size);
   const uint64_t L = 1ull << log_size;
   arena_.reserve(((uint64_t)ncols + 4) * L * 4 + (8u << 20));
-  arena_.reset();
-  pin_off_ = 0;
+  begin_op();
   std::vector<const uint32_t*> d_cols(ncols);
   for (uint32_t c = 0; c < ncols; ++c) {
     uint32_t* d = arena_.alloc_words(L);
@@ -2066,12 +2085,11 @@ void Context::op_accumulate_quotients(uint32_t log_size, const uint32_t* const* 
 // FriOps::fold_line (circle == 0) / FriOps::fold_circle_into_line (circle == 1; dst is accumulated:
 // dst = dst * alpha^2 + fold(src), as the FRI commit loop does)
 void Context::op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]) {
-  if (log_src < 1 || log_src > 27) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log size");
+  if (log_src < 1 || log_src > OP_MAX_LOG) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log size");
   ensure_twiddles((int)log_src + 1);
   const uint64_t L = 1ull << log_src;
   arena_.reserve(6 * L * 4 + (1u << 20));
-  arena_.reset();
-  pin_off_ = 0;
+  begin_op();
   uint32_t* d_src = arena_.alloc_words(4 * L);
   uint32_t* d_dst = arena_.alloc_words(2 * L);
   lmn_h2d(d_src, src, 16 * L, stream_);
@@ -2089,10 +2107,11 @@ void Context::op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t l
 
 // tiled FFT vs one-layer-per-launch kernels on pseudo-random data (device-side differential check)
 void Context::op_fft_selftest(uint32_t log_size, uint32_t ncols) {
+  check_op_log(log_size, "fft_selftest");
   ensure_twiddles((int)log_size);
   size_t w = (size_t)ncols << log_size;
   arena_.reserve(w * 8 + (1u << 20));
-  arena_.reset();
+  begin_op();
   std::vector<uint32_t> h(w);
   uint64_t st = 0x9E3779B97F4A7C15ull;
   for (auto& v : h) {

@@ -57,7 +57,9 @@ QM31 eval_composition_at_point(const std::vector<Instance>& inst, const std::vec
 // sizes in tree order (a LUT column has the log size of its lookup component)
 std::vector<int> assign_preprocessed(std::vector<Instance>& inst);
 // verify(proof, settings): crates/verifiers/rust/src/verifier.rs:21-143 (host only, no GPU work)
-void verify_proof(const uint8_t* data, size_t len, uint32_t protocol_variant);
+// `expect`: the verifier's own PcsConfig + protocol variant (a proof announcing another config is rejected);
+// `settings` (may be null): cross-checked against the tree-0 layout the claim implies
+void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings);
 
 // bump allocator over one device slab; reset per proof
 class Arena {
@@ -179,6 +181,7 @@ class Context {
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
+  void begin_op();
   void* pin_alloc(size_t bytes);
   void* stage_upload(const void* host, size_t bytes);           // -> device pointer (arena), async
   const void* stage_download(const void* dev, size_t bytes);    // -> pinned host pointer, valid after sync

@@ -40,7 +40,26 @@ struct Reader {
     if (elem_bytes && l > (n - o) / elem_bytes + 1) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: bad length");
     return (size_t)l;
   }
-  QM31 q() { return QM31{u32(), u32(), u32(), u32()}; }
+  // A field element on the wire is a canonical M31 word: anything >= P would make the 64-bit lazy arithmetic
+  // below compute outside the field and give equal values several accepted encodings.
+  uint32_t m31() {
+    uint32_t v = u32();
+    if (v >= P31) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: field word is not a canonical M31");
+    return v;
+  }
+  bool option_tag() {
+    uint8_t t = u8();
+    if (t > 1) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: bad Option tag");
+    return t == 1;
+  }
+  QM31 q() {
+    QM31 v;
+    v.a = m31();
+    v.b = m31();
+    v.c = m31();
+    v.d = m31();
+    return v;
+  }
   Hash32 hash() {
     Hash32 h;
     for (int i = 0; i < 8; ++i) h.w[i] = u32();
@@ -51,7 +70,7 @@ struct Reader {
     size_t nh = len(32);
     for (size_t i = 0; i < nh; ++i) d.hash_witness.push_back(hash());
     size_t nc = len(4);
-    for (size_t i = 0; i < nc; ++i) d.column_witness.push_back(u32());
+    for (size_t i = 0; i < nc; ++i) d.column_witness.push_back(m31());
     return d;
   }
   FriLayerProof layer() {
@@ -67,9 +86,17 @@ struct Reader {
 Proof parse_proof(const uint8_t* data, size_t n, int n_slots) {
   Reader r{data, n};
   Proof p;
-  for (int i = 0; i < n_slots; ++i) p.claim.push_back(r.u8() ? (int)r.u32() : -1);
   for (int i = 0; i < n_slots; ++i) {
-    bool some = r.u8() != 0;
+    if (!r.option_tag()) {
+      p.claim.push_back(-1);
+      continue;
+    }
+    uint32_t ls = r.u32();
+    if (ls > 26) throw LmnError(LMN_ERR_SERIALIZATION, "SerializationError: claim log_size out of range");
+    p.claim.push_back((int)ls);
+  }
+  for (int i = 0; i < n_slots; ++i) {
+    bool some = r.option_tag();
     p.interaction_claim.push_back({some, some ? r.q() : q_zero()});
   }
   p.pow_bits = r.u32();
@@ -96,7 +123,7 @@ Proof parse_proof(const uint8_t* data, size_t n, int n_slots) {
   for (size_t t = 0; t < nq; ++t) {
     std::vector<uint32_t> v;
     size_t k = r.len(4);
-    for (size_t i = 0; i < k; ++i) v.push_back(r.u32());
+    for (size_t i = 0; i < k; ++i) v.push_back(r.m31());
     p.queried_values.push_back(v);
   }
   p.proof_of_work = r.u64();
@@ -210,16 +237,25 @@ bool rebuild_pairs(const std::vector<uint32_t>& qpos, const std::map<uint32_t, Q
 
 }  // namespace
 
-void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
+void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings) {
+  const uint32_t variant = expect.protocol_variant;
   if (variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  if (expect.log_blowup != 1 || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
+      expect.pow_bits > 40)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad expected PCS config");
   const int n_slots = variant == LMN_VARIANT_KAT ? 8 : 17;
   Proof p = parse_proof(data, len, n_slots);
+  // The security parameters are the VERIFIER's (the reference builds PcsConfig::default() itself,
+  // crates/verifiers/rust/src/verifier.rs:36, and never reads them from the proof): a proof that announces other
+  // ones - fewer queries, no proof of work - is rejected, whatever else it contains.
+  if (p.pow_bits != expect.pow_bits || p.log_blowup != expect.log_blowup || p.log_last_layer != expect.log_last_layer ||
+      p.n_queries != expect.n_queries)
+    fail("proof was made for a different PCS config than the verifier's");
+  if (p.last_layer_log_size != p.log_last_layer) fail("last layer degree bound");
   const int lb = (int)p.log_blowup;
-  if (lb != 1) fail("unsupported blow-up");
   if (p.commitments.size() != 4 || p.sampled_values.size() != 4 || p.decommitments.size() != 4 ||
       p.queried_values.size() != 4)
     fail("expected 4 commitment trees");
-  if (p.n_queries == 0 || p.n_queries > 1024 || p.log_last_layer > 10) fail("bad PCS config");
 
   // components in struct order; tree layouts implied by the claim (Claim::log_sizes, components/mod.rs:164-170)
   std::vector<Instance> inst;
@@ -245,6 +281,23 @@ void verify_proof(const uint8_t* data, size_t len, uint32_t variant) {
     if (p.claim[kind] < 0 && p.interaction_claim[kind].first) fail("interaction claim without claim");
   std::vector<std::vector<int>> tree_logs(4);
   tree_logs[0] = assign_preprocessed(inst);
+  if (settings) {
+    // verifier.rs:47-57 derives the preprocessed column sizes from `settings.lookups`; here they follow from the
+    // claim (a LUT column has its lookup component's size), so the settings must describe the same layout
+    static const int kLookupKind[3] = {LMN_KIND_SIN_LOOKUP, LMN_KIND_EXP2_LOOKUP, LMN_KIND_LOG2_LOOKUP};
+    uint32_t present = 0;
+    for (int k = 0; k < 3; ++k)
+      if (kLookupKind[k] < n_slots && p.claim[kLookupKind[k]] >= 0) present |= 1u << k;
+    if (LMN_KIND_RANGE_CHECK_LOOKUP < n_slots && p.claim[LMN_KIND_RANGE_CHECK_LOOKUP] >= 0) present |= LMN_LOOKUP_RANGE_CHECK;
+    if (settings->has_lookups && settings->has_lookups != present) fail("settings.lookups do not match the proof's claim");
+    if (settings->n_luts && !settings->luts) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null luts pointer");
+    for (uint32_t i = 0; i < settings->n_luts; ++i) {
+      const lmn_lut& l = settings->luts[i];
+      if (l.kind > LMN_LUT_LOG2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad LUT kind in settings");
+      const int kind = kLookupKind[l.kind];
+      if (kind >= n_slots || p.claim[kind] != (int)l.log_size) fail("settings LUT size does not match the proof's claim");
+    }
+  }
   int max_log = 0;
   for (auto& ci : inst) {
     for (int c = 0; c < ci.spec->n_cols; ++c) tree_logs[1].push_back(ci.log_size);

@@ -158,13 +158,25 @@ class _R:
     def u64(self):
         return struct.unpack("<Q", self.take(8))[0]
 
+    def m31(self):
+        v = self.u32()
+        if v >= (1 << 31) - 1:
+            raise ValueError("SerializationError: field word is not a canonical M31")
+        return v
+
+    def tag(self):
+        t = self.u8()
+        if t > 1:
+            raise ValueError("SerializationError: bad Option tag")
+        return t
+
     def q(self):
-        return QM31(*struct.unpack("<4I", self.take(16)))
+        return QM31(self.m31(), self.m31(), self.m31(), self.m31())
 
 
 def _r_decommit(r: _R) -> Decommitment:
     hw = [bytes(r.take(32)) for _ in range(r.u64())]
-    cw = [r.u32() for _ in range(r.u64())]
+    cw = [r.m31() for _ in range(r.u64())]
     return Decommitment(hw, cw)
 
 
@@ -178,10 +190,12 @@ def from_bincode(data: bytes, n_claim_slots: int) -> LuminairProof:
     r = _R(data)
     claim = []
     for _ in range(n_claim_slots):
-        claim.append(r.u32() if r.u8() else None)
+        claim.append(r.u32() if r.tag() else None)
+        if claim[-1] is not None and claim[-1] > 26:
+            raise ValueError("SerializationError: claim log_size out of range")
     iclaim = []
     for _ in range(n_claim_slots):
-        iclaim.append(r.q() if r.u8() else None)
+        iclaim.append(r.q() if r.tag() else None)
     pow_bits, log_blowup, log_last = r.u32(), r.u32(), r.u32()
     n_queries = r.u64()
     commitments = [bytes(r.take(32)) for _ in range(r.u64())]
@@ -192,7 +206,7 @@ def from_bincode(data: bytes, n_claim_slots: int) -> LuminairProof:
             tree.append([r.q() for _ in range(r.u64())])
         sampled.append(tree)
     decommitments = [_r_decommit(r) for _ in range(r.u64())]
-    queried = [[r.u32() for _ in range(r.u64())] for _ in range(r.u64())]
+    queried = [[r.m31() for _ in range(r.u64())] for _ in range(r.u64())]
     pow_nonce = r.u64()
     first = _r_layer(r)
     inner = [_r_layer(r) for _ in range(r.u64())]

@@ -92,8 +92,13 @@ def _instances_from_claim(claim, iclaim):
     return inst
 
 
-def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT) -> None:
-    """Raises VerificationError on failure."""
+#: PcsConfig::default() (crates/verifiers/rust/src/verifier.rs:36): (pow_bits, log_blowup, log_last_layer, n_queries)
+DEFAULT_PCS_CONFIG = (5, 1, 0, 3)
+
+
+def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT, config=DEFAULT_PCS_CONFIG) -> None:
+    """Raises VerificationError on failure.  `config` is the VERIFIER's PcsConfig: the reference builds it itself
+    and never reads it from the proof, so a proof announcing other security parameters is rejected."""
     from .prover import (draw_queries, fold_positions, quotient_batches)
     s = proof.proof
     lb = s.log_blowup
@@ -103,8 +108,12 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT)
         raise VerificationError("empty claim")
     if len(s.commitments) != 4:
         raise VerificationError("expected 4 commitments")
+    if (s.pow_bits, s.log_blowup, s.log_last_layer, s.n_queries) != tuple(config):
+        raise VerificationError("proof was made for a different PCS config than the verifier's")
     if not (0 < s.n_queries <= 1024) or s.log_last_layer > 10 or s.log_blowup != 1:
         raise VerificationError("bad PCS config")
+    if s.last_layer_log_size != s.log_last_layer:
+        raise VerificationError("last layer degree bound")
     if any(ls is not None and not (4 <= ls <= 26) for ls in proof.claim):
         raise VerificationError("bad log_size")
     channel.mix_root(s.commitments[0])

@@ -70,7 +70,7 @@ def test_emu_error_codes(emu_ctx):
     with pytest.raises(backend.LuminairBackendError) as e:   # wrong table order
         t = syn.chain_graph(16, 1)
         emu_ctx.prove_tables([(t[1][0], t[1][1], 16), (t[0][0], t[0][1], 16)])
-    assert e.value.code == backend.ERR_CONSTRAINTS
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
 
 
 def test_emu_level2_ops(emu_ctx):

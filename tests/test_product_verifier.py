@@ -93,3 +93,86 @@ def test_product_verifier_survives_fuzzed_proofs(hip_lib_path, kat_bytes):
             b[i:i] = bytes(rnd.getrandbits(8) for _ in range(rnd.randint(1, 64)))
         with pytest.raises(backend.LuminairBackendError):
             lib.verify(bytes(b), rnd.choice([0, 0, 0, 1]))
+
+
+def test_verifier_owns_the_security_parameters(lib, kat_bytes):
+    """pow_bits / n_queries / log_last_layer are the verifier's, not the proof's.  Rewriting the
+    config words of a valid proof (a 'downgrade' a forger would ship together with a matching cheap proof) is
+    rejected by the product verifier and by the oracle verifier alike; a proof honestly made for another config is
+    accepted only by a verifier that expects that config."""
+    import struct
+    off = (8 + 2 * 4) + (8 + 2 * 16)          # 8 claim slots (2 Some(u32)) + 8 interaction slots (2 Some(QM31)) of the KAT
+    assert struct.unpack_from("<IIIQ", kat_bytes, off) == (5, 1, 0, 3)
+    for field, val in ((0, 0), (0, 4), (2, 1), (3, 1), (3, 2)):
+        b = bytearray(kat_bytes)
+        if field == 3:
+            struct.pack_into("<Q", b, off + 12, val)
+        else:
+            struct.pack_into("<I", b, off + 4 * field, val)
+        with pytest.raises(backend.LuminairBackendError) as e:
+            lib.verify(bytes(b), backend.VARIANT_KAT)
+        assert e.value.code == backend.ERR_VERIFICATION
+        with pytest.raises(Exception):
+            oracle_verify(from_bincode(bytes(b), 8))
+    # a proof made for 2 queries / 3 pow bits: rejected by the default verifier, accepted by one configured for it
+    cfg = lib.default_config()
+    cfg.n_queries, cfg.pow_bits = 2, 3
+    tabs = syn.chain_graph(40, 2)
+    from oracle.prover import PcsConfig
+    p = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], PcsConfig(pow_bits=3, n_queries=2)))
+    with pytest.raises(backend.LuminairBackendError):
+        lib.verify(p, backend.VARIANT_KAT)
+    lib.verify(p, config=cfg)
+    oracle_verify(from_bincode(p, 8), config=(3, 1, 0, 2))
+    with pytest.raises(Exception):
+        oracle_verify(from_bincode(p, 8))
+
+
+def test_verifier_rejects_non_canonical_encodings(lib, kat_bytes):
+    """field words >= 2^31-1, Option tags other than 0/1 and absurd claim sizes are
+    serialization errors before any arithmetic happens."""
+    import struct
+    P = (1 << 31) - 1
+    # first interaction claim's first coordinate: value v and v + P would be the same field element
+    off = 8 * 1 + 2 * 4 + 1                        # claims: 8 tags + 2 u32; then the first Some tag of the interaction claims
+    assert kat_bytes[off - 1] == 1
+    v = struct.unpack_from("<I", kat_bytes, off)[0]
+    for bad in (v + P, P, 0xffffffff):
+        if bad > 0xffffffff:
+            continue
+        b = bytearray(kat_bytes)
+        struct.pack_into("<I", b, off, bad)
+        with pytest.raises(backend.LuminairBackendError) as e:
+            lib.verify(bytes(b), backend.VARIANT_KAT)
+        assert e.value.code == backend.ERR_SERIALIZATION
+        with pytest.raises(ValueError):
+            from_bincode(bytes(b), 8)
+    b = bytearray(kat_bytes)
+    b[0] = 2                                        # Option tag of the first claim slot
+    with pytest.raises(backend.LuminairBackendError) as e:
+        lib.verify(bytes(b), backend.VARIANT_KAT)
+    assert e.value.code == backend.ERR_SERIALIZATION
+    b = bytearray(kat_bytes)
+    struct.pack_into("<I", b, 1, 0x80000004)        # claim log_size that a signed cast would turn negative
+    with pytest.raises(backend.LuminairBackendError) as e:
+        lib.verify(bytes(b), backend.VARIANT_KAT)
+    assert e.value.code == backend.ERR_SERIALIZATION
+
+
+def test_verifier_cross_checks_settings(lib):
+    """`settings` is no longer ignored - lookups announced by the settings must be the ones the
+    proof's claim carries, LUT sizes included."""
+    import ctypes as C
+    tabs, luts = syn.activation_graph(30, 4, names=("sin",))
+    p = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant.PINNED, luts=luts))
+    c0 = np.ascontiguousarray(luts["sin"][0], dtype=np.uint32)
+    c1 = np.ascontiguousarray(luts["sin"][1], dtype=np.uint32)
+    log = len(c0).bit_length() - 1
+    arr = (backend.LmnLut * 1)(backend.LmnLut(0, log, c0.ctypes.data, c1.ctypes.data))
+    lib.verify(p, backend.VARIANT_PINNED, settings=backend.LmnSettings(1, 1, arr))
+    lib.verify(p, backend.VARIANT_PINNED, settings=backend.LmnSettings(0, 0, None))
+    with pytest.raises(backend.LuminairBackendError):                       # settings announce exp2, proof has sin
+        lib.verify(p, backend.VARIANT_PINNED, settings=backend.LmnSettings(2, 0, None))
+    arr2 = (backend.LmnLut * 1)(backend.LmnLut(0, log + 1, c0.ctypes.data, c1.ctypes.data))
+    with pytest.raises(backend.LuminairBackendError):                       # LUT of another size
+        lib.verify(p, backend.VARIANT_PINNED, settings=backend.LmnSettings(1, 1, arr2))
