@@ -40,7 +40,25 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-anchor", action="store_true", help="skip the 32x32 reference-shape latency anchor")
     ap.add_argument("--cpu-sample-log", type=int, default=20)
+    ap.add_argument("--shard-proof", action="store_true",
+                    help="latency of ONE proof sharded over the --gpus ranks (lmn_ctx_set_shard_rccl) instead of "
+                         "proofs/s of independent proofs; --shard-workload picks the pie")
+    ap.add_argument("--shard-workload", default="config5", choices=["config5", "config2a", "config3"],
+                    help="config5: 256 x (Mul + SumReduce + Add), 2^24 rows; config2a: Add 2^log-rows; config3: 2^22 rows")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sub-results (host_rows, config_2b, sharded_proof) and print the headline only")
     return ap.parse_args(argv)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def dist_env():
@@ -92,8 +110,106 @@ def cpu_baseline(sample_log, full_log):
     oracle_prove(small, kernels=K, variant=ProtocolVariant.PINNED)
     small_ms = 1e3 * (time.perf_counter() - t0)
     return {"reference_shape_32x32_add_ms": small_ms,"value": 1.0 / (warm * scale), "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "C/OpenMP oracle proof of a 2^%d-row Add trace: %.2f s warm (tables cached), %.2f s cold%s"
                       % (sample_log, warm, cold, "" if scale == 1 else "; scaled x%d to 2^%d rows" % (scale, full_log))}
+
+
+def throughput(provers, bufs, steps, warmup, luts=None):
+    """proofs/s of `steps` proofs dealt round-robin over the in-flight contexts (no barrier: sub-results only)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(provers)
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        def one(i):
+            return provers[i].ctx.prove_tables(bufs[i], luts)
+        for f in [pool.submit(one, i % n) for i in range(warmup)]:
+            f.result()
+        t0 = time.perf_counter()
+        pending = []
+        for k in range(steps):
+            if len(pending) >= n:
+                pending.pop(0).result()
+            pending.append(pool.submit(one, k % n))
+        for f in pending:
+            f.result()
+        dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+
+
+def solo_latency(ctx, tables, n=9, luts=None):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        ctx.prove_tables(tables, luts)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def shard_workload(name, log_rows):
+    from luminair_amd import synthetic as syn
+    if name == "config5":
+        return syn.config5_linear_layers(), "BASELINE config 5: 256 x (Mul + SumReduce + Add), Mul 2^23 + SumReduce 2^23 + Add 2^15 rows"
+    if name == "config3":
+        return syn.config3_mixed(), "BASELINE config 3: Add 2^21 + Mul 2^20 + Recip 2^20 rows"
+    return syn.config2_add_only(1 << log_rows, 42), "BASELINE config 2a: Add 2^%d rows" % log_rows
+
+
+def shard_proof_main(args, rank, local_rank, world):
+    """ONE proof sharded over the ranks: every rank holds the same tables, evaluates / hashes /
+    folds only its row blocks, the library's own RCCL communicator carries the all-gathers on the prover's stream.
+    A step = one whole sharded proof; value = proofs/s of that single stream of proofs (1 / latency)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import luminair_amd
+    from luminair_amd.sharded import shard_context
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    prover = luminair_amd.Prover(local_rank)
+    tabs, what = shard_workload(args.shard_workload, args.log_rows)        # identical on every rank (fixed seed)
+    bufs = [(k, prover.ctx.upload(r), len(r)) for k, r in tabs]
+    plain = prover.ctx.prove_tables(bufs)                                   # unsharded reference bytes (+ context setup)
+    plain_ms = solo_latency(prover.ctx, bufs, 5) if rank == 0 else None
+    shard_context(prover.ctx)
+    out = {}
+
+    def step():
+        out["proof"] = prover.ctx.prove_tables(bufs)
+
+    def barrier():
+        dist.barrier(device_ids=[local_rank])
+
+    steps = min(args.steps, 32)
+    elapsed = timed_region(step, steps, min(args.warmup, 4), barrier, torch.cuda.synchronize)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tmax = float(t.item())
+    same = torch.tensor([1 if out["proof"] == plain else 0], device="cuda")
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        rows = sum(n for _, _, n in bufs)
+        print(json.dumps({
+            "metric": "sharded-proof latency (one proof over all GPUs)", "value": steps / tmax, "unit": "proofs/s",
+            "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 4), "ms_per_step": 1e3 * tmax / steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 (M31/QM31 field arithmetic)", "data": "synthetic",
+            "config": {"workload": what + "; ONE proof sharded into row blocks over %d rank(s), RCCL all-gathers of subtree "
+                                          "roots / composition evaluations / small FRI layers only" % world,
+                       "rows": rows, "parallelism": "single-proof row-block sharding x%d" % world,
+                       "proof_bytes": len(out["proof"]), "proof_sha256": hashlib.sha256(out["proof"]).hexdigest()},
+            "prove_latency_ms": 1e3 * tmax / steps, "unsharded_latency_ms_rank0": plain_ms,
+            "rows_per_s": rows * steps / tmax,
+            "bytes_identical_to_unsharded_proof_on_every_rank": bool(int(same.item())),
+        }))
+    prover.ctx.clear_shard()
+    for _, b, _ in bufs:
+        b.free()
+    dist.destroy_process_group()
 
 
 def main(argv=None):
@@ -101,6 +217,8 @@ def main(argv=None):
     rank, local_rank, world = dist_env()
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.shard_proof:
+        return shard_proof_main(args, rank, local_rank, world)
     import numpy as np
     import torch
     import luminair_amd
@@ -189,9 +307,15 @@ def main(argv=None):
     # applied: 2*FETCH_SIZE + WRITE_SIZE), per launch like `achieved`.
     tm = prover.timings()
     pmc = {}
+    pmc_source = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
-            pmc = json.load(f)["kernels"]
+        for cand in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+            pth = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pth):
+                with open(pth) as f:
+                    pmc = json.load(f)["kernels"]
+                pmc_source = "profiles/" + cand
+                break
     except Exception:
         pass
     fams = {
@@ -216,7 +340,10 @@ def main(argv=None):
         ops, alu_peak, alu_unit = alu[name]
         alu_achieved = ops / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
         return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches_per_proof": launches,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": (pmc_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)")
+                if traffic is not None and pmc_source else None,
+                "launches_per_proof": launches,
                 "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": nbytes / launches,
                 "alu_ceiling": {"achieved": alu_achieved, "peak_measured": alu_peak, "unit": alu_unit,
                                 "frac": alu_achieved / alu_peak}}
@@ -276,7 +403,10 @@ def main(argv=None):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31/QM31 field arithmetic)",
         "data": "synthetic" + (" (host rows: PCIe-inclusive)" if args.host_rows else ""),
         "config": {"workload": "BASELINE config 2a: single Add-op AIR, 2^%d trace rows per proof, PcsConfig default "
-                               "(pow 5, blowup 2x, 3 queries), KAT protocol variant" % args.log_rows,
+                               "(pow 5, blowup 2x, 3 queries), KAT protocol variant (the variant the reference's only "
+                               "known-answer proof pins; Add's constraint forms are KAT-pinned, Mul's second "
+                               "eval_fixed_mul slot and the Recip/Sqrt/Rem forms are unpinned and not used here)"
+                               % args.log_rows,
                    "rows": 1 << args.log_rows, "proofs_per_rank": args.steps, "parallelism": "proof-sharded x%d" % world,
                    "proofs_in_flight_per_gpu": inflight,
                    "proof_bytes": len(out["proof"])},
@@ -287,12 +417,74 @@ def main(argv=None):
         "roofline_other": roofline_other,
         "whole_proof_vs_traffic_model": whole,
     }
+    if rank == 0 and not args.no_extras and not args.host_rows:
+        # sub-results next to the headline: the same workload with the trace rows handed over as
+        # host buffers (the reference API takes a host pie: 60 MiB over PCIe per proof), and config 2b = what
+        # gen_trace really emits for an Add node at HEAD (Add 2^20 rows consumed with multiplicity -1 + the Inputs
+        # table of 2^21 rows; PINNED protocol variant - parity unpinned)
+        try:
+            hb = [[(k, r, len(r)) for k, r in tabs] for _ in provers]
+            line["host_rows"] = dict(throughput(provers, hb, 48, 8), note="trace rows as host buffers: PCIe-inclusive",
+                                     prove_latency_ms=solo_latency(prover.ctx, hb[0]))
+        except Exception as e:  # never lose the headline over a sub-result
+            line["host_rows"] = {"error": str(e)}
+        try:
+            from luminair_amd import backend as _bk
+            p2 = [luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED) for _ in range(min(inflight, 2))]
+            t2 = syn.config2_graph_faithful(1 << args.log_rows, 42)
+            b2 = [[(k, q.ctx.upload(r), len(r)) for k, r in t2] for q in p2]
+            for q, bb in zip(p2, b2):
+                q.ctx.prove_tables(bb)
+            line["config_2b"] = dict(throughput(p2, b2, 32, 4),
+                                     workload="BASELINE config 2b (graph-faithful): Add 2^%d rows + Inputs 2^%d rows, "
+                                              "PINNED protocol variant (parity unpinned)" % (args.log_rows, args.log_rows + 1),
+                                     prove_latency_ms=solo_latency(p2[0].ctx, b2[0]), proofs_in_flight_per_gpu=len(p2))
+            for bb in b2:
+                for _, b_, _ in bb:
+                    b_.free()
+            for q in p2:
+                q.ctx.close()
+        except Exception as e:
+            line["config_2b"] = {"error": str(e)}
     if anchor:
         line["reference_shape_anchor"] = anchor
     if trace_gen:
         line["device_trace_generation"] = trace_gen
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows)
+    if use_dist and not args.no_extras and os.environ.get("LMN_BENCH_SHARDED_EXTRA", "1") != "0":
+        # Sub-result at N > 1: latency of ONE 2^log_rows-row Add proof sharded over all N GPUs (the library's own RCCL
+        # communicator on the prover stream), next to the solo latency above.  A watchdog makes sure the headline
+        # line is printed even if the multi-GPU transport misbehaves on this node.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["sharded_proof"] = {"error": "timed out (watchdog)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "120")), give_up)
+        dog.daemon = True
+        dog.start()
+        res = {}
+        try:
+            from luminair_amd.sharded import shard_context
+            sp = luminair_amd.Prover(dev)
+            stabs = syn.config2_add_only(1 << args.log_rows, 42)            # the same table on every rank
+            sb = [(k, sp.ctx.upload(r), len(r)) for k, r in stabs]
+            want = sp.ctx.prove_tables(sb)
+            shard_context(sp.ctx)
+            got = sp.ctx.prove_tables(sb)
+            el = timed_region(lambda: sp.ctx.prove_tables(sb), 16, 2, barrier, torch.cuda.synchronize)
+            tmax = reduce_max(el)
+            res = {"workload": "ONE 2^%d-row Add proof sharded into row blocks over %d GPUs" % (args.log_rows, world),
+                   "prove_latency_ms": 1e3 * tmax / 16, "solo_unsharded_latency_ms": latency_ms,
+                   "bytes_identical_to_unsharded_proof": got == want, "scaling": "strong"}
+            sp.ctx.clear_shard()
+        except Exception as e:
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+        line["sharded_proof"] = res
     if rank == 0:
         print(json.dumps(line))
     pool.shutdown()
