@@ -93,7 +93,12 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
            "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block",
-           "lmn_verify_with_config", "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
+           "lmn_verify_with_config", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
+           "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
+           "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
+           "lmn_col_commit", "lmn_tree_root", "lmn_tree_log_size", "lmn_tree_layer_to_cpu", "lmn_tree_free",
+           "lmn_col_accumulate", "lmn_col_accumulate_quotients", "lmn_col_fold_line", "lmn_col_fold_circle_into_line",
+           "lmn_col_decompose", "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -146,6 +151,37 @@ class Library:
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_upload_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        VP, U32 = C.c_void_p, C.c_uint32
+        lib.lmn_col_alloc.argtypes = [VP, U32, U32, C.POINTER(VP)]
+        lib.lmn_col_from_cpu.argtypes = [VP, VP, U32, U32, C.POINTER(VP)]
+        lib.lmn_col_to_cpu.argtypes = [VP, VP, VP]
+        lib.lmn_col_free.argtypes = [VP, VP]
+        lib.lmn_col_free.restype = None
+        lib.lmn_col_ncols.argtypes = [VP]
+        lib.lmn_col_ncols.restype = U32
+        lib.lmn_col_log_size.argtypes = [VP]
+        lib.lmn_col_log_size.restype = U32
+        lib.lmn_col_device_ptr.argtypes = [VP]
+        lib.lmn_col_device_ptr.restype = VP
+        lib.lmn_col_bit_reverse.argtypes = [VP, VP]
+        lib.lmn_col_precompute_twiddles.argtypes = [VP, U32]
+        lib.lmn_col_interpolate.argtypes = [VP, VP]
+        lib.lmn_col_evaluate.argtypes = [VP, VP, U32, C.POINTER(VP)]
+        lib.lmn_col_evaluate_block.argtypes = [VP, VP, U32, U32, U32, C.POINTER(VP)]
+        lib.lmn_col_extend.argtypes = [VP, VP, U32, C.POINTER(VP)]
+        lib.lmn_col_eval_at_point.argtypes = [VP, VP, U32, VP, VP]
+        lib.lmn_col_commit.argtypes = [VP, C.POINTER(VP), U32, C.POINTER(VP)]
+        lib.lmn_tree_root.argtypes = [VP, VP, VP]
+        lib.lmn_tree_log_size.argtypes = [VP]
+        lib.lmn_tree_log_size.restype = U32
+        lib.lmn_tree_layer_to_cpu.argtypes = [VP, VP, U32, VP]
+        lib.lmn_tree_free.argtypes = [VP, VP]
+        lib.lmn_tree_free.restype = None
+        lib.lmn_col_accumulate.argtypes = [VP, VP, VP]
+        lib.lmn_col_accumulate_quotients.argtypes = [VP, C.POINTER(VP), U32, VP, VP, VP, U32, VP, U32, VP, C.POINTER(VP)]
+        lib.lmn_col_fold_line.argtypes = [VP, VP, VP, C.POINTER(VP)]
+        lib.lmn_col_fold_circle_into_line.argtypes = [VP, VP, VP, VP]
+        lib.lmn_col_decompose.argtypes = [VP, VP, C.POINTER(VP), VP]
         lib.lmn_ctx_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(LmnCollective)]
         lib.lmn_rccl_unique_id.argtypes = [C.c_void_p]
         lib.lmn_ctx_set_shard_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -222,6 +258,114 @@ class DeviceBuffer:
         self.ptr = 0
 
 
+class Col:
+    """`lmn_col`: ncols columns of 2^log_size words resident in HBM (stwo `Col<B, _>` / `SecureColumnByCoords<B>`).
+    Every method is one level-2 op on the device data; only `from_cpu` / `to_cpu` move bytes over PCIe."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    @property
+    def ncols(self) -> int:
+        return int(self.ctx.lib.lib.lmn_col_ncols(self.handle))
+
+    @property
+    def log_size(self) -> int:
+        return int(self.ctx.lib.lib.lmn_col_log_size(self.handle))
+
+    @property
+    def device_ptr(self) -> int:
+        return int(self.ctx.lib.lib.lmn_col_device_ptr(self.handle))
+
+    def _new(self, fn, *args) -> "Col":
+        out = C.c_void_p()
+        self.ctx._check(fn(self.ctx.handle, self.handle, *args, C.byref(out)))
+        return Col(self.ctx, out)
+
+    def to_cpu(self) -> np.ndarray:
+        host = np.empty((self.ncols, 1 << self.log_size), dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.lib.lmn_col_to_cpu(self.ctx.handle, self.handle, host.ctypes.data))
+        return host
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.lib.lmn_col_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def bit_reverse(self) -> "Col":
+        self.ctx._check(self.ctx.lib.lib.lmn_col_bit_reverse(self.ctx.handle, self.handle))
+        return self
+
+    def interpolate(self) -> "Col":
+        """evaluations -> coefficients, in place"""
+        self.ctx._check(self.ctx.lib.lib.lmn_col_interpolate(self.ctx.handle, self.handle))
+        return self
+
+    def evaluate(self, log_domain: int) -> "Col":
+        return self._new(self.ctx.lib.lib.lmn_col_evaluate, log_domain)
+
+    def evaluate_block(self, log_domain: int, log_blocks: int, block: int) -> "Col":
+        return self._new(self.ctx.lib.lib.lmn_col_evaluate_block, log_domain, log_blocks, block)
+
+    def extend(self, log_size: int) -> "Col":
+        return self._new(self.ctx.lib.lib.lmn_col_extend, log_size)
+
+    def eval_at_point(self, column: int, point_xy: Sequence[int]) -> Tuple[int, int, int, int]:
+        pt = (C.c_uint32 * 8)(*[int(v) for v in point_xy])
+        out = (C.c_uint32 * 4)()
+        self.ctx._check(self.ctx.lib.lib.lmn_col_eval_at_point(self.ctx.handle, self.handle, column, pt, out))
+        return tuple(int(v) for v in out)
+
+    def accumulate(self, other: "Col") -> "Col":
+        """self += other"""
+        self.ctx._check(self.ctx.lib.lib.lmn_col_accumulate(self.ctx.handle, self.handle, other.handle))
+        return self
+
+    def fold_line(self, alpha) -> "Col":
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        return self._new(self.ctx.lib.lib.lmn_col_fold_line, al)
+
+    def fold_circle_into_line(self, src: "Col", alpha) -> "Col":
+        """self = self * alpha^2 + fold(src)"""
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        self.ctx._check(self.ctx.lib.lib.lmn_col_fold_circle_into_line(self.ctx.handle, self.handle, src.handle, al))
+        return self
+
+    def decompose(self):
+        """FriOps::decompose -> (g, lambda)"""
+        out = C.c_void_p()
+        lam = (C.c_uint32 * 4)()
+        self.ctx._check(self.ctx.lib.lib.lmn_col_decompose(self.ctx.handle, self.handle, C.byref(out), lam))
+        return Col(self.ctx, out), tuple(int(v) for v in lam)
+
+
+class Tree:
+    """`lmn_tree`: a committed Merkle tree whose layers stay in HBM."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    def root(self) -> bytes:
+        out = (C.c_uint8 * 32)()
+        self.ctx._check(self.ctx.lib.lib.lmn_tree_root(self.ctx.handle, self.handle, out))
+        return bytes(out)
+
+    @property
+    def log_size(self) -> int:
+        return int(self.ctx.lib.lib.lmn_tree_log_size(self.handle))
+
+    def layer(self, layer_log: int) -> List[bytes]:
+        buf = (C.c_uint8 * (32 << layer_log))()
+        self.ctx._check(self.ctx.lib.lib.lmn_tree_layer_to_cpu(self.ctx.handle, self.handle, layer_log, buf))
+        raw = bytes(buf)
+        return [raw[32 * i:32 * i + 32] for i in range(1 << layer_log)]
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.lib.lmn_tree_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+
 class Context:
     """One prover context per GPU (`lmn_ctx`)."""
 
@@ -250,6 +394,46 @@ class Context:
         if rc != LMN_OK:
             msg = self.lib.lib.lmn_last_error(self.handle).decode() or self.lib.lib.lmn_strerror(rc).decode()
             raise LuminairBackendError(rc, msg)
+
+    # ---- level-2 ops on device handles (lmn_col_* / lmn_tree_*)
+    def col_from_cpu(self, cols: np.ndarray) -> Col:
+        a = np.ascontiguousarray(cols, dtype=np.uint32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        ncols, n = a.shape
+        if n & (n - 1) or n == 0:
+            raise ValueError("column length must be a power of two")
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_col_from_cpu(self.handle, a.ctypes.data, ncols, n.bit_length() - 1, C.byref(out)))
+        return Col(self, out)
+
+    def col_zeros(self, ncols: int, log_size: int) -> Col:
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_col_alloc(self.handle, ncols, log_size, C.byref(out)))
+        return Col(self, out)
+
+    def precompute_twiddles(self, log_size: int):
+        self._check(self.lib.lib.lmn_col_precompute_twiddles(self.handle, log_size))
+
+    def commit(self, cols: Sequence[Col]) -> Tree:
+        arr = (C.c_void_p * max(len(cols), 1))(*[c.handle for c in cols])
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_col_commit(self.handle, arr, len(cols), C.byref(out)))
+        return Tree(self, out)
+
+    def col_accumulate_quotients(self, cols: Sequence[Col], samples, points, alpha) -> Col:
+        """As `accumulate_quotients`, on resident columns; returns the secure column (4 coordinate columns)."""
+        arr = (C.c_void_p * len(cols))(*[c.handle for c in cols])
+        sc = np.array([s[0] for s in samples], dtype=np.uint32)
+        sp = np.array([s[1] for s in samples], dtype=np.uint32)
+        sv = np.array([list(s[2]) for s in samples], dtype=np.uint32).reshape(-1)
+        pts = np.array([list(p) for p in points], dtype=np.uint32).reshape(-1)
+        al = (C.c_uint32 * 4)(*[int(v) for v in alpha])
+        out = C.c_void_p()
+        self._check(self.lib.lib.lmn_col_accumulate_quotients(
+            self.handle, arr, len(cols), sc.ctypes.data, sp.ctypes.data, sv.ctypes.data, len(samples), pts.ctypes.data,
+            len(points), al, C.byref(out)))
+        return Col(self, out)
 
     # ---- single-proof sharding (lmn_ctx_set_shard*)
     def set_shard(self, rank: int, world: int, all_gather, fri_min_log: int = 0):

@@ -2,33 +2,14 @@
 // bind in place of /root/reference/crates/prover/src/prover.rs:28-31.
 #include "../../include/luminair_hip.h"
 
-#include "prover.h"
+#include "capi_internal.h"
 
 using lmn::Context;
-
-
-struct lmn_ctx {
-  Context* impl;
-  std::string last_error;
-};
 
 namespace {
 template <typename F>
 int guard(lmn_ctx* ctx, F&& f) {
-  try {
-    f();
-    return LMN_OK;
-  } catch (const LmnError& e) {
-    if (ctx) ctx->last_error = e.what();
-    int c = e.code;
-    return (c == -100 || (c <= -1 && c >= -10)) ? c : LMN_ERR_INTERNAL;
-  } catch (const std::bad_alloc&) {
-    if (ctx) ctx->last_error = "host allocation failed";
-    return LMN_ERR_OUT_OF_MEMORY;
-  } catch (const std::exception& e) {
-    if (ctx) ctx->last_error = e.what();
-    return LMN_ERR_INTERNAL;
-  }
+  return lmn::capi_guard(ctx, std::forward<F>(f));
 }
 thread_local std::string g_create_error;
 }  // namespace

@@ -38,6 +38,14 @@ void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n
 void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32_t* dst, uint64_t dst_stride,
                    int log_dst, int ncols, lmn_stream_t s);
 
+// ---- level-2 column ops (stwo ColumnOps / FriOps pieces that `prove` itself never needs as separate passes)
+// in-place bit-reversal permutation of every column (ColumnOps::bit_reverse_column)
+void launch_bit_reverse(uint32_t* data, uint64_t col_stride, int ncols, int log_n, lmn_stream_t s);
+// FriOps::decompose of a secure column f (4 x 2^log_n): lambda_out[0] = (sum of first half - sum of second half) / 2^log_n;
+// g = f - lambda on the first half, f + lambda on the second.  scratch: decompose_num_blocks(log_n) QM31 values.
+int decompose_num_blocks(int log_n);
+void launch_decompose(const uint32_t* f, int log_n, uint32_t* g, QM31* lambda_out, QM31* scratch, lmn_stream_t s);
+
 // ---- a4: Blake2s Merkle layer.  out[i] = H(prev[2i] || prev[2i+1] || cols[0][i] .. cols[ncols-1][i])
 void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
                          lmn_stream_t s);

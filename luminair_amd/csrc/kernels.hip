@@ -11,6 +11,9 @@ namespace lmn {
 constexpr int TPB = 256;
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+LMN_D QM31 load_secure_col(const uint32_t* __restrict__ base, uint64_t stride, uint64_t i) {
+  return QM31{base[i], base[stride + i], base[2 * stride + i], base[3 * stride + i]};
+}
 
 // =============================================================================================
 // a3  AoS -> SoA transpose with padding rows (is_last_idx = 1, everything else 0)
@@ -695,6 +698,78 @@ void launch_extend(const uint32_t* src, uint64_t src_stride, int log_src, uint32
   uint64_t dl = 1ull << log_dst;
   LMN_LAUNCH(k_extend, dim3(cdiv(dl, TPB), ncols), dim3(TPB), 0, s, src, src_stride, 1ull << log_src, dst,
              dst_stride, dl);
+}
+
+// =============================================================================================
+// level-2 column ops: bit reversal, FriOps::decompose
+// =============================================================================================
+LMN_KERNEL k_bit_reverse(uint32_t* __restrict__ data, uint64_t col_stride, int log_n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1ull << log_n)) return;
+  const uint64_t j = log_n == 0 ? 0 : (uint64_t)(__brev((uint32_t)i) >> (32 - log_n));
+  if (i >= j) return;  // each unordered pair is swapped once, by its smaller index
+  uint32_t* col = data + (uint64_t)blockIdx.y * col_stride;
+  const uint32_t a = col[i], b = col[j];
+  col[i] = b;
+  col[j] = a;
+}
+void launch_bit_reverse(uint32_t* data, uint64_t col_stride, int ncols, int log_n, lmn_stream_t s) {
+  if (log_n > 32) throw LmnError(-100, "bit_reverse: column too large");
+  LMN_LAUNCH(k_bit_reverse, dim3(cdiv(1ull << log_n, TPB), ncols), dim3(TPB), 0, s, data, col_stride, log_n);
+}
+
+int decompose_num_blocks(int log_n) { return log_n < 1 ? 1 : (int)cdiv(1ull << (log_n - 1), TPB); }
+
+// partial[b] = sum over the block's i < n/2 of f[i] - f[i + n/2]
+LMN_KERNEL k_decompose_partial(const uint32_t* __restrict__ f, int log_n, QM31* __restrict__ partial) {
+  LMN_SHARED QM31 red[TPB];
+  const uint64_t n = 1ull << log_n, half = n >> 1;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  QM31 v = q_zero();
+  if (i < half) {
+    const QM31 a = load_secure_col(f, n, i), b = load_secure_col(f, n, i + half);
+    v = q_sub(a, b);
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = q_add(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// lambda = (sum of partials) * n_inv
+LMN_KERNEL k_decompose_lambda(const QM31* __restrict__ partial, int nblocks, uint32_t n_inv, QM31* __restrict__ lambda) {
+  LMN_SHARED QM31 red[TPB];
+  QM31 acc = q_zero();
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc = q_add(acc, partial[b]);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = TPB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] = q_add(red[threadIdx.x], red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *lambda = q_mul_m(red[0], n_inv);
+}
+LMN_KERNEL k_decompose_apply(const uint32_t* __restrict__ f, int log_n, uint32_t* __restrict__ g,
+                             const QM31* __restrict__ lambda) {
+  const uint64_t n = 1ull << log_n;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const QM31 l = *lambda, v = load_secure_col(f, n, i);
+  const QM31 r = i >= (n >> 1) ? q_add(v, l) : q_sub(v, l);
+  g[i] = r.a;
+  g[n + i] = r.b;
+  g[2 * n + i] = r.c;
+  g[3 * n + i] = r.d;
+}
+void launch_decompose(const uint32_t* f, int log_n, uint32_t* g, QM31* lambda_out, QM31* scratch, lmn_stream_t s) {
+  if (log_n < 1) throw LmnError(-100, "decompose: a circle domain has at least two points");
+  const int nb = decompose_num_blocks(log_n);
+  LMN_LAUNCH(k_decompose_partial, dim3(nb), dim3(TPB), 0, s, f, log_n, scratch);
+  int e = (31 - (log_n % 31)) % 31;  // 2^-log_n mod P
+  LMN_LAUNCH(k_decompose_lambda, dim3(1), dim3(TPB), 0, s, scratch, nb, 1u << e, lambda_out);
+  LMN_LAUNCH(k_decompose_apply, dim3(cdiv(1ull << log_n, TPB)), dim3(TPB), 0, s, f, log_n, g, lambda_out);
 }
 
 // =============================================================================================

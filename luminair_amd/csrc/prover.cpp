@@ -1950,6 +1950,12 @@ constexpr uint32_t OP_MAX_LOG = 26;  // largest column a level-2 op accepts (as 
 static void check_op_log(uint32_t log_size, const char* what) {
   if (log_size > OP_MAX_LOG) throw LmnError(LMN_ERR_INVALID_ARGUMENT, std::string(what) + ": log size above 26");
 }
+void Context::set_device() {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+}
+void Context::reset_event_log() { g_log(this)->reset(); }
 // every op starts from an empty device arena AND an empty pinned staging buffer
 void Context::begin_op() {
 #ifndef LMN_EMU

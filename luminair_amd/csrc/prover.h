@@ -139,6 +139,29 @@ class Context {
   void set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id);
   void clear_shard();
 
+  // level-2 ops on device handles (level2.cpp)
+  lmn_col* col_alloc(uint32_t ncols, uint32_t log_size, bool zero);
+  lmn_col* col_from_cpu(const uint32_t* host, uint32_t ncols, uint32_t log_size);
+  void col_to_cpu(const lmn_col* c, uint32_t* host);
+  void col_free(lmn_col* c);
+  void col_bit_reverse(lmn_col* c);
+  void col_precompute_twiddles(uint32_t log_size);
+  void col_interpolate(lmn_col* c);
+  lmn_col* col_evaluate(const lmn_col* coeffs, uint32_t log_domain);
+  lmn_col* col_evaluate_block(const lmn_col* coeffs, uint32_t log_domain, uint32_t log_blocks, uint32_t block);
+  lmn_col* col_extend(const lmn_col* coeffs, uint32_t log_size);
+  void col_eval_at_point(const lmn_col* coeffs, uint32_t column, const uint32_t pt[8], uint32_t out[4]);
+  lmn_tree* col_commit(const lmn_col* const* cols, uint32_t n);
+  void tree_layer_to_cpu(const lmn_tree* t, uint32_t layer_log, uint8_t* out);
+  void tree_free(lmn_tree* t);
+  void col_accumulate(lmn_col* dst, const lmn_col* src);
+  lmn_col* col_accumulate_quotients(const lmn_col* const* cols, uint32_t n, const uint32_t* sample_col,
+                                    const uint32_t* sample_point, const uint32_t* sample_values, uint32_t nsamples,
+                                    const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4]);
+  lmn_col* col_fold_line(const lmn_col* src, const uint32_t alpha[4]);
+  void col_fold_circle_into_line(lmn_col* dst, const lmn_col* src, const uint32_t alpha[4]);
+  lmn_col* col_decompose(const lmn_col* f, uint32_t lambda_out[4]);
+
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
   void upload_to(const void* host, size_t bytes, void* dst);
@@ -182,6 +205,8 @@ class Context {
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
   void begin_op();
+  void set_device();
+  void reset_event_log();
   void* pin_alloc(size_t bytes);
   void* stage_upload(const void* host, size_t bytes);           // -> device pointer (arena), async
   const void* stage_download(const void* dev, size_t bytes);    // -> pinned host pointer, valid after sync

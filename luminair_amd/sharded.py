@@ -63,21 +63,29 @@ def row_block(cols: Sequence[np.ndarray], rank: int, world: int) -> List[np.ndar
 
 def commit_sharded(ctx, coeff_cols: Sequence[np.ndarray], log_blowup: int = 1, group=None) -> bytes:
     """`tree_builder.extend_polys(..).commit()` sharded over the ranks of `group` with no bulk exchange
-    (DESIGN.md §6): every rank holds the coefficient columns, evaluates ONLY its block of rows of every column's LDE
-    (`lmn_op_evaluate_block`: the top log2(world) FFT layers reduce to a world-point combination at fixed row, the
-    rest runs inside the block), hashes the Merkle subtree over that block, and the subtree roots are all-gathered.
-    Returns the same root as a single-GPU commit of all columns (world sizes 1, 2, 4, 8)."""
+    (DESIGN.md §6), on device handles: the coefficient columns are uploaded ONCE (`lmn_col_from_cpu`), every rank
+    evaluates ONLY its block of rows of every column's LDE (`lmn_col_evaluate_block`) and hashes the Merkle subtree
+    over those blocks (`lmn_col_commit`) without the data leaving HBM; the 32-byte subtree roots are all-gathered
+    and the top log2(world) levels hashed on every rank.  Returns the same root as a single-GPU commit of all
+    columns (world sizes 1, 2, 4, 8).  (`lmn_prove` on a context with `shard_context` does all of this - and the
+    rest of the proof - natively; this is the level-2 building block.)"""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world & (world - 1) or world > 8:
         raise ValueError("world size must be 1, 2, 4 or 8")
     g = world.bit_length() - 1
-    blocks = []
+    blocks, handles = [], []
     for c in coeff_cols:
-        c = np.ascontiguousarray(c, dtype=np.uint32).reshape(1, -1)
-        log_domain = c.shape[1].bit_length() - 1 + log_blowup
-        blocks.append(ctx.evaluate(c, log_domain)[0] if g == 0 else ctx.evaluate_block(c, log_domain, g, rank)[0])
-    return _gather_root(ctx.merkle_root(blocks), group)
+        h = ctx.col_from_cpu(np.ascontiguousarray(c, dtype=np.uint32).reshape(1, -1))
+        log_domain = h.log_size + log_blowup
+        blocks.append(h.evaluate(log_domain) if g == 0 else h.evaluate_block(log_domain, g, rank))
+        handles.append(h)
+    tree = ctx.commit(blocks)
+    sub = tree.root()
+    tree.free()
+    for h in handles + blocks:
+        h.free()
+    return _gather_root(sub, group)
 
 
 def merkle_root_sharded(ctx, cols: Sequence[np.ndarray], group=None) -> bytes:

@@ -354,3 +354,116 @@ def check_evaluate_block(ctx, logs=((5, 6), (9, 10), (12, 13), (13, 14))):
             for b in range(1 << g):
                 got = ctx.evaluate_block(co, log_domain, g, b)
                 assert np.array_equal(got, full[:, b * S:(b + 1) * S]), (log_coeffs, log_domain, g, b)
+
+
+def check_device_handle_ops(ctx, log=7):
+    """Every `lmn_col_*` / `lmn_tree_*` op against the oracle's restatement of the same stwo operation, on
+    HBM-resident handles, and a chained interpolate -> evaluate -> commit -> quotients -> fold pipeline with ONE
+    upload and ONE download of column data."""
+    from oracle import fft
+    from oracle.circle import Coset, LineDomain
+    from oracle.field import P, QM31
+    from oracle.merkle import MerkleTree
+    from oracle.prover import accumulate_quotients, fold_circle_into_line, fold_line
+    rng = np.random.default_rng(23)
+    n = 1 << log
+    q = lambda: QM31(*[int(v) for v in rng.integers(0, P, size=4)])
+
+    # from_cpu / to_cpu / zeros / device_ptr
+    ev = rng.integers(0, P, size=(3, n), dtype=np.uint64)
+    h = ctx.col_from_cpu(ev)
+    assert (h.ncols, h.log_size) == (3, log) and h.device_ptr
+    assert np.array_equal(h.to_cpu(), ev.astype(np.uint32))
+    z = ctx.col_zeros(2, 5)
+    assert not z.to_cpu().any()
+    z.free()
+
+    # ColumnOps::bit_reverse_column
+    br = ctx.col_from_cpu(ev).bit_reverse()
+    idx = np.array([int(format(i, "0%db" % log)[::-1], 2) for i in range(n)])
+    assert np.array_equal(br.to_cpu(), ev[:, idx].astype(np.uint32))
+    assert np.array_equal(br.bit_reverse().to_cpu(), ev.astype(np.uint32))      # an involution
+    br.free()
+
+    # PolyOps::precompute_twiddles / interpolate / evaluate / extend / eval_at_point / evaluate_block
+    ctx.precompute_twiddles(log + 2)
+    h.interpolate()
+    co = fft.interpolate(ev)
+    assert np.array_equal(h.to_cpu(), co.astype(np.uint32))
+    lde = h.evaluate(log + 1)
+    want_lde = fft.evaluate(co, log + 1)
+    assert np.array_equal(lde.to_cpu(), want_lde.astype(np.uint32))
+    ext = h.extend(log + 2)
+    want_ext = np.concatenate([co, np.zeros((3, 3 * n), dtype=np.uint64)], axis=1)
+    assert np.array_equal(ext.to_cpu(), want_ext.astype(np.uint32))
+    assert np.array_equal(ext.evaluate(log + 2).to_cpu(), fft.evaluate(co, log + 2).astype(np.uint32))
+    pt = (q(), q())
+    for c in range(3):
+        assert h.eval_at_point(c, pt[0].v + pt[1].v) == fft.eval_at_point(co[c], pt).v
+    for lg_b in (1, 2):
+        for b in range(1 << lg_b):
+            blk = h.evaluate_block(log + 1, lg_b, b)
+            w = (2 * n) >> lg_b
+            assert np.array_equal(blk.to_cpu(), want_lde[:, b * w:(b + 1) * w].astype(np.uint32))
+            blk.free()
+
+    # MerkleOps::commit_on_layer chain over mixed sizes, layers kept on the device
+    small = ctx.col_from_cpu(rng.integers(0, P, size=(2, n // 4), dtype=np.uint64))
+    tree = ctx.commit([small, lde])
+    cols_host = [c for c in small.to_cpu()] + [c for c in lde.to_cpu()]
+    ref = MerkleTree(cols_host)
+    assert tree.root() == ref.root() and tree.log_size == log + 1
+    for lg in (0, 1, log + 1):
+        assert tree.layer(lg) == [bytes(x) for x in ref.layers[lg]]
+    tree.free()
+    small.free()
+
+    # AccumulationOps::accumulate
+    a = rng.integers(0, P, size=(4, n), dtype=np.uint64)
+    b = rng.integers(0, P, size=(4, n), dtype=np.uint64)
+    ha, hb = ctx.col_from_cpu(a), ctx.col_from_cpu(b)
+    assert np.array_equal(ha.accumulate(hb).to_cpu(), ((a + b) % P).astype(np.uint32))
+
+    # FriOps::fold_line / fold_circle_into_line
+    alpha = q()
+    dom = LineDomain(Coset.half_odds(log))
+    fl = hb.fold_line(alpha.v)
+    assert np.array_equal(fl.to_cpu().T.astype(np.uint64), fold_line(b.T, alpha, dom))
+    dst = rng.integers(0, P, size=(4, n // 2), dtype=np.uint64)
+    hd = ctx.col_from_cpu(dst)
+    hd.fold_circle_into_line(hb, alpha.v)
+    assert np.array_equal(hd.to_cpu().T.astype(np.uint64), fold_circle_into_line(dst.T, b.T, alpha, log))
+
+    # FriOps::decompose: f = g + lambda * v_n (bit-reversed circle domain: +1 on the first half, -1 on the second)
+    g, lam = hb.decompose()
+    bq = b.astype(object)
+    inv_n = pow(n, P - 2, P)
+    want_lam = tuple(int((int(bq[k, :n // 2].sum()) - int(bq[k, n // 2:].sum())) * inv_n % P) for k in range(4))
+    assert lam == want_lam
+    want_g = b.copy()
+    for k in range(4):
+        want_g[k, :n // 2] = (b[k, :n // 2] + P - want_lam[k]) % P
+        want_g[k, n // 2:] = (b[k, n // 2:] + want_lam[k]) % P
+    assert np.array_equal(g.to_cpu(), want_g.astype(np.uint32))
+    for x in (ha, hb, fl, hd, g, ext):
+        x.free()
+
+    # QuotientOps::accumulate_quotients on resident columns
+    pts = [(q(), q()), (q(), q())]
+    samples = [[(pts[0], q())], [(pts[0], q())], [(pts[1], q()), (pts[0], q())]]
+    L = 2 * n
+    want_q = accumulate_quotients(log + 1, [c for c in want_lde], samples, alpha)
+    flat = [(c, pts.index(p_), val.v) for c, ss in enumerate(samples) for (p_, val) in ss]
+    hq = ctx.col_accumulate_quotients([lde], flat, [p_[0].v + p_[1].v for p_ in pts], alpha.v)
+    assert np.array_equal(hq.to_cpu().T.astype(np.uint64), want_q)
+
+    # chained: (ONE upload above: `ev`) interpolate -> evaluate -> commit -> quotients -> circle fold -> line fold,
+    # ONE download of the final layer
+    layer = ctx.col_zeros(4, log)
+    layer.fold_circle_into_line(hq, alpha.v)
+    nxt = layer.fold_line(alpha.v)
+    w1 = fold_circle_into_line(np.zeros((n, 4), dtype=np.uint64), want_q, alpha, log + 1)
+    w2 = fold_line(w1, alpha, LineDomain(Coset.half_odds(log)))
+    assert np.array_equal(nxt.to_cpu().T.astype(np.uint64), w2)
+    for x in (h, lde, hq, layer, nxt):
+        x.free()

@@ -95,6 +95,12 @@ def test_emu_level2_ops(emu_ctx):
     check_evaluate_block(emu_ctx)
 
 
+def test_emu_device_handle_ops(emu_ctx):
+    from level2_checks import check_device_handle_ops
+    check_device_handle_ops(emu_ctx, 7)
+    check_device_handle_ops(emu_ctx, 4)
+
+
 def test_emu_device_trace_generation(emu_ctx):
     from level2_checks import check_device_trace_generation
     check_device_trace_generation(emu_ctx, 300)

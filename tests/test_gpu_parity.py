@@ -216,6 +216,14 @@ def test_gpu_level2_ops_match_oracle(gpu_prover):
     check_evaluate_block(ctx, logs=((5, 6), (12, 13), (15, 16), (19, 20), (20, 21)))
 
 
+def test_gpu_device_handle_ops_match_oracle(gpu_prover):
+    """Level 2 on device handles (lmn_col_* / lmn_tree_*): every op vs the oracle, plus the chained
+    interpolate -> evaluate -> commit -> quotients -> folds pipeline with one upload and one download."""
+    from level2_checks import check_device_handle_ops
+    check_device_handle_ops(gpu_prover.ctx, 7)
+    check_device_handle_ops(gpu_prover.ctx, 13)     # multi-pass FFT, fused Merkle kernel sizes
+
+
 @pytest.mark.parametrize("seed,scale", [(0, 1), (1, 1), (2, 40), (3, 40), (4, 150), (5, 150)])
 def test_gpu_random_pies_equal_c_oracle(gpu_prover_pinned, c_oracle, seed, scale):
     """Random component mixes with ragged sizes (up to ~10^5 rows): mixed-size Merkle trees, several
