@@ -5,10 +5,10 @@ Host-side mirror of the reference interface for the hot path only
 `crates/prover/src/lib.rs:15-32`).  All proving work happens in hand-written HIP kernels for
 gfx950 behind the C ABI of `include/luminair_hip.h`; there is no CPU fallback.
 """
-from .pie import (CircuitSettings, ExecutionResources, LuminairError, LuminairPie, LuminairProof, Metadata,
-                  TraceTable, TraceTableKind)
+from .pie import (CircuitSettings, ExecutionResources, Lookup, LookupLayout, LuminairError, LuminairPie, LuminairProof,
+                  Metadata, RangeCheckLookup, TraceTable, TraceTableKind)
 from .graph import DeviceGraph
 from .prover import Prover, prove, verify
 
-__all__ = ["CircuitSettings", "ExecutionResources", "LuminairError", "LuminairPie", "LuminairProof", "Metadata",
+__all__ = ["Lookup", "LookupLayout", "RangeCheckLookup", "CircuitSettings", "ExecutionResources", "LuminairError", "LuminairPie", "LuminairProof", "Metadata",
            "TraceTable", "TraceTableKind", "Prover", "prove", "verify", "DeviceGraph"]

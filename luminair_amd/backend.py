@@ -63,6 +63,11 @@ class LmnNodeInfo(C.Structure):
                 ("is_final_output", C.c_uint32), ("input_mults", C.c_int32 * 2)]
 
 
+class LmnRange(C.Structure):
+    """`Range(Fixed, Fixed)`: inclusive range of Fixed<12> values (i64)."""
+    _fields_ = [("lo", C.c_int64), ("hi", C.c_int64)]
+
+
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
@@ -93,7 +98,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
            "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block",
-           "lmn_verify_with_config", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
+           "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
            "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
            "lmn_col_commit", "lmn_tree_root", "lmn_tree_log_size", "lmn_tree_layer_to_cpu", "lmn_tree_free",
@@ -151,6 +156,8 @@ class Library:
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_upload_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.lmn_lut_log_size.argtypes = [C.POINTER(LmnRange), C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.lmn_lut_from_ranges.argtypes = [C.c_uint32, C.POINTER(LmnRange), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         VP, U32 = C.c_void_p, C.c_uint32
         lib.lmn_col_alloc.argtypes = [VP, U32, U32, C.POINTER(VP)]
         lib.lmn_col_from_cpu.argtypes = [VP, VP, U32, U32, C.POINTER(VP)]
@@ -209,6 +216,28 @@ class Library:
 
     def kind_columns(self, kind: int) -> int:
         return int(self.lib.lmn_kind_columns(kind))
+
+    def lut_log_size(self, ranges: Sequence[Tuple[int, int]]) -> int:
+        """`LookupLayout::new(ranges).log_size` (crates/air/src/preprocessed.rs:49-52)."""
+        arr = (LmnRange * len(ranges))(*[LmnRange(int(a), int(b)) for a, b in ranges])
+        out = C.c_uint32()
+        rc = self.lib.lmn_lut_log_size(arr, len(ranges), C.byref(out))
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, "bad LUT ranges")
+        return int(out.value)
+
+    def lut_from_ranges(self, name: str, ranges: Sequence[Tuple[int, int]], log_size: Optional[int] = None):
+        """The two preprocessed columns of a sin / exp2 / log2 LUT from the reference's `LookupLayout`
+        (`SinPreProcessed::gen_column` and siblings).  Returns (col0, col1), uint32 arrays of 2^log_size words."""
+        if log_size is None:
+            log_size = self.lut_log_size(ranges)
+        arr = (LmnRange * len(ranges))(*[LmnRange(int(a), int(b)) for a, b in ranges])
+        c0 = np.empty(1 << log_size, dtype=np.uint32)
+        c1 = np.empty(1 << log_size, dtype=np.uint32)
+        rc = self.lib.lmn_lut_from_ranges(LUT_KINDS[name], arr, len(ranges), log_size, c0.ctypes.data, c1.ctypes.data)
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, "bad LUT ranges")
+        return c0, c1
 
     def grind(self, digest: bytes, pow_bits: int, variant: int = VARIANT_KAT) -> int:
         """GrindOps::grind on a 32-byte channel digest."""

@@ -4,6 +4,9 @@
 
 #include "capi_internal.h"
 
+#include <algorithm>
+#include <cmath>
+
 using lmn::Context;
 
 namespace {
@@ -267,6 +270,72 @@ int lmn_ctx_set_shard_rccl(lmn_ctx* ctx, uint32_t rank, uint32_t world, uint32_t
 int lmn_ctx_clear_shard(lmn_ctx* ctx) {
   if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->clear_shard(); });
+}
+
+// ---- LUT columns from the reference's layouts (preprocessed.rs:34-46, 351-383, 434-466, 517-549)
+static int lut_values(const lmn_range* ranges, uint32_t n, std::vector<int64_t>& vals) {
+  if (!ranges || n == 0) return LMN_ERR_INVALID_ARGUMENT;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (ranges[i].hi < ranges[i].lo || ranges[i].lo <= -(1ll << 30) || ranges[i].hi >= (1ll << 30)) return LMN_ERR_INVALID_ARGUMENT;
+    total += (uint64_t)(ranges[i].hi - ranges[i].lo + 1);
+    if (total > (1ull << 26)) return LMN_ERR_INVALID_ARGUMENT;
+  }
+  vals.reserve(total);
+  for (uint32_t i = 0; i < n; ++i)
+    for (int64_t v = ranges[i].lo; v <= ranges[i].hi; ++v) vals.push_back(v);
+  std::sort(vals.begin(), vals.end());
+  vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+  return LMN_OK;
+}
+int lmn_lut_log_size(const lmn_range* ranges, uint32_t n_ranges, uint32_t* log_size_out) {
+  if (!log_size_out) return LMN_ERR_INVALID_ARGUMENT;
+  // LookupLayout::new counts the values of the (already coalesced) ranges: value_count, preprocessed.rs:117-119
+  uint64_t count = 0;
+  if (!ranges || n_ranges == 0) return LMN_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < n_ranges; ++i) {
+    if (ranges[i].hi < ranges[i].lo) return LMN_ERR_INVALID_ARGUMENT;
+    count += (uint64_t)(ranges[i].hi - ranges[i].lo + 1);
+  }
+  if (count > (1ull << 26)) return LMN_ERR_INVALID_ARGUMENT;
+  // calculate_log_size: ceil(count / 16) rounded up to a power of two, times 16 (LOG_N_LANES = 4)
+  uint64_t packs = (count + 15) >> 4, p2 = 1;
+  uint32_t lg = 0;
+  while (p2 < packs) {
+    p2 <<= 1;
+    ++lg;
+  }
+  *log_size_out = lg + 4;
+  return LMN_OK;
+}
+int lmn_lut_from_ranges(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_ranges, uint32_t log_size, uint32_t* col0_out,
+                        uint32_t* col1_out) {
+  if (!col0_out || !col1_out || lut_kind > LMN_LUT_LOG2 || log_size > 26) return LMN_ERR_INVALID_ARGUMENT;
+  std::vector<int64_t> vals;
+  int rc = lut_values(ranges, n_ranges, vals);
+  if (rc != LMN_OK) return rc;
+  const uint64_t n = 1ull << log_size;
+  if (vals.size() > n) return LMN_ERR_INVALID_ARGUMENT;
+  const double scale = 4096.0;
+  auto to_m31 = [](int64_t v) { return (uint32_t)(v >= 0 ? v : (int64_t)lmn::P31 + v); };  // Fixed::to_m31
+  for (uint64_t i = 0; i < n; ++i) col0_out[i] = col1_out[i] = 0u;
+  for (size_t i = 0; i < vals.size(); ++i) {
+    const double x = (double)vals[i] / scale;
+    double y;
+    if (lut_kind == LMN_LUT_SIN) {
+      y = std::sin(x);
+    } else if (lut_kind == LMN_LUT_EXP2) {
+      y = std::exp2(x);
+    } else {
+      if (vals[i] <= 0) return LMN_ERR_INVALID_ARGUMENT;
+      y = std::log2(x);
+    }
+    const double r = std::round(y * scale);
+    if (!(std::fabs(r) < (double)(1ll << 30))) return LMN_ERR_INVALID_ARGUMENT;
+    col0_out[i] = to_m31(vals[i]);
+    col1_out[i] = to_m31((int64_t)r);
+  }
+  return LMN_OK;
 }
 
 int lmn_upload_to(lmn_ctx* ctx, const void* host, size_t bytes, void* device_dst) {

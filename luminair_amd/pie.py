@@ -93,14 +93,46 @@ class LuminairPie:
 
 
 @dataclass
-class CircuitSettings:
-    """`CircuitSettings { lookups }` (crates/air/src/settings.rs).  `lookups` maps "sin" / "exp2" /
-    "log2" to that LUT's two preprocessed columns (col0 = inputs, col1 = outputs; uint32 M31 words,
-    2^k rows), i.e. what `lookups_to_preprocessed_column` + `gen_column_simd` produce from the
-    reference's layouts; the 8-bit range-check LUT is implied by a RangeCheckLookup table."""
-    lookups: Optional[dict] = None
+class LookupLayout:
+    """`LookupLayout { ranges: Vec<Range(Fixed, Fixed)>, log_size }` (crates/air/src/preprocessed.rs:34-46)."""
+    ranges: List[tuple]
+    log_size: int
 
-    def lut_columns(self) -> dict:
+
+@dataclass
+class Lookup:
+    """`SinLookup { layout, multiplicities }` (crates/air/src/components/lookups/sin/mod.rs:20-24; Exp2Lookup and
+    Log2Lookup alike).  `multiplicities` = the `AtomicMultiplicityColumn`'s 2^log_size counters."""
+    layout: LookupLayout
+    multiplicities: List[int]
+
+
+@dataclass
+class RangeCheckLookup:
+    """`RangeCheckLookup<1> { layout: RangeCheckLayout { ranges: [u32; 1], log_size }, multiplicities }`
+    (crates/air/src/components/lookups/range_check/mod.rs:23-37; graph.rs:142-146 builds it with ranges [8], log 8)."""
+    ranges: List[int]
+    log_size: int
+    multiplicities: List[int]
+
+
+_LOOKUP_FIELDS = ("sin", "exp2", "log2", "range_check")   # `Lookups` field order, lookups/mod.rs:18-28
+
+
+@dataclass
+class CircuitSettings:
+    """`CircuitSettings { lookups: Lookups }` (crates/air/src/settings.rs:14-17).  Two ways to describe a LUT:
+    * the reference's own form - `layouts[name] = Lookup(LookupLayout(ranges, log_size), multiplicities)` and
+      `range_check = RangeCheckLookup(...)`: this is what (de)serialises (bincode 1.3 and serde-JSON) and from which
+      the preprocessed columns are generated behind the boundary (`lmn_lut_from_ranges`);
+    * pre-expanded columns - `lookups[name] = (col0, col1)` (uint32 M31 words, 2^k rows) exactly as
+      `lookups_to_preprocessed_column` + `gen_column_simd` produce them; not serialisable (the reference has no
+      such form), kept for callers that generate LUTs themselves."""
+    lookups: Optional[dict] = None
+    layouts: Optional[dict] = None
+    range_check: Optional[RangeCheckLookup] = None
+
+    def lut_columns(self, library=None) -> dict:
         out = {}
         for name, cols in (self.lookups or {}).items():
             if name == "range_check":
@@ -108,22 +140,126 @@ class CircuitSettings:
             if name not in ("sin", "exp2", "log2"):
                 raise LuminairError("InvalidArgument", "unknown lookup " + name)
             out[name] = cols
+        if self.layouts:
+            from . import backend
+            lib = library or backend.default_library()
+            for name, lk in self.layouts.items():
+                if name not in ("sin", "exp2", "log2"):
+                    raise LuminairError("InvalidArgument", "unknown lookup " + name)
+                if name not in out:
+                    out[name] = lib.lut_from_ranges(name, lk.layout.ranges, lk.layout.log_size)
         return out
 
+    # ---- bincode 1.3 (fixed-width little-endian ints, u64 lengths, Option = one tag byte): numerair's `Fixed` is a
+    # newtype over i64 and serialises as that i64; `AtomicU32` as u32; `[u32; 1]` (serde_as) without a length
     def to_bincode(self, kat_era: bool = False) -> bytes:
-        """bincode of `CircuitSettings { lookups: Lookups }` for LUT-free graphs: one `None` tag per
-        `Lookups` field (HEAD: sin, exp2, log2, range_check; the KAT era had `sin` only, which is what
-        `ui/demo/public/settings` holds).  Settings WITH lookups carry numerair `Fixed` ranges and an
-        stwo-air-utils multiplicity column whose wire formats are un-vendored: not serialised here."""
-        if self.lookups:
-            raise LuminairError("SerializationError", "LUT layouts (value ranges) are not carried by this mirror")
-        return bytes(1 if kat_era else 4)
+        """bincode of `CircuitSettings`.  HEAD has four `Lookups` fields (sin, exp2, log2, range_check); the KAT era
+        had `sin` only, which is what `ui/demo/public/settings` holds (one `None` tag)."""
+        import struct
+        if self.lookups and not self.layouts:
+            raise LuminairError("SerializationError",
+                                "pre-expanded LUT columns have no wire form: describe the LUTs as LookupLayout ranges")
+        out = bytearray()
+        for name in _LOOKUP_FIELDS[:1] if kat_era else _LOOKUP_FIELDS:
+            if name == "range_check":
+                rc = self.range_check
+                if rc is None:
+                    out += b"\x00"
+                    continue
+                out += b"\x01" + b"".join(struct.pack("<I", v) for v in rc.ranges) + struct.pack("<I", rc.log_size)
+                out += struct.pack("<Q", len(rc.multiplicities)) + struct.pack("<%dI" % len(rc.multiplicities), *rc.multiplicities)
+                continue
+            lk = (self.layouts or {}).get(name)
+            if lk is None:
+                out += b"\x00"
+                continue
+            out += b"\x01" + struct.pack("<Q", len(lk.layout.ranges))
+            for lo, hi in lk.layout.ranges:
+                out += struct.pack("<qq", int(lo), int(hi))
+            out += struct.pack("<I", lk.layout.log_size)
+            out += struct.pack("<Q", len(lk.multiplicities)) + struct.pack("<%dI" % len(lk.multiplicities), *lk.multiplicities)
+        return bytes(out)
 
     @staticmethod
-    def from_bincode(data: bytes) -> "CircuitSettings":
-        if len(data) not in (1, 4) or any(data):
-            raise LuminairError("SerializationError", "only LUT-free settings can be deserialised")
-        return CircuitSettings()
+    def from_bincode(data: bytes, kat_era: Optional[bool] = None) -> "CircuitSettings":
+        import struct
+        if kat_era is None:
+            kat_era = len(data) == 1
+        pos = [0]
+
+        def take(fmt):
+            n = struct.calcsize(fmt)
+            if pos[0] + n > len(data):
+                raise LuminairError("SerializationError", "truncated settings")
+            v = struct.unpack_from(fmt, data, pos[0])
+            pos[0] += n
+            return v
+
+        def tag():
+            t = take("<B")[0]
+            if t > 1:
+                raise LuminairError("SerializationError", "bad Option tag")
+            return t == 1
+
+        def vec_len(elem):
+            n = take("<Q")[0]
+            if n * elem > len(data) - pos[0]:
+                raise LuminairError("SerializationError", "bad length")
+            return n
+        layouts, rc = {}, None
+        for name in _LOOKUP_FIELDS[:1] if kat_era else _LOOKUP_FIELDS:
+            if not tag():
+                continue
+            if name == "range_check":
+                bound, log = take("<II")
+                m = list(take("<%dI" % vec_len(4)))
+                rc = RangeCheckLookup([bound], log, m)
+                continue
+            ranges = [take("<qq") for _ in range(vec_len(16))]
+            log = take("<I")[0]
+            m = list(take("<%dI" % vec_len(4)))
+            layouts[name] = Lookup(LookupLayout(ranges, log), m)
+        if pos[0] != len(data):
+            raise LuminairError("SerializationError", "trailing bytes")
+        return CircuitSettings(None, layouts or None, rc)
+
+    # ---- serde-JSON (`to_json` = serde_json::to_string_pretty, settings.rs:71-76): tuple structs are arrays,
+    # newtypes their inner value
+    def to_json(self) -> str:
+        import json
+        if self.lookups and not self.layouts:
+            raise LuminairError("SerializationError",
+                                "pre-expanded LUT columns have no wire form: describe the LUTs as LookupLayout ranges")
+        lk = {}
+        for name in _LOOKUP_FIELDS[:3]:
+            v = (self.layouts or {}).get(name)
+            lk[name] = None if v is None else {
+                "layout": {"ranges": [[int(a), int(b)] for a, b in v.layout.ranges], "log_size": v.layout.log_size},
+                "multiplicities": {"data": list(v.multiplicities)}}
+        rc = self.range_check
+        lk["range_check"] = None if rc is None else {
+            "layout": {"ranges": list(rc.ranges), "log_size": rc.log_size}, "multiplicities": {"data": list(rc.multiplicities)}}
+        return json.dumps({"lookups": lk}, indent=2)
+
+    @staticmethod
+    def from_json(text: str) -> "CircuitSettings":
+        import json
+        try:
+            lk = json.loads(text)["lookups"]
+            layouts = {}
+            for name in _LOOKUP_FIELDS[:3]:
+                v = lk.get(name)
+                if v is not None:
+                    layouts[name] = Lookup(LookupLayout([(int(a), int(b)) for a, b in v["layout"]["ranges"]],
+                                                        int(v["layout"]["log_size"])),
+                                           [int(x) for x in v["multiplicities"]["data"]])
+            rc = lk.get("range_check")
+            rcl = None if rc is None else RangeCheckLookup([int(x) for x in rc["layout"]["ranges"]],
+                                                           int(rc["layout"]["log_size"]),
+                                                           [int(x) for x in rc["multiplicities"]["data"]])
+        except (KeyError, TypeError, ValueError) as e:
+            raise LuminairError("SerializationError", "Failed to deserialize settings from JSON: %s" % e)
+        return CircuitSettings(None, layouts or None, rcl)
 
 
 @dataclass

@@ -39,7 +39,7 @@ class Prover:
 
     def prove(self, pie: LuminairPie, settings: Optional[CircuitSettings] = None) -> LuminairProof:
         tables = [(int(t.kind), t.rows, t.n_rows) for t in pie.trace_tables]
-        luts = settings.lut_columns() if settings is not None else None
+        luts = settings.lut_columns(self.ctx.lib) if settings is not None else None
         try:
             return LuminairProof(self.ctx.prove_tables(tables, luts))
         except backend.LuminairBackendError as e:
@@ -65,7 +65,23 @@ def verify(proof: LuminairProof, settings: Optional[CircuitSettings] = None,
     """Drop-in for the reference's `verify(proof, settings)` (crates/verifiers/rust/src/verifier.rs:21-143):
     host-side check of a proof's bincode bytes; raises LuminairError(StwoVerifierError | InvalidLogUp | ...)."""
     lib = library or backend.default_library()
+    c_settings, keep = None, None
+    if settings is not None and (settings.layouts or settings.lookups or settings.range_check):
+        # what verifier.rs:47-57 reads from the settings: which lookups exist and how large their LUTs are
+        mask, luts = 0, []
+        for bit, name in enumerate(("sin", "exp2", "log2")):
+            if settings.layouts and name in settings.layouts:
+                mask |= 1 << bit
+                luts.append(backend.LmnLut(backend.LUT_KINDS[name], settings.layouts[name].layout.log_size, None, None))
+            elif settings.lookups and name in settings.lookups:
+                mask |= 1 << bit
+                luts.append(backend.LmnLut(backend.LUT_KINDS[name], len(settings.lookups[name][0]).bit_length() - 1, None, None))
+        if settings.range_check is not None:
+            mask |= 8
+        keep = (backend.LmnLut * max(len(luts), 1))(*luts)
+        c_settings = backend.LmnSettings(mask, len(luts), keep)
     try:
-        lib.verify(proof.to_bincode() if isinstance(proof, LuminairProof) else bytes(proof), protocol_variant)
+        lib.verify(proof.to_bincode() if isinstance(proof, LuminairProof) else bytes(proof), protocol_variant,
+                   settings=c_settings)
     except backend.LuminairBackendError as e:
         raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e

@@ -1,0 +1,107 @@
+"""`CircuitSettings` with lookups (crates/air/src/settings.rs, preprocessed.rs:34-46, lookups/sin/mod.rs:20-24,
+lookups/range_check/mod.rs:23-37): bincode / JSON round trips of the reference's own layout form, and the LUT columns
+generated behind the C ABI (`lmn_lut_from_ranges`, restating `SinPreProcessed::gen_column`, preprocessed.rs:351-383)."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import luminair_amd
+from luminair_amd import backend, synthetic as syn
+from luminair_amd.pie import CircuitSettings, Lookup, LookupLayout, RangeCheckLookup
+
+
+@pytest.fixture(scope="module")
+def lib(root):
+    so = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    if not os.path.exists(so):
+        subprocess.run([os.path.join(root, "tests", "emu", "build_emu.sh")], check=True, capture_output=True)
+    return backend.Library(so)
+
+
+def _settings():
+    return CircuitSettings(
+        layouts={"sin": Lookup(LookupLayout([(-300, -100), (5, 40)], 8), list(range(256))),
+                 "log2": Lookup(LookupLayout([(1, 16)], 4), [3] * 16)},
+        range_check=RangeCheckLookup([8], 8, [1] * 256))
+
+
+def test_settings_bincode_layout_and_round_trip():
+    s = _settings()
+    b = s.to_bincode()
+    # Lookups { sin: Some(..), exp2: None, log2: Some(..), range_check: Some(..) }, field by field
+    assert b[0] == 1 and struct.unpack_from("<Q", b, 1)[0] == 2                      # Some, 2 ranges
+    assert struct.unpack_from("<qqqq", b, 9) == (-300, -100, 5, 40)                 # Range(Fixed, Fixed) = two i64
+    assert struct.unpack_from("<I", b, 41)[0] == 8                                  # log_size
+    assert struct.unpack_from("<Q", b, 45)[0] == 256                                # multiplicities.data: Vec<AtomicU32>
+    off = 53 + 4 * 256
+    assert b[off] == 0                                                              # exp2: None
+    back = CircuitSettings.from_bincode(b)
+    assert back.layouts["sin"].layout.ranges == [(-300, -100), (5, 40)] and back.layouts["sin"].multiplicities == list(range(256))
+    assert "exp2" not in back.layouts and back.layouts["log2"].layout.log_size == 4
+    assert back.range_check.ranges == [8] and back.range_check.log_size == 8 and len(back.range_check.multiplicities) == 256
+    assert back.to_bincode() == b
+    for bad in (b[:-1], b + b"\x00", b"\x02" + b[1:]):
+        with pytest.raises(luminair_amd.LuminairError):
+            CircuitSettings.from_bincode(bad)
+    assert CircuitSettings().to_bincode() == bytes(4) and CircuitSettings.from_bincode(bytes(4)).layouts is None
+
+
+def test_settings_json_round_trip():
+    s = _settings()
+    j = s.to_json()
+    d = json.loads(j)
+    assert d["lookups"]["exp2"] is None
+    assert d["lookups"]["sin"]["layout"] == {"ranges": [[-300, -100], [5, 40]], "log_size": 8}
+    assert d["lookups"]["range_check"]["layout"] == {"ranges": [8], "log_size": 8}
+    assert CircuitSettings.from_json(j).to_bincode() == s.to_bincode()
+    with pytest.raises(luminair_amd.LuminairError):
+        CircuitSettings.from_json('{"lookups": {"sin": {"layout": 3}}}')
+
+
+@pytest.mark.parametrize("name,lo,hi", [("sin", -4 * 4096, 4 * 4096), ("exp2", -2 * 4096, 2 * 4096), ("log2", 1, 4 * 4096),
+                                        ("sin", -7, 9)])
+def test_lut_from_ranges_matches_the_host_generator(lib, name, lo, hi):
+    want0, want1 = syn.make_lut(name, lo, hi)
+    assert lib.lut_log_size([(lo, hi)]) == len(want0).bit_length() - 1
+    c0, c1 = lib.lut_from_ranges(name, [(lo, hi)])
+    assert np.array_equal(c0, want0) and np.array_equal(c1, want1)
+    # ranges in any order, overlapping: values are sorted and de-duplicated (gen_column: sort_unstable + dedup)
+    mid = (lo + hi) // 2
+    d0, d1 = lib.lut_from_ranges(name, [(mid, hi), (lo, mid + 3 if mid + 3 <= hi else mid)], len(want0).bit_length() - 1)
+    assert np.array_equal(d0, want0) and np.array_equal(d1, want1)
+
+
+def test_lut_from_ranges_rejects_bad_input(lib):
+    for name, ranges, log in (("sin", [(5, 4)], 4), ("log2", [(0, 5)], 4), ("sin", [(0, 100)], 4), ("sin", [], 4)):
+        with pytest.raises(backend.LuminairBackendError):
+            lib.lut_from_ranges(name, ranges, log)
+
+
+def test_prove_from_layout_settings_equals_prove_from_columns(lib):
+    """`lmn_prove` fed by the reference's own settings form (ranges -> columns behind the boundary) gives the bytes
+    of the same proof fed by pre-expanded LUT columns, and the verifier accepts it together with those settings."""
+    tabs, luts = syn.activation_graph(30, 4, names=("sin", "exp2"))
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    want = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts)
+    ranges = {"sin": (-4 * 4096, 4 * 4096), "exp2": (-2 * 4096, 2 * 4096)}
+    mult = {4: None, 10: None}
+    for k, r in tabs:
+        if k in mult:
+            mult[k] = [int(v) for v in r[:, 0]]
+    settings = CircuitSettings(layouts={
+        "sin": Lookup(LookupLayout([ranges["sin"]], lib.lut_log_size([ranges["sin"]])), mult[4]),
+        "exp2": Lookup(LookupLayout([ranges["exp2"]], lib.lut_log_size([ranges["exp2"]])), mult[10])})
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], settings.lut_columns(lib))
+    assert got == want
+    settings2 = CircuitSettings.from_bincode(settings.to_bincode())
+    luminair_amd.verify(luminair_amd.LuminairProof(got), settings2, backend.VARIANT_PINNED, library=lib)
+    wrong = CircuitSettings(layouts={"log2": Lookup(LookupLayout([(1, 16)], 4), [0] * 16)})
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.verify(luminair_amd.LuminairProof(got), wrong, backend.VARIANT_PINNED, library=lib)
+    ctx.close()
