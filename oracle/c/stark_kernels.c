@@ -83,40 +83,110 @@ static const qm QZERO = {0, 0, 0, 0};
  * tw[i] = twiddles of layer i (2^(log_n-1-i) words): forward twiddles, or their inverses when
  * inverse != 0 (the caller passes the matching table).  Inverse also scales by 2^-log_n.
  * ------------------------------------------------------------------------------------------- */
+/* The layers are grouped into two cache-resident passes (the same split the GPU kernels use): the low layers
+ * 0..CH-1 stay inside one contiguous chunk of 2^CH words; the high layers CH..log_n-1 pair rows that are 2^CH words
+ * apart, so a tile of FFT_G consecutive words x all 2^(log_n-CH) rows is gathered into a local buffer, transformed and
+ * scattered back.  Every butterfly is the same arithmetic as the one-layer-at-a-time form (tests/test_oracle_c.py
+ * compares it with the numpy restatement); only the order of independent butterflies changes.
+ * HOT marks the functions compiled for AVX-512 / AVX2 / baseline x86-64 and dispatched by cpuid at load time: the
+ * library is built in one container and travels to other hosts. */
+#define HOT __attribute__((target_clones("arch=skylake-avx512", "avx2", "default")))
+#define FFT_G 16
+#define PAR_MIN (1L << 15) /* below this many words an OpenMP team costs more than it saves */
+
+static inline void bfly_fwd(u32* lo, u32* hi, u32 w) {
+  u32 x = mmul(*hi, w), a = *lo;
+  *lo = madd(a, x);
+  *hi = msub(a, x);
+}
+static inline void bfly_inv(u32* lo, u32* hi, u32 w) {
+  u32 a = *lo, b = *hi;
+  *lo = madd(a, b);
+  *hi = mmul(msub(a, b), w);
+}
+
+/* layers [0, ch) of the chunk starting at word `base` of a column (chunk index = base >> ch) */
+HOT static void fft_low_chunk(u32* col, long base, int ch, const u32* const* tw, int inverse) {
+  u32* d = col + base;
+  for (int s = 0; s < ch; ++s) {
+    const int i = inverse ? s : ch - 1 - s;
+    const long span = 1L << i, nh = 1L << (ch - 1 - i);
+    const u32* t = tw[i] + ((base >> ch) << (ch - 1 - i));
+    for (long h = 0; h < nh; ++h) {
+      const u32 w = t[h];
+      u32* lo = d + (h << (i + 1));
+      u32* hi = lo + span;
+      if (inverse)
+        for (long l = 0; l < span; ++l) bfly_inv(lo + l, hi + l, w);
+      else
+        for (long l = 0; l < span; ++l) bfly_fwd(lo + l, hi + l, w);
+    }
+  }
+}
+
+/* layers [ch, log_n) on the tile of FFT_G words starting at low offset l0: buf[row][j], row = index >> ch */
+HOT static void fft_high_tile(u32* col, long l0, int ch, int log_n, const u32* const* tw, int inverse, u32* buf) {
+  const int T = log_n - ch;
+  const long rows = 1L << T;
+  for (long r = 0; r < rows; ++r)
+    for (int j = 0; j < FFT_G; ++j) buf[r * FFT_G + j] = col[(r << ch) + l0 + j];
+  for (int s = 0; s < T; ++s) {
+    const int k = inverse ? s : T - 1 - s; /* row bit paired by layer ch + k */
+    const long span = 1L << k, nh = 1L << (T - 1 - k);
+    const u32* t = tw[ch + k];
+    for (long h = 0; h < nh; ++h) {
+      const u32 w = t[h];
+      for (long l = 0; l < span; ++l) {
+        u32* lo = buf + ((h << (k + 1)) + l) * FFT_G;
+        u32* hi = lo + span * FFT_G;
+        if (inverse)
+          for (int j = 0; j < FFT_G; ++j) bfly_inv(lo + j, hi + j, w);
+        else
+          for (int j = 0; j < FFT_G; ++j) bfly_fwd(lo + j, hi + j, w);
+      }
+    }
+  }
+  for (long r = 0; r < rows; ++r)
+    for (int j = 0; j < FFT_G; ++j) col[(r << ch) + l0 + j] = buf[r * FFT_G + j];
+}
+
+HOT static void scale_words(u32* d, long n, u32 sc) {
+  for (long k = 0; k < n; ++k) d[k] = mmul(d[k], sc);
+}
+
 void orc_circle_fft(u32* data, long ncols, int log_n, const u32* const* tw, int inverse) {
   const long n = 1L << log_n;
-  const long half_n = n >> 1;
   const u32 sc = minv(mpow(2, (u32)log_n));
-#pragma omp parallel
+  int ch = log_n <= 12 ? log_n : (log_n - 12 > 12 ? log_n - 12 : 12);
+  if (ch < 4 && log_n >= 4) ch = 4; /* a high tile needs FFT_G consecutive words */
+  if (log_n < 4) ch = log_n;
+  const long nchunks = n >> ch, ntiles = ch >= 4 ? (1L << ch) / FFT_G : 0;
+  const int T = log_n - ch;
+  const int par = ncols * n >= PAR_MIN;
+#pragma omp parallel if (par)
   {
-    for (int s = 0; s < log_n; ++s) {
-      const int i = inverse ? s : log_n - 1 - s;
-      const u32* t = tw[i];
-      const long hmask = (1L << i) - 1;
-      /* flat butterfly index over all columns: (column, h, l) */
-#pragma omp for schedule(static)
-      for (long f = 0; f < ncols * half_n; ++f) {
-        const long c = f / half_n, bfly = f - c * half_n;
-        const long h = bfly >> i, l = bfly & hmask;
-        u32* lo = data + c * n + (h << (i + 1)) + l;
-        u32* hi = lo + (1L << i);
-        const u32 w = t[h];
-        if (inverse) {
-          u32 a = *lo, b = *hi;
-          *lo = madd(a, b);
-          *hi = mmul(msub(a, b), w);
-        } else {
-          u32 x = mmul(*hi, w);
-          u32 a = *lo;
-          *lo = madd(a, x);
-          *hi = msub(a, x);
-        }
-      } /* implicit barrier between layers */
+    u32* buf = T > 0 ? (u32*)malloc(sizeof(u32) * FFT_G << T) : NULL;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int low = inverse ? pass == 0 : pass == 1;
+      if (low) {
+#pragma omp for schedule(static) collapse(2)
+        for (long c = 0; c < ncols; ++c)
+          for (long k = 0; k < nchunks; ++k) fft_low_chunk(data + c * n, k << ch, ch, tw, inverse);
+      } else if (T > 0) {
+#pragma omp for schedule(static) collapse(2)
+        for (long c = 0; c < ncols; ++c)
+          for (long k = 0; k < ntiles; ++k) fft_high_tile(data + c * n, k * FFT_G, ch, log_n, tw, inverse, buf);
+      }
     }
     if (inverse) {
+      const long blk = 1L << 14, nblk = (ncols * n + blk - 1) / blk;
 #pragma omp for schedule(static)
-      for (long k = 0; k < ncols * n; ++k) data[k] = mmul(data[k], sc);
+      for (long k = 0; k < nblk; ++k) {
+        const long a = k * blk, e = a + blk < ncols * n ? a + blk : ncols * n;
+        scale_words(data + a, e - a, sc);
+      }
     }
+    free(buf);
   }
 }
 
@@ -150,9 +220,63 @@ static void compress(u32 h[8], const u32 m[16], u32 t, u32 f) {
 #undef G
   for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
 }
+/* LW independent hashes side by side (one per SIMD lane): the same compression function written over arrays so
+ * that the compiler turns every line into one vector instruction (vprord etc. under AVX-512). */
+#define LW 16
+HOT static void compress_lanes(u32 h[8][LW], u32 m[16][LW], u32 t, u32 f) {
+  u32 v[16][LW];
+  for (int i = 0; i < 8; ++i)
+    for (int l = 0; l < LW; ++l) { v[i][l] = h[i][l]; v[i + 8][l] = IV[i]; }
+  for (int l = 0; l < LW; ++l) { v[12][l] ^= t; v[14][l] ^= f; }
+#define GL(a, b, c, d, x, y)                                                                  \
+  for (int l = 0; l < LW; ++l) {                                                              \
+    v[a][l] += v[b][l] + m[x][l]; v[d][l] = rotr(v[d][l] ^ v[a][l], 16);                      \
+    v[c][l] += v[d][l];           v[b][l] = rotr(v[b][l] ^ v[c][l], 12);                      \
+    v[a][l] += v[b][l] + m[y][l]; v[d][l] = rotr(v[d][l] ^ v[a][l], 8);                       \
+    v[c][l] += v[d][l];           v[b][l] = rotr(v[b][l] ^ v[c][l], 7);                       \
+  }
+  for (int r = 0; r < 10; ++r) {
+    const unsigned char* s = SIGMA[r];
+    GL(0, 4, 8, 12, s[0], s[1]) GL(1, 5, 9, 13, s[2], s[3])
+    GL(2, 6, 10, 14, s[4], s[5]) GL(3, 7, 11, 15, s[6], s[7])
+    GL(0, 5, 10, 15, s[8], s[9]) GL(1, 6, 11, 12, s[10], s[11])
+    GL(2, 7, 8, 13, s[12], s[13]) GL(3, 4, 9, 14, s[14], s[15])
+  }
+#undef GL
+  for (int i = 0; i < 8; ++i)
+    for (int l = 0; l < LW; ++l) h[i][l] ^= v[i][l] ^ v[i + 8][l];
+}
+
+/* nodes [i0, i0 + LW) of one Merkle layer (all lanes valid) */
+HOT static void merkle_lanes(const u32* prev, const u32* const* cols, int ncols, long i0, u32* out) {
+  const int npre = prev ? 16 : 0;
+  const int w = npre + ncols;
+  const int nblocks = w == 0 ? 1 : (w + 15) / 16;
+  u32 h[8][LW], m[16][LW];
+  for (int k = 0; k < 8; ++k)
+    for (int l = 0; l < LW; ++l) h[k][l] = IV[k] ^ (k == 0 ? 0x01010020u : 0u);
+  for (int b = 0; b < nblocks; ++b) {
+    for (int k = 0; k < 16; ++k) {
+      const int j = 16 * b + k;
+      if (j < npre) {
+        for (int l = 0; l < LW; ++l) m[k][l] = prev[16 * (i0 + l) + j];
+      } else if (j < w) {
+        const u32* c = cols[j - npre] + i0;
+        for (int l = 0; l < LW; ++l) m[k][l] = c[l];
+      } else {
+        for (int l = 0; l < LW; ++l) m[k][l] = 0;
+      }
+    }
+    const int last = b + 1 == nblocks;
+    compress_lanes(h, m, last ? (u32)(4 * w) : (u32)(64 * (b + 1)), last ? 0xffffffffu : 0);
+  }
+  for (int l = 0; l < LW; ++l)
+    for (int k = 0; k < 8; ++k) out[8 * (i0 + l) + k] = h[k][l];
+}
+
 void orc_blake2s_rows(const u32* words, long n, int w, u32* out) {
   const int nblocks = w == 0 ? 1 : (w + 15) / 16;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * (long)(w + 8) >= PAR_MIN)
   for (long i = 0; i < n; ++i) {
     u32 h[8];
     for (int k = 0; k < 8; ++k) h[k] = IV[k];
@@ -177,7 +301,7 @@ void orc_logup_columns(const u32* const* val, const u32* const* id /* entries ma
                        const u32* const* mult, int k, long n, const u32* zs /* 4 per relation */,
                        const u32* alphas /* 4 per relation */, const int* neg, u32* out, u32 claimed[4]) {
   u64 acc[4] = {0, 0, 0, 0};
-#pragma omp parallel
+#pragma omp parallel if (n * (long)k >= 2048)
   {
     u64 loc[4] = {0, 0, 0, 0};
 #pragma omp for schedule(static)
@@ -309,7 +433,7 @@ void orc_composition(int kind, int n_cols, int n_rel, const u32* const* rel_val,
                      const u32* main, const u32* inter, long E, const int64_t* prev_idx, const u32 shift[4],
                      const u32* coeff /* 4 words each */, const u32* zinv, u32* out, int accumulate) {
   const qm SH = {shift[0], shift[1], shift[2], shift[3]};
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (E >= 2048)
   for (long s = 0; s < E; ++s) {
     u32 c[32], lc[16];
     for (int k = 0; k < n_cols; ++k) c[k] = main[(long)k * E + s];
@@ -368,7 +492,7 @@ void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 
     const int k = log_n - 1;
     const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
     const long half = n / 2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (half >= 4096)
     for (long i = 0; i < half; ++i) acc[i] = qadd(qfromm(coeffs[i]), qmulm(m, coeffs[half + i]));
   }
   for (int k = log_n - 2; k >= 0; --k) {
@@ -389,7 +513,7 @@ void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 
 void orc_quotients(const u32* const* cols, long L, int nbatch, const int* bstart, const int* col_idx,
                    const u32* la, const u32* lb, const u32* lc /* 4 words per entry */, const u32* pts /* 8/batch */,
                    const u32* batch_coeff /* 4/batch */, const u32* xs, const u32* ys, u32* out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (L >= 2048)
   for (long s = 0; s < L; ++s) {
     const u32 x = xs[s], y = ys[s];
     qm row = QZERO;
@@ -419,7 +543,7 @@ void orc_fold(u32* dst, const u32* src, long src_len, const u32* itw, const u32 
   const qm AL = {alpha[0], alpha[1], alpha[2], alpha[3]};
   const qm AL2 = qmul(AL, AL);
   const long n = src_len / 2, L = src_len;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= 4096)
   for (long i = 0; i < n; ++i) {
     qm a = {src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
     qm b = {src[2 * i + 1], src[L + 2 * i + 1], src[2 * L + 2 * i + 1], src[3 * L + 2 * i + 1]};
@@ -438,8 +562,10 @@ void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long s
   const int npre = prev ? 16 : 0;
   const int w = npre + ncols;
   const int nblocks = w == 0 ? 1 : (w + 15) / 16;
-#pragma omp parallel for schedule(static)
-  for (long i = 0; i < size; ++i) {
+  const long groups = size / LW;
+#pragma omp parallel for schedule(static) if (size * (long)(w + 8) >= PAR_MIN)
+  for (long g = 0; g < groups; ++g) merkle_lanes(prev, cols, ncols, g * LW, out);
+  for (long i = groups * LW; i < size; ++i) { /* ragged tail (and layers narrower than LW): one hash at a time */
     u32 h[8];
     for (int k = 0; k < 8; ++k) h[k] = IV[k];
     h[0] ^= 0x01010020u;
@@ -459,7 +585,7 @@ void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long s
 /* out[i] = 1/v[i] (Montgomery batch inversion in chunks, chunks in parallel) */
 void orc_batch_inverse(const u32* v, long n, u32* out) {
   const long chunk = 4096;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= 16384)
   for (long c0 = 0; c0 < n; c0 += chunk) {
     long c1 = c0 + chunk < n ? c0 + chunk : n;
     u32 pre[4096];

@@ -82,6 +82,46 @@ def test_gpu_linear_layer_2_19_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
     assert _gpu_bytes(gpu_prover, tabs) == to_bincode(prove(tabs, kernels=c_oracle))
 
 
+def _sha(b):
+    import hashlib
+    return hashlib.sha256(b).hexdigest()
+
+
+def test_gpu_config3_full_size_2_22_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
+    """BASELINE config 3 at FULL size (Add 2^21 + Mul 2^20 + Recip 2^20 rows, three components in every
+    commitment, mixed-size trees): the GPU proof and the C oracle's proof have the same SHA-256."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config3_mixed(21, 20, 20, 5)
+    want = to_bincode(prove(tabs, kernels=c_oracle))
+    got = _gpu_bytes(gpu_prover, tabs)
+    assert len(got) == len(want) and _sha(got) == _sha(want)
+
+
+def test_gpu_config2b_full_size_equals_c_oracle_bytes(gpu_prover_pinned, c_oracle):
+    """BASELINE config 2b at FULL size (what gen_trace emits for one Add node at HEAD: Add 2^20 rows consumed with
+    multiplicity -1 + the Inputs table of 2^21 rows; PINNED variant), byte-for-byte against the C oracle."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config2_graph_faithful(1 << 20, 42)
+    want = to_bincode(prove(tabs, kernels=c_oracle, variant=ProtocolVariant.PINNED))
+    got = _gpu_bytes(gpu_prover_pinned, tabs)
+    assert len(got) == len(want) and _sha(got) == _sha(want)
+
+
+def test_gpu_config5_full_size_2_24_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
+    """BASELINE config 5 at FULL size (256 x (Mul + SumReduce + Add): Mul 2^23 + SumReduce 2^23 + Add 2^15 rows,
+    composition LDE of 2^25 rows): SHA-256 of the GPU proof == SHA-256 of the C oracle's proof.  The oracle run is
+    the long part (tens of seconds on the GPU box's host cores, ~25 GB of host memory)."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config5_linear_layers()
+    got = _gpu_bytes(gpu_prover, tabs)
+    want = to_bincode(prove(tabs, kernels=c_oracle))
+    assert len(got) == len(want) and _sha(got) == _sha(want)
+
+
 def test_gpu_device_resident_rows_give_same_proof(gpu_prover):
     tabs = syn.chain_graph(3000, 11)
     want = _gpu_bytes(gpu_prover, tabs)
