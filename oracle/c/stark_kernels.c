@@ -93,6 +93,11 @@ static const qm QZERO = {0, 0, 0, 0};
 #define HOT __attribute__((target_clones("arch=skylake-avx512", "avx2", "default")))
 #define FFT_G 16
 #define PAR_MIN (1L << 15) /* below this many words an OpenMP team costs more than it saves */
+#include <omp.h>
+/* A loop goes parallel only when every thread of the (full) team gets at least 2^12 work units: waking a 256-thread
+ * team for a 2^12-point loop costs more than the loop itself.  (Always the full team or none: libgomp tears threads
+ * down and re-creates them when consecutive regions ask for different team sizes.) */
+static inline int par_ok(long work) { return work >= ((long)omp_get_max_threads() << 12); }
 
 static inline void bfly_fwd(u32* lo, u32* hi, u32 w) {
   u32 x = mmul(*hi, w), a = *lo;
@@ -162,8 +167,7 @@ void orc_circle_fft(u32* data, long ncols, int log_n, const u32* const* tw, int 
   if (log_n < 4) ch = log_n;
   const long nchunks = n >> ch, ntiles = ch >= 4 ? (1L << ch) / FFT_G : 0;
   const int T = log_n - ch;
-  const int par = ncols * n >= PAR_MIN;
-#pragma omp parallel if (par)
+#pragma omp parallel if (par_ok(ncols * n * (long)log_n / 8))
   {
     u32* buf = T > 0 ? (u32*)malloc(sizeof(u32) * FFT_G << T) : NULL;
     for (int pass = 0; pass < 2; ++pass) {
@@ -276,7 +280,7 @@ HOT static void merkle_lanes(const u32* prev, const u32* const* cols, int ncols,
 
 void orc_blake2s_rows(const u32* words, long n, int w, u32* out) {
   const int nblocks = w == 0 ? 1 : (w + 15) / 16;
-#pragma omp parallel for schedule(static) if (n * (long)(w + 8) >= PAR_MIN)
+#pragma omp parallel for schedule(static) if (par_ok(n * (long)(w + 8) * 8))
   for (long i = 0; i < n; ++i) {
     u32 h[8];
     for (int k = 0; k < 8; ++k) h[k] = IV[k];
@@ -301,7 +305,7 @@ void orc_logup_columns(const u32* const* val, const u32* const* id /* entries ma
                        const u32* const* mult, int k, long n, const u32* zs /* 4 per relation */,
                        const u32* alphas /* 4 per relation */, const int* neg, u32* out, u32 claimed[4]) {
   u64 acc[4] = {0, 0, 0, 0};
-#pragma omp parallel if (n * (long)k >= 2048)
+#pragma omp parallel if (par_ok(n * (long)k * 64))
   {
     u64 loc[4] = {0, 0, 0, 0};
 #pragma omp for schedule(static)
@@ -433,7 +437,7 @@ void orc_composition(int kind, int n_cols, int n_rel, const u32* const* rel_val,
                      const u32* main, const u32* inter, long E, const int64_t* prev_idx, const u32 shift[4],
                      const u32* coeff /* 4 words each */, const u32* zinv, u32* out, int accumulate) {
   const qm SH = {shift[0], shift[1], shift[2], shift[3]};
-#pragma omp parallel for schedule(static) if (E >= 2048)
+#pragma omp parallel for schedule(static) if (par_ok(E * 64))
   for (long s = 0; s < E; ++s) {
     u32 c[32], lc[16];
     for (int k = 0; k < n_cols; ++k) c[k] = main[(long)k * E + s];
@@ -492,13 +496,13 @@ void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 
     const int k = log_n - 1;
     const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
     const long half = n / 2;
-#pragma omp parallel for schedule(static) if (half >= 4096)
+#pragma omp parallel for schedule(static) if (par_ok(half * 8))
     for (long i = 0; i < half; ++i) acc[i] = qadd(qfromm(coeffs[i]), qmulm(m, coeffs[half + i]));
   }
   for (int k = log_n - 2; k >= 0; --k) {
     const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
     const long half = 1L << k;
-#pragma omp parallel for schedule(static) if (half > 4096)
+#pragma omp parallel for schedule(static) if (par_ok(half * 8))
     for (long i = 0; i < half; ++i) acc[i] = qadd(acc[i], qmul(acc[half + i], m));
   }
   out[0] = acc[0].a; out[1] = acc[0].b; out[2] = acc[0].c; out[3] = acc[0].d;
@@ -513,7 +517,7 @@ void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 
 void orc_quotients(const u32* const* cols, long L, int nbatch, const int* bstart, const int* col_idx,
                    const u32* la, const u32* lb, const u32* lc /* 4 words per entry */, const u32* pts /* 8/batch */,
                    const u32* batch_coeff /* 4/batch */, const u32* xs, const u32* ys, u32* out) {
-#pragma omp parallel for schedule(static) if (L >= 2048)
+#pragma omp parallel for schedule(static) if (par_ok(L * 64))
   for (long s = 0; s < L; ++s) {
     const u32 x = xs[s], y = ys[s];
     qm row = QZERO;
@@ -543,7 +547,7 @@ void orc_fold(u32* dst, const u32* src, long src_len, const u32* itw, const u32 
   const qm AL = {alpha[0], alpha[1], alpha[2], alpha[3]};
   const qm AL2 = qmul(AL, AL);
   const long n = src_len / 2, L = src_len;
-#pragma omp parallel for schedule(static) if (n >= 4096)
+#pragma omp parallel for schedule(static) if (par_ok(n * 16))
   for (long i = 0; i < n; ++i) {
     qm a = {src[2 * i], src[L + 2 * i], src[2 * L + 2 * i], src[3 * L + 2 * i]};
     qm b = {src[2 * i + 1], src[L + 2 * i + 1], src[2 * L + 2 * i + 1], src[3 * L + 2 * i + 1]};
@@ -563,7 +567,7 @@ void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long s
   const int w = npre + ncols;
   const int nblocks = w == 0 ? 1 : (w + 15) / 16;
   const long groups = size / LW;
-#pragma omp parallel for schedule(static) if (size * (long)(w + 8) >= PAR_MIN)
+#pragma omp parallel for schedule(static) if (par_ok(size * (long)(w + 8) * 8))
   for (long g = 0; g < groups; ++g) merkle_lanes(prev, cols, ncols, g * LW, out);
   for (long i = groups * LW; i < size; ++i) { /* ragged tail (and layers narrower than LW): one hash at a time */
     u32 h[8];
@@ -585,7 +589,7 @@ void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long s
 /* out[i] = 1/v[i] (Montgomery batch inversion in chunks, chunks in parallel) */
 void orc_batch_inverse(const u32* v, long n, u32* out) {
   const long chunk = 4096;
-#pragma omp parallel for schedule(static) if (n >= 16384)
+#pragma omp parallel for schedule(static) if (par_ok(n * 4))
   for (long c0 = 0; c0 < n; c0 += chunk) {
     long c1 = c0 + chunk < n ? c0 + chunk : n;
     u32 pre[4096];
