@@ -183,7 +183,8 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, co
 
 // SumReduce rows (prim.rs:1486-1510, 1536-1561): row r = (i*back + j)*dim + k holds input[i, k, j], the
 // running sum before and after it, and the output on the group's last step.  One lane per row; the prefix
-// inside a group is re-summed per lane (dim is a tensor axis, at most a few hundred), rows leave through LDS.
+// inside a group comes from a block-wide segmented scan (plus one cooperative carry-in for the group that straddles
+// the block's first row), rows leave through LDS.
 // MAX: MaxReduce rows (prim.rs:1591-1734): the running maximum starts at the group's first element, is_max marks
 // the rows whose input becomes the new maximum (strict comparison).
 template <bool MAX>
@@ -191,15 +192,59 @@ LMN_KERNEL k_trace_reduce(const int32_t* __restrict__ input, uint64_t dim, uint6
                           uint64_t n_out, TraceNode nd, uint32_t* __restrict__ rows, int32_t* __restrict__ out) {
   constexpr int NC = MAX ? 15 : 14, ST = MAX ? 17 : 15;
   LMN_SHARED uint32_t tile[TPB * ST];
+  LMN_SHARED int64_t scan[TPB];   // inclusive segmented scan of the block's inputs (segment = reduction group)
+  LMN_SHARED uint32_t head[TPB];  // distance (in lanes) back to the segment's first lane inside this block
   const uint64_t row0 = (uint64_t)blockIdx.x * TPB;
   const uint64_t r = row0 + threadIdx.x;
-  if (r < n_rows) {
-    const uint64_t g = r / dim, k = r % dim;  // output index (i*back + j), reduction step
-    const uint64_t i = g / back, j = g % back;
-    const int32_t* p = input + i * dim * back + j;
-    int64_t acc = MAX ? (int64_t)p[0] : 0;
-    for (uint64_t kk = 0; kk < k; ++kk) acc = MAX ? (p[kk * back] > acc ? (int64_t)p[kk * back] : acc) : acc + p[kk * back];
-    const int64_t v = p[k * back], next = MAX ? (v > acc ? v : acc) : acc + v;
+  const bool on = r < n_rows;
+  const uint64_t g = on ? r / dim : 0, k = on ? r % dim : 0;  // output index (i*back + j), reduction step
+  const uint64_t i = g / back, j = g % back;
+  const int32_t* p = input + i * dim * back + j;
+  const int64_t v = on ? (int64_t)p[k * back] : 0;
+  auto op = [](int64_t a, int64_t b) { return MAX ? (a > b ? a : b) : a + b; };
+  // carry-in of the group that straddles the block's first row: steps [0, k0) of that group, reduced cooperatively
+  // (the block's first lane has k = k0); every other group starts inside the block
+  const uint64_t k0 = row0 % dim;
+  {
+    const uint64_t g0 = row0 / dim, i0 = g0 / back, j0 = g0 % back;
+    const int32_t* p0 = input + i0 * dim * back + j0;
+    int64_t part = MAX ? INT64_MIN : 0;
+    for (uint64_t kk = threadIdx.x; kk < k0; kk += TPB) part = op(part, (int64_t)p0[kk * back]);
+    scan[threadIdx.x] = part;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) scan[threadIdx.x] = op(scan[threadIdx.x], scan[threadIdx.x + st]);
+      __syncthreads();
+    }
+  }
+  const int64_t carry = scan[0];
+  __syncthreads();
+  // Hillis-Steele segmented inclusive scan: lane t combines with lane t - d only while that lane is still inside
+  // the same group (head[t] = lanes back to the group's first lane in this block)
+  const uint32_t dist = (uint32_t)(k < (uint64_t)threadIdx.x ? k : threadIdx.x);
+  scan[threadIdx.x] = v;
+  head[threadIdx.x] = dist;
+  __syncthreads();
+  for (uint32_t d = 1; d < TPB; d <<= 1) {
+    int64_t add = 0;
+    const bool take = d <= dist;
+    if (take) add = scan[threadIdx.x - d];
+    __syncthreads();
+    if (take) scan[threadIdx.x] = op(scan[threadIdx.x], add);
+    __syncthreads();
+  }
+  if (on) {
+    // exclusive value: everything of the group before step k (inside the block, plus the carry for the straddling group)
+    const bool first_seg = k == k0 + threadIdx.x;  // this lane's group began before the block
+    int64_t acc;
+    if (k == 0) {
+      acc = MAX ? v : 0;
+    } else {
+      const bool has_prev = dist > 0;
+      const int64_t inside = has_prev ? scan[threadIdx.x - 1] : (MAX ? INT64_MIN : 0);
+      acc = first_seg ? (has_prev ? op(carry, inside) : carry) : inside;
+    }
+    const int64_t next = op(acc, v);
     const bool last_step = k + 1 == dim;
     uint32_t* t = tile + threadIdx.x * ST;
     t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = (uint32_t)g; t[3] = g + 1 == n_out ? 1u : 0u;

@@ -144,6 +144,21 @@ def check_device_linear_layer(ctx, n_out=20, dim=7, seed=2):
     assert np.array_equal(ctx.download(out, np.int32), groups.sum(axis=1))
     for buf in (dx, dw, db, mul_rows, prod, sum_rows, y1, add_rows, y, dt, rows, out):
         buf.free()
+    # reduction groups longer than a workgroup (the running value crosses block boundaries through the carry-in),
+    # groups that end exactly on a block boundary, and several short groups inside one block - sum and max
+    for front, dim2, back in ((2, 600, 3), (3, 256, 1), (5, 100, 2), (1, 1500, 1)):
+        t = rng.integers(-2000, 2000, size=(front, dim2, back)).astype(np.int32)
+        dt = ctx.upload(t.reshape(-1))
+        groups = t.transpose(0, 2, 1).reshape(front * back, dim2)
+        for maximum in (False, True):
+            rows, out = ctx.trace_sum_reduce(dt, front, dim2, back, node_id=21, input_id=20, num_consumers=1, maximum=maximum)
+            gen = syn.max_reduce_rows if maximum else syn.sum_reduce_rows
+            want_rows = gen(groups, node=21, input_id=20, input_mult=-1, out_mult=1)
+            assert np.array_equal(ctx.download(rows).reshape(front * back * dim2, 15 if maximum else 14), want_rows)
+            assert np.array_equal(ctx.download(out, np.int32), groups.max(axis=1) if maximum else groups.sum(axis=1))
+            rows.free()
+            out.free()
+        dt.free()
 
 
 def check_device_graph(lib, device=0):
