@@ -8,6 +8,7 @@ full single-proof sharding needs beyond it."""
 from __future__ import annotations
 
 import hashlib
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -31,7 +32,20 @@ def shard_context(ctx, group=None, fri_min_log: int = 0):
         ctx.set_shard_rccl(rank, world, bytes(ident.cpu().numpy().tobytes()), fri_min_log)
         return
 
+    device_memory = "emu" not in os.path.basename(ctx.lib.path)     # the emulation build's "device" memory is host memory
+
     def all_gather(buf, nbytes, _stream):
+        if device_memory:
+            # a transport that only speaks host memory (gloo) under the real library: stage this rank's part through
+            # the host on the prover's own stream (lmn_download / lmn_upload_to are stream-ordered and synchronous).
+            # This is the test path that runs several ranks on ONE GPU; production uses the RCCL transport above.
+            from .backend import DeviceBuffer
+            mine = ctx.download(DeviceBuffer(ctx, buf + rank * nbytes, nbytes, owned=False), np.uint8)
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(mine), group=group)
+            whole = np.concatenate([p_.numpy() for p_ in parts])
+            ctx.upload_to(DeviceBuffer(ctx, buf, nbytes * world, owned=False), whole)
+            return
         whole = np.ctypeslib.as_array((C.c_uint8 * (nbytes * world)).from_address(buf))
         t = torch.from_numpy(whole)
         parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]

@@ -137,3 +137,49 @@ def test_gpu_sharded_prove_single_rank_over_rccl(hip_lib_path):
         plain.close()
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_worker(rank, world, port, fri_min_log, lib_path, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from luminair_amd import backend, synthetic as syn
+    from luminair_amd.sharded import shard_context
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = backend.Library(lib_path)
+        ctx = backend.Context(0, None, lib)             # every rank on GPU 0: the sharded code paths, not the speed-up
+        shard_context(ctx, fri_min_log=fri_min_log)
+        out = []
+        for tabs in (syn.config2_add_only(1 << 15, 3), syn.config3_mixed(13, 12, 12, 4), syn.config5_linear_layers(4, 16, 32, 5)):
+            out.append(hashlib.sha256(ctx.prove_tables([(k, r, len(r)) for k, r in tabs])).hexdigest())
+        q.put((rank, out))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,fri_min_log", [(2, 6), (4, 0), (8, 7)])
+def test_gpu_sharded_prove_multi_rank_on_one_gpu(world, fri_min_log, hip_lib_path):
+    """The world > 1 code paths of the REAL library (row-block LDEs from `k_fft_top_block`, halo blocks of the last
+    logup group, row-offset constraint / quotient / fold kernels, owner-aware decommitment) on hardware: `world`
+    processes share GPU 0, the collective is the gloo-staged callback, and every rank must return the unsharded
+    proof's bytes."""
+    from luminair_amd import backend, synthetic as syn
+    plain = backend.Context(0, None, backend.Library(hip_lib_path))
+    want = [hashlib.sha256(plain.prove_tables([(k, r, len(r)) for k, r in tabs])).hexdigest()
+            for tabs in (syn.config2_add_only(1 << 15, 3), syn.config3_mixed(13, 12, 12, 4), syn.config5_linear_layers(4, 16, 32, 5))]
+    plain.close()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, fri_min_log, hip_lib_path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert out == want
