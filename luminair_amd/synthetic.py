@@ -200,11 +200,12 @@ def lut_lookup_rows(multiplicities, lut_len: int) -> np.ndarray:
     return m.reshape(-1, 1).astype(np.uint32)
 
 
-def activation_graph(n: int, seed: int = 42, names=("sin", "exp2", "log2")):
+def activation_graph(n: int, seed: int = 42, names=("sin", "exp2", "log2"), ranges=None):
     """y = f(a) for each LUT function in `names`, each on its own fresh input tensor.  Returns
-    (tables, luts): the trace tables in `gen_trace` order and the LUT columns the settings carry."""
+    (tables, luts): the trace tables in `gen_trace` order and the LUT columns the settings carry.
+    `ranges`: {name: (lo, hi)} fixed-point input range of each LUT (defaults: a few units wide, 2^14-2^16 rows)."""
     rng = np.random.default_rng(seed)
-    ranges = {"sin": (-4 * SCALE, 4 * SCALE), "exp2": (-2 * SCALE, 2 * SCALE), "log2": (1, 4 * SCALE)}
+    ranges = dict({"sin": (-4 * SCALE, 4 * SCALE), "exp2": (-2 * SCALE, 2 * SCALE), "log2": (1, 4 * SCALE)}, **(ranges or {}))
     tables, luts, inputs = [], {}, []
     for t, name in enumerate(names):
         lo, hi = ranges[name]

@@ -142,7 +142,7 @@ def test_emu_pinned_variant_with_inputs_component(root):
     lib.verify(got, backend.VARIANT_PINNED)
     # Sin / Exp2 / Log2 + their lookup components: two-column LUTs of different sizes in tree 0 (passed in as
     # settings data), width-2 LUT relations with three more element sets
-    tabs4, luts = syn.activation_graph(50, 8)
+    tabs4, luts = syn.activation_graph(50, 8, ranges={"sin": (-3000, 2500), "exp2": (-900, 1100), "log2": (1, 700)})
     got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs4], luts)
     assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs4], variant=ProtocolVariant.PINNED,
                                           luts=luts))
@@ -155,7 +155,7 @@ def test_emu_pinned_variant_with_inputs_component(root):
     assert e.value.code == backend.ERR_INVALID_LOGUP
     # the KAT era drew one LUT relation (sin): Sin + SinLookup fit its 8-slot claim
     kat_ctx = backend.Context(0, None, lib)
-    tabs5, luts5 = syn.activation_graph(20, 9, names=("sin",))
+    tabs5, luts5 = syn.activation_graph(20, 9, names=("sin",), ranges={"sin": (-800, 800)})
     tabs5 = [t for t in tabs5 if t[0] != 15]       # no Inputs component in the KAT era
     got = kat_ctx.prove_tables([(k, r, len(r)) for k, r in tabs5], luts5)
     assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs5], luts=luts5))

@@ -84,12 +84,12 @@ def test_lut_from_ranges_rejects_bad_input(lib):
 def test_prove_from_layout_settings_equals_prove_from_columns(lib):
     """`lmn_prove` fed by the reference's own settings form (ranges -> columns behind the boundary) gives the bytes
     of the same proof fed by pre-expanded LUT columns, and the verifier accepts it together with those settings."""
-    tabs, luts = syn.activation_graph(30, 4, names=("sin", "exp2"))
+    ranges = {"sin": (-700, 900), "exp2": (-300, 200)}        # small LUTs (2^11 and 2^9 rows): the emulation is slow
+    tabs, luts = syn.activation_graph(30, 4, names=("sin", "exp2"), ranges=ranges)
     cfg = lib.default_config()
     cfg.protocol_variant = backend.VARIANT_PINNED
     ctx = backend.Context(0, cfg, lib)
     want = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts)
-    ranges = {"sin": (-4 * 4096, 4 * 4096), "exp2": (-2 * 4096, 2 * 4096)}
     mult = {4: None, 10: None}
     for k, r in tabs:
         if k in mult:

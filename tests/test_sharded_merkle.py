@@ -23,7 +23,7 @@ def _free_port():
 def _columns():
     rng = np.random.default_rng(17)
     P = (1 << 31) - 1
-    return [rng.integers(0, P, size=1 << k, dtype=np.uint64).astype(np.uint32) for k in (9, 9, 7, 9, 4, 7, 12)]
+    return [rng.integers(0, P, size=1 << k, dtype=np.uint64).astype(np.uint32) for k in (9, 9, 7, 9, 4, 7, 10)]
 
 
 def _worker(rank, world, port, q):
@@ -75,7 +75,7 @@ def test_row_block_validation():
         row_block(cols, 0, 3)
     with pytest.raises(ValueError):
         row_block(cols, 0, 32)      # the 16-row column cannot be split 32 ways
-    assert [len(c) for c in row_block(cols, 1, 4)] == [128, 128, 32, 128, 4, 32, 1024]
+    assert [len(c) for c in row_block(cols, 1, 4)] == [128, 128, 32, 128, 4, 32, 256]
 
 
 @pytest.mark.gpu

@@ -28,7 +28,7 @@ def _cases():
     """(name, tables, luts, pinned variant?)"""
     sys.path.insert(0, ROOT)
     from luminair_amd import synthetic as syn
-    act, luts = syn.activation_graph(40, 8, names=("sin", "exp2"))
+    act, luts = syn.activation_graph(40, 8, names=("sin", "exp2"), ranges={"sin": (-500, 400), "exp2": (-100, 90)})
     return [
         ("2a-small", syn.config2_add_only(300, 1), None, False),
         ("config3-small", syn.config3_mixed(8, 7, 7, 2), None, False),
