@@ -150,6 +150,91 @@ __global__ void __launch_bounds__(1024) k_issue_blake_g(uint32_t* out, uint64_t*
   }
 }
 
+// the same quarter round with every v_add3_u32 split into two v_add_u32 (14 instructions, 10 of them full rate)
+__global__ void __launch_bounds__(1024) k_issue_blake_g_adds(uint32_t* out, uint64_t* cycles, int iters) {
+  uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  __syncthreads();
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        asm volatile(
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %4\n v_xor_b32 %3, %3, %0\n v_alignbit_b32 %3, %3, %3, 16\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_alignbit_b32 %1, %1, %1, 12\n"
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %5\n v_xor_b32 %3, %3, %0\n v_alignbit_b32 %3, %3, %3, 8\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_alignbit_b32 %1, %1, %1, 7\n"
+            : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]), "+v"(d[k])
+            : "v"(mx), "v"(my));
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+  if ((threadIdx.x & 63u) == 0) {
+    const uint64_t w = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    cycles[2 * w] = t1 - t0;
+    cycles[2 * w + 1] = r1 - r0;
+  }
+}
+
+// the same quarter round with every v_add3_u32 split into two v_add_u32 (14 instructions, 10 of them full rate)
+__global__ void __launch_bounds__(1024) k_issue_blake_g_allf(uint32_t* out, uint64_t* cycles, int iters) {
+  uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  uint32_t tmp = 0;
+  __syncthreads();
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        asm volatile(
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %4\n v_xor_b32 %3, %3, %0\n v_lshrrev_b32 %6, 16, %3\n v_lshlrev_b32 %3, 16, %3\n v_or_b32 %3, %3, %6\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_lshrrev_b32 %6, 12, %1\n v_lshlrev_b32 %1, 20, %1\n v_or_b32 %1, %1, %6\n"
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %5\n v_xor_b32 %3, %3, %0\n v_lshrrev_b32 %6, 8, %3\n v_lshlrev_b32 %3, 24, %3\n v_or_b32 %3, %3, %6\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_lshrrev_b32 %6, 7, %1\n v_lshlrev_b32 %1, 25, %1\n v_or_b32 %1, %1, %6\n"
+            : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]), "+v"(d[k])
+            : "v"(mx), "v"(my), "v"(tmp));
+      }
+    }
+  }
+  const uint64_t t1 = __builtin_readcyclecounter();
+  const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+  if ((threadIdx.x & 63u) == 0) {
+    const uint64_t w = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    cycles[2 * w] = t1 - t0;
+    cycles[2 * w + 1] = r1 - r0;
+  }
+}
+
 // two instruction kinds alternating over independent chains (is a mixed stream priced per class?)
 template <class OPA, class OPB>
 __global__ void __launch_bounds__(1024) k_issue_mix(uint32_t* out, uint64_t* cycles, int iters) {
@@ -349,6 +434,20 @@ int main(int argc, char** argv) {
                    (double)g_iters * 4 * 4 * 12, clk_hz, d_out, d_cyc);
     show(r, w);
   }
+  printf("\n%-14s", "blake2s_G adds");
+  for (int w : {1, 2, 4, 8}) {
+    Result r = run([&](int g, int t) { hipLaunchKernelGGL(k_issue_blake_g_adds, dim3(g), dim3(t), 0, 0, d_out, d_cyc, g_iters); }, w,
+                   (double)g_iters * 4 * 4 * 14, clk_hz, d_out, d_cyc);
+    show(r, w);
+  }
+  printf("  [14 instr per G: compare G-rounds/clk = value/14 with blake2s_G value/12]");
+  printf("\n%-14s", "blake2s_G allF");
+  for (int w : {1, 2, 4, 8}) {
+    Result r = run([&](int g, int t) { hipLaunchKernelGGL(k_issue_blake_g_allf, dim3(g), dim3(t), 0, 0, d_out, d_cyc, g_iters); }, w,
+                   (double)g_iters * 4 * 4 * 22, clk_hz, d_out, d_cyc);
+    show(r, w);
+  }
+  printf("  [22 instr per G]");
   printf("\n%-14s", "blake2s_G x4il");
   for (int w : {1, 2, 4, 8}) {
     Result r = run([&](int g, int t) { hipLaunchKernelGGL(k_issue_blake_g4, dim3(g), dim3(t), 0, 0, d_out, d_cyc, g_iters); }, w,
