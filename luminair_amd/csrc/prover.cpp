@@ -166,6 +166,7 @@ static EventLog* g_log(Context* c) { return static_cast<EventLog*>(c->event_log)
 
 // ------------------------------------------------------------------------------------ context
 static void rccl_release(void* transport);  // single-proof sharding section below
+static void release_host_scratch(void* p);  // decommit-planning storage, defined with HostScratch
 void rccl_unique_id(uint8_t* out);
 
 Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
@@ -205,6 +206,8 @@ Context::~Context() {
 #endif
   delete static_cast<EventLog*>(event_log);
   event_log = nullptr;
+  release_host_scratch(host_scratch);
+  host_scratch = nullptr;
   if (shard_.rccl) rccl_release(shard_.rccl);
   shard_.rccl = nullptr;
   for (void* p : tw_allocs_) lmn_dev_free(p);
@@ -801,6 +804,34 @@ static Ref node_ref(const DevMerkle& m, int layer, uint64_t node) {
   const int sh = layer - m.g;
   return {m.layers[layer] + (node & ((1ull << sh) - 1)) * 8, 8, (int)(node >> sh)};
 }
+
+// Decommitment plan of one tree / FRI layer, and the per-context scratch that keeps the plans' storage alive across
+// proofs (the planning runs on the host between the last FRI sync and the gather launch, i.e. on the critical
+// path of the proof's latency: no allocations there after the first proof).
+struct DecommitPlan {
+  std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
+  void clear() {
+    fri_wit.clear();
+    queried.clear();
+    hash_wit.clear();
+    col_wit.clear();
+  }
+};
+struct HostScratch {
+  std::vector<DecommitPlan> plans;
+  size_t used = 0;
+  std::vector<GatherEntry> entries;
+  std::vector<std::pair<int, uint32_t>> runs;
+  std::vector<ColRef> cols;
+  DecommitPlan& next() {
+    if (used == plans.size()) plans.emplace_back();
+    DecommitPlan& p = plans[used++];
+    p.clear();
+    return p;
+  }
+};
+
+static void release_host_scratch(void* p) { delete static_cast<HostScratch*>(p); }
 
 // MerkleProver::decommit: emits device references in output order
 static void plan_merkle_decommit(const DevMerkle& m, const std::vector<ColRef>& cols_sorted, int g,
@@ -1666,19 +1697,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // ---- decommitment: plan device references, gather once, distribute
   {
     StageTimer st(this, log, stream_, C_DECOMMIT);
-    struct Plan {
-      std::vector<Ref> fri_wit, queried, hash_wit, col_wit;
-      Plan() {  // small reserves only: large ones cost more in page faults than the regrowth they avoid
-        fri_wit.reserve(16);
-        queried.reserve(32);
-        hash_wit.reserve(64);
-        col_wit.reserve(32);
-      }
-    };
-    std::vector<Plan> plans;  // [first, inner..., tree0..3]
-    plans.reserve(inner.size() + 5);
+    typedef DecommitPlan Plan;
+    if (!host_scratch) host_scratch = new HostScratch();
+    HostScratch& hs = *static_cast<HostScratch*>(host_scratch);
+    hs.used = 0;
+    hs.plans.reserve(inner.size() + 5);  // plans are handed out by reference: no reallocation while planning
+    std::vector<Plan>& plans = hs.plans;  // [first, inner..., tree0..3]
     {
-      Plan p;
+      Plan& p = hs.next();
       std::map<int, std::vector<uint32_t>> dec;
       for (size_t qk = 0; qk < quots.size(); ++qk) {
         const ColRef(&c4)[4] = *reinterpret_cast<const ColRef(*)[4]>(&first_cols[4 * qk]);
@@ -1686,24 +1712,24 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       }
       std::vector<Ref> dummy;
       plan_merkle_decommit(first_merkle, first_cols, g, dec, dummy, p.hash_wit, p.col_wit);
-      plans.push_back(std::move(p));
     }
     std::vector<uint32_t> lq = fold_positions(queries, 1);
     for (auto& fl : inner) {
-      Plan p;
+      Plan& p = hs.next();
       std::map<int, std::vector<uint32_t>> dec;
-      std::vector<ColRef> lc;
+      std::vector<ColRef>& lc = hs.cols;
+      lc.clear();
       secure_cols(fl.vals, fl.log, fl.sharded, lc);
       const ColRef(&c4)[4] = *reinterpret_cast<const ColRef(*)[4]>(lc.data());
       plan_fri_witness(c4, g, lq, dec[fl.log], p.fri_wit);
       std::vector<Ref> dummy;
       plan_merkle_decommit(fl.merkle, lc, g, dec, dummy, p.hash_wit, p.col_wit);
-      plans.push_back(std::move(p));
       lq = fold_positions(lq, 1);
     }
     for (auto* t : trees) {
-      Plan p;
-      std::vector<ColRef> sorted;
+      Plan& p = hs.next();
+      std::vector<ColRef>& sorted = hs.cols;
+      sorted.clear();
       std::map<int, std::vector<uint32_t>> qmap;
       sorted.reserve(t->cols.size());
       for (auto& c : t->cols) {
@@ -1712,13 +1738,13 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       }
       std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
       plan_merkle_decommit(t->merkle, sorted, g, qmap, p.queried, p.hash_wit, p.col_wit);
-      plans.push_back(std::move(p));
     }
     // Every rank plans the same list; it fetches the runs it holds into its own slot of the output buffer, the
     // slots are all-gathered (a few KB per rank) and each run is then read from its owner's slot.
-    std::vector<GatherEntry> entries;
-    entries.reserve(1024);
-    std::vector<std::pair<int, uint32_t>> runs;  // (owner, len) in output order
+    std::vector<GatherEntry>& entries = hs.entries;
+    entries.clear();
+    std::vector<std::pair<int, uint32_t>>& runs = hs.runs;  // (owner, len) in output order
+    runs.clear();
     uint32_t out_words = 0;
     auto add_refs = [&](const std::vector<Ref>& refs) {
       for (auto& r : refs) {
@@ -1727,7 +1753,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         out_words += r.len;
       }
     };
-    for (auto& p : plans) {
+    for (size_t k = 0; k < hs.used; ++k) {
+      Plan& p = plans[k];
       add_refs(p.fri_wit);
       add_refs(p.queried);
       add_refs(p.hash_wit);

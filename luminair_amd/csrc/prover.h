@@ -180,6 +180,7 @@ class Context {
   lmn_timings timings{};
   bool profiling = false;  // record HIP events around stages/kernels (lmn_set_profiling)
   void* event_log = nullptr;  // EventLog (prover.cpp)
+  void* host_scratch = nullptr;  // HostScratch (prover.cpp): decommit-planning storage reused across proofs
   std::string last_error;
 
  private:
