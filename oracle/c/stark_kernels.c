@@ -97,7 +97,10 @@ static const qm QZERO = {0, 0, 0, 0};
 /* A loop goes parallel only when every thread of the (full) team gets at least 2^12 work units: waking a 256-thread
  * team for a 2^12-point loop costs more than the loop itself.  (Always the full team or none: libgomp tears threads
  * down and re-creates them when consecutive regions ask for different team sizes.) */
-static inline int par_ok(long work) { return work >= ((long)omp_get_max_threads() << 12); }
+static inline int par_ok(long work) {
+  const long per_team = (long)omp_get_max_threads() << 12;
+  return work >= (per_team > (1L << 18) ? per_team : (1L << 18));
+}
 
 static inline void bfly_fwd(u32* lo, u32* hi, u32 w) {
   u32 x = mmul(*hi, w), a = *lo;
