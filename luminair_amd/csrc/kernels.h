@@ -159,7 +159,6 @@ struct CompositionArgs {
   const uint32_t* prev_last;   // last 4 interaction columns where the mask offset -1 reads them (other row blocks)
   uint32_t* out;               // 4 coordinate columns, stride 2^eval_log
   int accumulate;              // out += instead of out =
-  int zero_slot;               // 1: Mul's second eval_fixed_mul slot contributes zero (KAT form)
   QM31 z, alpha;               // NodeElements
   QM31 z2, alpha2;             // the component's LUT element set (range check / sin / exp2 / log2)
   const uint32_t* pre;         // preprocessed columns on the eval domain (lookup components)

@@ -105,3 +105,29 @@ def test_prove_from_layout_settings_equals_prove_from_columns(lib):
     with pytest.raises(luminair_amd.LuminairError):
         luminair_amd.verify(luminair_amd.LuminairProof(got), wrong, backend.VARIANT_PINNED, library=lib)
     ctx.close()
+
+
+def test_proof_json_round_trip(kat_bytes, lib):
+    """`LuminairProof::to_json / from_json` mirror (crates/prover/src/lib.rs:62-106): the reference's known-answer
+    proof (KAT-era 8-slot claim) and a HEAD-layout proof survive bincode -> JSON -> bincode unchanged."""
+    p = luminair_amd.LuminairProof(kat_bytes)
+    d = json.loads(p.to_json())
+    assert list(d["claim"]) == ["add", "mul", "recip", "sin", "sin_lookup", "sum_reduce", "max_reduce", "sqrt"]
+    assert d["claim"]["add"] == {"log_size": 4} and d["claim"]["recip"] is None
+    assert d["proof"]["config"] == {"pow_bits": 5, "fri_config": {"log_blowup_factor": 1, "log_last_layer_degree_bound": 0,
+                                                                   "n_queries": 3}}
+    assert len(d["proof"]["commitments"]) == 4 and len(d["proof"]["commitments"][0]) == 32
+    assert luminair_amd.LuminairProof.from_json(p.to_json()).to_bincode() == kat_bytes
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    tabs = syn.config2_graph_faithful(40, 3)
+    head = luminair_amd.LuminairProof(ctx.prove_tables([(k, r, len(r)) for k, r in tabs]))
+    dh = head.to_dict()
+    assert len(dh["claim"]) == 17 and dh["claim"]["inputs"] is not None
+    assert luminair_amd.LuminairProof.from_json(head.to_json()).to_bincode() == head.to_bincode()
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.LuminairProof.from_json('{"claim": {}}')
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.LuminairProof(kat_bytes[:-1]).to_json()
+    ctx.close()
