@@ -97,7 +97,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_op_evaluate_block",
+           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
            "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
            "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
@@ -156,6 +156,7 @@ class Library:
         lib.lmn_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.lmn_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_upload_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.lmn_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_lut_log_size.argtypes = [C.POINTER(LmnRange), C.c_uint32, C.POINTER(C.c_uint32)]
         lib.lmn_lut_from_ranges.argtypes = [C.c_uint32, C.POINTER(LmnRange), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         VP, U32 = C.c_void_p, C.c_uint32
@@ -515,6 +516,10 @@ class Context:
             raise ValueError("destination too small")
         self._check(self.lib.lib.lmn_upload_to(self.handle, arr.ctypes.data, arr.nbytes, buf.ptr))
         return buf
+
+    def device_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        """Stream-ordered device-to-device copy (returns without waiting)."""
+        self._check(self.lib.lib.lmn_device_copy(self.handle, dst_ptr, src_ptr, nbytes))
 
     def download(self, buf: DeviceBuffer, dtype=np.uint32) -> np.ndarray:
         host = np.empty(buf.nbytes // np.dtype(dtype).itemsize, dtype=dtype)

@@ -338,6 +338,11 @@ int lmn_lut_from_ranges(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_r
   return LMN_OK;
 }
 
+int lmn_device_copy(lmn_ctx* ctx, void* device_dst, const void* device_src, size_t bytes) {
+  if (!ctx || !device_dst || !device_src) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->device_copy(device_dst, device_src, bytes); });
+}
+
 int lmn_upload_to(lmn_ctx* ctx, const void* host, size_t bytes, void* device_dst) {
   if (!ctx || !host || !device_dst) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] { ctx->impl->upload_to(host, bytes, device_dst); });

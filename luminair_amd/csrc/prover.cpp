@@ -265,6 +265,12 @@ void Context::upload_to(const void* host, size_t bytes, void* dst) {
   lmn_h2d(dst, host, bytes, stream_);
   lmn_sync(stream_);  // the host buffer is borrowed only for the duration of the call
 }
+void Context::device_copy(void* dst, const void* src, size_t bytes) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  lmn_d2d(dst, src, bytes, stream_);  // stream-ordered, no wait
+}
 void Context::download(const void* device, void* host, size_t bytes) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
@@ -1003,6 +1009,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   int max_log = 0;
   int prev_kind = -1;
   size_t words = 0;
+  // a sharded context holds only its row block of every LDE / Merkle layer / large FRI layer
+  const int size_g = shard_.active ? shard_.g : 0;
+  auto row_split = [&](uint64_t w) { return size_g ? (w >> size_g) + 8192 : w; };
   for (size_t t = 0; t < n_tables; ++t) {
     const lmn_table& tb = tables[t];
     const ComponentSpec* sp = component_spec((int)tb.kind);
@@ -1023,18 +1032,19 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     infos.push_back({sp, tb.n_rows, ls, tb.rows, (tb.flags & LMN_TABLE_ROWS_ON_DEVICE) != 0});
     max_log = std::max(max_log, ls);
     uint64_t cells = (uint64_t)(sp->n_cols + 4 * sp->n_rel) << ls;
-    words += cells * (2 + (1ull << lb));                       // evals + coeffs + lde
+    words += cells * 2 + row_split(cells << lb);               // evals + coeffs + lde (this rank's row block)
     if (!infos.back().on_device) words += tb.n_rows * sp->n_cols;  // staging
-    words += (uint64_t)sp->n_pre * (4ull << ls);               // preprocessed columns: evals + coeffs + lde
+    words += (uint64_t)sp->n_pre * ((2ull << ls) + row_split(2ull << ls));  // preprocessed columns: evals + coeffs + lde
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
     if (shard_.active) words += (4ull << (ls + 1)) + 4096;     // halo rows of the last logup column group
   }
   const int comp_log = max_log + 1;
   const int max_lde = comp_log + lb;
-  words += (4ull << comp_log) * 2 + (4ull << max_lde);         // composition values/coeffs + lde
-  words += (4ull << max_lde) * 3;                              // quotient columns (all sizes) + fri layers
-  words += 7 * (16ull << max_lde);                             // merkle trees (4 trace + fri first + inner)
+  words += (4ull << comp_log) * 2 + row_split(4ull << max_lde);  // composition values/coeffs + lde
+  words += row_split((4ull << max_lde) * 3);                   // quotient columns (all sizes) + fri layers
+  words += row_split(7 * (16ull << max_lde));                  // merkle trees (4 trace + fri first + inner)
+  if (shard_.active) words += 64ull << std::min(max_lde, std::max(shard_.fri_min_log, 12) + 2);  // replicated small FRI layers + their trees
   words += (16u << 20);                                        // slack: tables, partials, gather buffers
   ensure_twiddles(max_lde);
   arena_.reserve(words * 4);

@@ -165,6 +165,7 @@ class Context {
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
   void upload_to(const void* host, size_t bytes, void* dst);
+  void device_copy(void* dst, const void* src, size_t bytes);
   void download(const void* device, void* host, size_t bytes);
   void trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,
                     const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out);
