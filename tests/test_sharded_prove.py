@@ -1,4 +1,4 @@
-"""Single-proof sharding (BASELINE configs 4/5): `lmn_prove` on world-2 and world-4 process groups
+"""Single-proof sharding (BASELINE configs 4/5): `lmn_prove` on world-2, world-4 and world-8 process groups
 (gloo, the TEST-ONLY emulation build, the `lmn_collective` callback as transport) must return, on every rank, exactly
 the bytes an unsharded context produces - for one table, mixed-size tables, a config-5-shaped pie and a pie with
 lookups, with the FRI sharding threshold low enough that split layers, the split -> replicated transition and the
@@ -30,6 +30,7 @@ def _cases():
     from luminair_amd import synthetic as syn
     act, luts = syn.activation_graph(40, 8, names=("sin", "exp2"), ranges={"sin": (-500, 400), "exp2": (-100, 90)})
     return [
+        ("examples/simple (16-row tables: 4-row blocks at world 8)", syn.simple_example(), None, False),
         ("2a-small", syn.config2_add_only(300, 1), None, False),
         ("config3-small", syn.config3_mixed(8, 7, 7, 2), None, False),
         ("mixed-sizes", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])], None, False),
@@ -90,7 +91,7 @@ def single_rank_proofs():
     return _single()
 
 
-@pytest.mark.parametrize("world,fri_min_log", [(2, 4), (4, 5), (2, 0)])
+@pytest.mark.parametrize("world,fri_min_log", [(2, 4), (4, 5), (8, 0)])
 def test_sharded_prove_is_byte_identical(world, fri_min_log, single_rank_proofs):
     port = _free_port()
     ctx = mp.get_context("spawn")
