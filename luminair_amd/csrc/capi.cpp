@@ -253,7 +253,10 @@ void rccl_unique_id(uint8_t* out);
 }
 int lmn_ctx_set_shard(lmn_ctx* ctx, uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
   if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
-  return guard(ctx, [&] { ctx->impl->set_shard(rank, world, fri_min_log, coll); });
+  return guard(ctx, [&] {
+    ctx->impl->clear_shard();  // releases a previous built-in RCCL transport, if any
+    ctx->impl->set_shard(rank, world, fri_min_log, coll);
+  });
 }
 int lmn_rccl_unique_id(uint8_t id_out[LMN_RCCL_ID_BYTES]) {
   if (!id_out) return LMN_ERR_INVALID_ARGUMENT;

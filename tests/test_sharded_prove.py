@@ -140,6 +140,31 @@ def test_gpu_sharded_prove_single_rank_over_rccl(hip_lib_path):
         dist.destroy_process_group()
 
 
+def _gpu_cases():
+    """(tables, luts, pinned variant?): sizes where every kernel family of the big workloads runs, plus BASELINE
+    config 4 (the black-scholes MLP shape with its exp2 LUT in tree 0), which north_star shards over 4 GPUs."""
+    from luminair_amd import synthetic as syn
+    c4, luts4 = syn.config4_black_scholes_shape()
+    return [(syn.config2_add_only(1 << 15, 3), None, False), (syn.config3_mixed(13, 12, 12, 4), None, False),
+            (syn.config5_linear_layers(4, 16, 32, 5), None, False), (c4, luts4, True)]
+
+
+def _gpu_prove_all(lib, shard=None):
+    from luminair_amd import backend
+    out, ctxs = [], {}
+    for tabs, luts, pinned in _gpu_cases():
+        if pinned not in ctxs:
+            cfg = lib.default_config()
+            cfg.protocol_variant = backend.VARIANT_PINNED if pinned else backend.VARIANT_KAT
+            ctxs[pinned] = backend.Context(0, cfg, lib)
+            if shard:
+                shard(ctxs[pinned])
+        out.append(hashlib.sha256(ctxs[pinned].prove_tables([(k, r, len(r)) for k, r in tabs], luts)).hexdigest())
+    for c in ctxs.values():
+        c.close()
+    return out
+
+
 def _gpu_worker(rank, world, port, fri_min_log, lib_path, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -148,14 +173,8 @@ def _gpu_worker(rank, world, port, fri_min_log, lib_path, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lib = backend.Library(lib_path)
-        ctx = backend.Context(0, None, lib)             # every rank on GPU 0: the sharded code paths, not the speed-up
-        shard_context(ctx, fri_min_log=fri_min_log)
-        out = []
-        for tabs in (syn.config2_add_only(1 << 15, 3), syn.config3_mixed(13, 12, 12, 4), syn.config5_linear_layers(4, 16, 32, 5)):
-            out.append(hashlib.sha256(ctx.prove_tables([(k, r, len(r)) for k, r in tabs])).hexdigest())
-        q.put((rank, out))
-        ctx.close()
+        # every rank on GPU 0: the sharded code paths, not the speed-up
+        q.put((rank, _gpu_prove_all(backend.Library(lib_path), lambda c: shard_context(c, fri_min_log=fri_min_log))))
     finally:
         dist.destroy_process_group()
 
@@ -167,11 +186,8 @@ def test_gpu_sharded_prove_multi_rank_on_one_gpu(world, fri_min_log, hip_lib_pat
     logup group, row-offset constraint / quotient / fold kernels, owner-aware decommitment) on hardware: `world`
     processes share GPU 0, the collective is the gloo-staged callback, and every rank must return the unsharded
     proof's bytes."""
-    from luminair_amd import backend, synthetic as syn
-    plain = backend.Context(0, None, backend.Library(hip_lib_path))
-    want = [hashlib.sha256(plain.prove_tables([(k, r, len(r)) for k, r in tabs])).hexdigest()
-            for tabs in (syn.config2_add_only(1 << 15, 3), syn.config3_mixed(13, 12, 12, 4), syn.config5_linear_layers(4, 16, 32, 5))]
-    plain.close()
+    from luminair_amd import backend
+    want = _gpu_prove_all(backend.Library(hip_lib_path))
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
