@@ -71,8 +71,18 @@ struct MerkleSegs {
 struct MerkleLevels {
   uint32_t* p[MERKLE_MAX_FUSED + 1];  // p[0] = start level output, p[l] = l levels above it
 };
+// FRI layers: the leaves of a layer's tree are the fold of the previous layer.  With `fold` given, the start level
+// computes leaf i = fold(src[2i], src[2i+1]) itself (FriOps::fold_line / fold_circle_into_line without an
+// accumulator), writes it to dst (the layer's 4 coordinate columns, which later steps read) and hashes it - one
+// launch and one pass over the layer less than fold kernel + leaf hashing.
+struct MerkleFold {
+  const uint32_t* src;   // previous layer / quotient column: 4 coordinate columns of 2*size words, stride 2*size
+  const uint32_t* itw;   // inverse twiddles of the fold (one per leaf)
+  const QM31* alpha;     // device: the folding randomness drawn by the previous layer's channel step
+  uint32_t* dst;         // this layer: 4 coordinate columns of `size` words, stride `size`
+};
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s);
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold = nullptr);
 // one block, size <= 1024 start nodes, nfused <= 10
 // If `ch` is given and this launch reaches the root, it also mixes the root into the device channel
 // and draws the next felt (saves a launch per FRI layer).

@@ -1036,8 +1036,26 @@ LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, i
 // drop the run selection and the multi-block loop from the hot loop.
 template <int MODE>
 LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                            uint32_t i, uint32_t m[16]) {
-  if (MODE == 1) {
+                            uint32_t i, uint32_t m[16], const MerkleFold& fold = MerkleFold{}) {
+  if (MODE == 3) {
+    // leaf i of a FRI layer = fold of the pair (2i, 2i+1) of the previous layer (same arithmetic as k_fold)
+    const uint64_t L = 2ull * size;
+    const uint32_t* __restrict__ sp = fold.src + 2ull * i;
+    const QM31 a{sp[0], sp[L], sp[2 * L], sp[3 * L]};
+    const QM31 b{sp[1], sp[L + 1], sp[2 * L + 1], sp[3 * L + 1]};
+    const QM31 r = q_add(q_add(a, b), q_mul(*fold.alpha, q_mul_m(q_sub(a, b), fold.itw[i])));
+    uint32_t* __restrict__ o = fold.dst + i;
+    o[0] = r.a;
+    o[(uint64_t)size] = r.b;
+    o[2ull * size] = r.c;
+    o[3ull * size] = r.d;
+    m[0] = r.a;
+    m[1] = r.b;
+    m[2] = r.c;
+    m[3] = r.d;
+#pragma unroll
+    for (int k = 4; k < 16; ++k) m[k] = 0u;
+  } else if (MODE == 1) {
     const uint32_t* __restrict__ base = sg.base[0] + i;
 #pragma unroll
     for (int k = 0; k < 16; ++k) m[k] = k < ncols ? base[(uint64_t)k * size] : 0u;
@@ -1055,7 +1073,10 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
 template <int MODE>
 LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
                             uint32_t i, uint32_t m[16], uint32_t h[8]) {
-  if (MODE == 1) {
+  if (MODE == 3) {
+    b2_init(h);
+    b2_compress(h, m, 16u, 0xffffffffu);
+  } else if (MODE == 1) {
     b2_init(h);
     b2_compress(h, m, 4u * (uint32_t)ncols, 0xffffffffu);
   } else if (MODE == 2) {
@@ -1068,7 +1089,7 @@ LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
 
 template <int MODE>
 LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
-                          MerkleLevels outs, int sub, int nfused) {
+                          MerkleLevels outs, int sub, int nfused, MerkleFold fold) {
   // Wave-cooperative subtree: in batch j lane l hashes start node W0 + 64*j + l (coalesced column
   // loads and hash stores).  Siblings sit in neighbouring lanes, so after every second batch the
   // lanes swap one hash with lane^1 and ALL 64 lanes compress one level-1 parent (even lanes for the
@@ -1083,7 +1104,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   uint32_t cur[8];
   uint32_t cur_idx = 0;
   uint32_t mnext[16];
-  merkle_load_mode<MODE>(prev, sg, ncols, size, W0 + lane, mnext);
+  merkle_load_mode<MODE>(prev, sg, ncols, size, W0 + lane, mnext, fold);
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
@@ -1092,7 +1113,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     uint32_t mcur[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) mcur[k] = mnext[k];
-    if (j + 1 < per) merkle_load_mode<MODE>(prev, sg, ncols, size, node + 64u, mnext);
+    if (j + 1 < per) merkle_load_mode<MODE>(prev, sg, ncols, size, node + 64u, mnext, fold);
     merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mcur, cur);
     store_hash(outs.p[0] + (uint64_t)node * 8, cur);
     uint32_t jj = j;
@@ -1254,18 +1275,22 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 }
 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s) {
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold) {
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
   if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
       size % ((uint32_t)TPB << sub) != 0)
     throw LmnError(-100, "merkle_fused: bad arguments");
   const dim3 g(cdiv(size >> sub, TPB)), b(TPB);
-  if (!prev && ncols <= 16 && sg.n[0] == ncols)
-    LMN_LAUNCH(k_merkle_fused<1>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
+  const MerkleFold none{};
+  if (fold) {
+    if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
+    LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+  } else if (!prev && ncols <= 16 && sg.n[0] == ncols)
+    LMN_LAUNCH(k_merkle_fused<1>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
   else if (prev && ncols == 0)
-    LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
+    LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
   else
-    LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused);
+    LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
 }
 
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,

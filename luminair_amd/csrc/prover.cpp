@@ -455,8 +455,10 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
 // columns) plus up to 8 following levels that have no columns of their own.
 void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                                   const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch,
-                                  QM31* alpha_out, uint32_t* root_copy) {
+                                  QM31* alpha_out, uint32_t* root_copy, const MerkleFold* fold) {
   bool chan_done = false;
+  if (fold && (max_log <= 10 || per_level[max_log].size() != 4))
+    throw LmnError(LMN_ERR_INTERNAL, "merkle: a folded leaf level needs a 4-column tree of more than 2^10 leaves");
   {
     StageTimer t(this, g_log(this), stream_, C_MERKLE);
     const uint32_t* prev = nullptr;
@@ -506,7 +508,8 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         nfused = std::min(nfused, sub + 8);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = layers[level - l];
         StageTimer tf(this, g_log(this), stream_, C_MERKLE_FUSED);
-        launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_);
+        launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_,
+                            level == max_log ? fold : nullptr);
         timings.merkle_fused_launches++;
         uint64_t words = (prev ? 16 : 0) + lc.size();
         timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
@@ -532,7 +535,8 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
 }
 
 void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch, QM31* alpha_out,
-                           uint32_t* root_copy, bool sharded) {
+                           uint32_t* root_copy, bool sharded, const MerkleFold* fold) {
+  if (fold && sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: folded leaf levels are not sharded");
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].log;
   m.layers.assign(m.max_log + 1, nullptr);
   m.g = 0;
@@ -547,7 +551,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
       if (c.sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: sharded column in a replicated tree");
       per_level[c.log].push_back(c.ptr);
     }
-    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy);
+    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy, fold);
     return;
   }
   // Sharded tree (SURVEY.md §8e stage C/D): the aligned block of rows [rank * 2^(k-g), (rank+1) * 2^(k-g)) of every
@@ -1555,10 +1559,31 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     int layer_log = ls0 - 1;
     bool lay_sh = sharded_log(layer_log);
     uint32_t* layer = layer_alloc(layer_log, lay_sh);
-    fold(true, layer, lay_sh, quots[0].vals, ls0, quots[0].sharded, d_alphas + (n_roots - 1), 0);
-    if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
+    // Unsharded proofs leave the fold that produces a layer PENDING, so that the layer's own leaf hashing can
+    // compute it (MerkleFold): one launch and one pass over the layer less.  It is materialised by the plain fold
+    // kernel instead whenever something else needs the values first (a quotient column that joins the layer, the
+    // single-block FRI tail, a layer too small for the fused kernel).
+    struct PendingFold {
+      bool on = false, circle = false;
+      const uint32_t* src = nullptr;
+      int src_log = 0;
+      const QM31* alpha = nullptr;
+    } pend;
+    auto materialise = [&](uint32_t* dst) {
+      if (!pend.on) return;
+      fold(pend.circle, dst, false, pend.src, pend.src_log, false, pend.alpha, 0);
+      pend.on = false;
+    };
+    static const bool fuse_folds = getenv("LMN_NO_FOLD_FUSION") == nullptr;
+    if (!sh && fuse_folds) {
+      pend = {true, true, quots[0].vals, ls0, d_alphas + (n_roots - 1)};
+    } else {
+      fold(true, layer, lay_sh, quots[0].vals, ls0, quots[0].sharded, d_alphas + (n_roots - 1), 0);
+      if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
+    }
     size_t qi = 1;
     while (layer_log > last_size_log) {
+      if (pend.on && layer_log <= 10) materialise(layer);
       if (!lay_sh && layer_log <= 10 && qi == quots.size()) {
         // all remaining layers fit one block: commit + fold them in a single launch
         int n_tail = layer_log - last_size_log;
@@ -1596,13 +1621,24 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       fl.sharded = lay_sh;
       std::vector<ColRef> lc;
       secure_cols(layer, layer_log, lay_sh, lc);
-      build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, lay_sh);
+      if (pend.on) {
+        const MerkleFold mf{pend.src, pend.circle ? itwY_[pend.src_log] : itwX_[pend.src_log + 1], pend.alpha, layer};
+        build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, false, &mf);
+        pend.on = false;
+      } else {
+        build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, lay_sh);
+      }
       ++n_roots;
       const QM31* d_alpha = d_alphas + (n_roots - 1);
       const int next_log = layer_log - 1;
       const bool next_sh = sharded_log(next_log);
       uint32_t* next = layer_alloc(next_log, next_sh);
-      fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
+      const bool joins = qi < quots.size() && quots[qi].log - 1 == next_log;
+      if (!sh && fuse_folds && !joins && next_log > 10) {
+        pend = {true, false, layer, layer_log, d_alpha};
+      } else {
+        fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
+      }
       inner.push_back(fl);
       while (qi < quots.size() && quots[qi].log - 1 == next_log) {
         fold(true, next, next_sh, quots[qi].vals, quots[qi].log, quots[qi].sharded, d_alpha, 1);
@@ -1614,6 +1650,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       layer_log = next_log;
       lay_sh = next_sh;
     }
+    materialise(layer);  // a last layer larger than the fused threshold (log_last_layer > 9) is still pending
     hm.mark("fri enqueued");
     // one sync: roots + alphas back, then replay the transcript on the host channel
     const uint32_t* h_roots = (const uint32_t*)stage_download(d_roots, (size_t)n_roots * 32);

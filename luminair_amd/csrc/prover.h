@@ -192,11 +192,14 @@ class Context {
   void lde_and_merkle(DevTree& tree);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its
   // row block, the subtree roots are all-gathered and the top log2(world) levels are hashed on every rank.
+  // `fold` (unsharded FRI layers of more than 2^10 rows only): the leaf level computes the layer as the fold of the
+  // previous one while hashing it (MerkleFold, kernels.h); cols_sorted then names the 4 columns it writes.
   void build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch = nullptr,
-                    QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr, bool sharded = false);
+                    QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr, bool sharded = false,
+                    const MerkleFold* fold = nullptr);
   void build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                            const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch, QM31* alpha_out,
-                           uint32_t* root_copy);
+                           uint32_t* root_copy, const MerkleFold* fold = nullptr);
   // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
   void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);

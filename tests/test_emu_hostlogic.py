@@ -41,6 +41,10 @@ def test_emu_reproduces_kat(emu_ctx, kat_bytes):
     ("single-row", syn.chain_graph(1, 6)),
     ("linear-layer+max", syn.linear_layer(20, 7, 2, True)),
     ("config5-3-layers", syn.config5_linear_layers(3, 4, 5, 8)),
+    # FRI layers above 2^10 rows: the leaf hashing computes the fold itself (MerkleFold), except where a smaller
+    # quotient column joins the layer
+    ("add-2^11 (fold fused into leaf hashing)", syn.config2_add_only(1 << 11, 5)),
+    ("mixed 2^11 + 2^10 (fused and plain folds)", [(0, syn.chain_graph(2000, 4)[0][1]), (1, syn.chain_graph(1000, 5)[1][1])]),
 ])
 def test_emu_matches_oracle(emu_ctx, name, tabs):
     got, want = _both(emu_ctx, tabs)
