@@ -511,6 +511,8 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_,
                             level == max_log ? fold : nullptr);
         timings.merkle_fused_launches++;
+        // a folded leaf level also reads the pair it folds (32 B) and writes the layer (16 B) instead of reading it (16 B)
+        if (fold && level == max_log) timings.merkle_fused_bytes += ((uint64_t)1 << level) * 32ull;
         uint64_t words = (prev ? 16 : 0) + lc.size();
         timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
         timings.merkle_fused_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
