@@ -35,18 +35,35 @@ static lmn_col* new_col(uint32_t ncols, uint32_t log_size) {
   return c;
 }
 
+// frees a freshly allocated handle when the op that fills it throws
+struct ColGuard {
+  lmn_col* c;
+  explicit ColGuard(lmn_col* c_) : c(c_) {}
+  ~ColGuard() {
+    if (c) {
+      lmn_dev_free(c->d);
+      delete c;
+    }
+  }
+  lmn_col* release() {
+    lmn_col* r = c;
+    c = nullptr;
+    return r;
+  }
+};
+
 lmn_col* Context::col_alloc(uint32_t ncols, uint32_t log_size, bool zero) {
   set_device();
-  lmn_col* c = new_col(ncols, log_size);
-  if (zero) lmn_memset(c->d, 0, c->words() * 4, stream_);
-  return c;
+  ColGuard c(new_col(ncols, log_size));
+  if (zero) lmn_memset(c.c->d, 0, c.c->words() * 4, stream_);
+  return c.release();
 }
 lmn_col* Context::col_from_cpu(const uint32_t* host, uint32_t ncols, uint32_t log_size) {
   set_device();
-  lmn_col* c = new_col(ncols, log_size);
-  lmn_h2d(c->d, host, c->words() * 4, stream_);
+  ColGuard c(new_col(ncols, log_size));
+  lmn_h2d(c.c->d, host, c.c->words() * 4, stream_);
   lmn_sync(stream_);  // the host buffer is borrowed only for the duration of the call
-  return c;
+  return c.release();
 }
 void Context::col_to_cpu(const lmn_col* c, uint32_t* host) {
   set_device();
@@ -111,9 +128,9 @@ lmn_col* Context::col_evaluate_block(const lmn_col* co, uint32_t log_domain, uin
 lmn_col* Context::col_extend(const lmn_col* co, uint32_t log_size) {
   set_device();
   if (log_size < co->log_size) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "extend: target smaller than the polynomial");
-  lmn_col* out = new_col(co->ncols, log_size);
-  launch_extend(co->d, 1ull << co->log_size, (int)co->log_size, out->d, 1ull << log_size, (int)log_size, (int)co->ncols, stream_);
-  return out;
+  ColGuard out(new_col(co->ncols, log_size));
+  launch_extend(co->d, 1ull << co->log_size, (int)co->log_size, out.c->d, 1ull << log_size, (int)log_size, (int)co->ncols, stream_);
+  return out.release();
 }
 void Context::col_eval_at_point(const lmn_col* co, uint32_t column, const uint32_t pt[8], uint32_t out[4]) {
   if (column >= co->ncols) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "eval_at_point: column index out of range");
@@ -236,10 +253,10 @@ lmn_col* Context::col_fold_line(const lmn_col* src, const uint32_t alpha[4]) {
   begin_op();
   std::vector<QM31> av{QM31{alpha[0], alpha[1], alpha[2], alpha[3]}};
   QM31* d_alpha = upload_vec(av);
-  lmn_col* out = new_col(4, src->log_size - 1);
-  launch_fold_line(out->d, src->d, 1u << src->log_size, itwX_[src->log_size + 1], d_alpha, stream_);
+  ColGuard out(new_col(4, src->log_size - 1));
+  launch_fold_line(out.c->d, src->d, 1u << src->log_size, itwX_[src->log_size + 1], d_alpha, stream_);
   lmn_sync(stream_);  // alpha lives in the arena
-  return out;
+  return out.release();
 }
 void Context::col_fold_circle_into_line(lmn_col* dst, const lmn_col* src, const uint32_t alpha[4]) {
   check_secure(src, "fold_circle_into_line");
@@ -261,7 +278,8 @@ lmn_col* Context::col_decompose(const lmn_col* f, uint32_t lambda_out[4]) {
   begin_op();
   QM31* d_lambda = (QM31*)arena_.alloc_bytes(sizeof(QM31));
   QM31* scratch = (QM31*)arena_.alloc_bytes((size_t)decompose_num_blocks((int)f->log_size) * sizeof(QM31));
-  lmn_col* g = new_col(4, f->log_size);
+  ColGuard gg(new_col(4, f->log_size));
+  lmn_col* g = gg.c;
   launch_decompose(f->d, (int)f->log_size, g->d, d_lambda, scratch, stream_);
   const QM31* l = (const QM31*)stage_download(d_lambda, sizeof(QM31));
   lmn_sync(stream_);
@@ -269,7 +287,7 @@ lmn_col* Context::col_decompose(const lmn_col* f, uint32_t lambda_out[4]) {
   lambda_out[1] = l->b;
   lambda_out[2] = l->c;
   lambda_out[3] = l->d;
-  return g;
+  return gg.release();
 }
 
 }  // namespace lmn
