@@ -199,6 +199,9 @@ def shard_proof_main(args, rank, local_rank, world):
 
 
 def main(argv=None):
+    # RCCL prints a version banner on STDOUT when a communicator is created unless told otherwise; the contract is
+    # ONE JSON line on stdout
+    os.environ.setdefault("NCCL_DEBUG", "NONE")
     args = parse_args(argv)
     rank, local_rank, world = dist_env()
     if world != args.gpus and world > 1:
@@ -475,7 +478,7 @@ def main(argv=None):
         dog.cancel()
         line["sharded_proof"] = res
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     pool.shutdown()
     for bl in bufs:
         for _, b, _ in bl:

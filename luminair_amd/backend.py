@@ -73,7 +73,7 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_voi
 
 class LmnCollective(C.Structure):
     """`lmn_collective`: the one exchange primitive of a sharded proof, an in-place all-gather on device memory."""
-    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN)]
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("group_begin", C.c_void_p), ("group_end", C.c_void_p)]
 
 
 RCCL_ID_BYTES = 128
@@ -478,7 +478,7 @@ class Context:
                 traceback.print_exc()
                 return 1
         self._shard_cb = ALL_GATHER_FN(_cb)            # keep the trampoline alive as long as the context uses it
-        self._shard_coll = LmnCollective(None, self._shard_cb)
+        self._shard_coll = LmnCollective(None, self._shard_cb, None, None)
         self._check(self.lib.lib.lmn_ctx_set_shard(self.handle, rank, world, fri_min_log, C.byref(self._shard_coll)))
 
     def rccl_unique_id(self) -> bytes:

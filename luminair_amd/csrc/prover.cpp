@@ -593,11 +593,14 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
 // In-place all-gather of column blocks through the shard's collective (RCCL over xGMI, or the caller's callback).
 void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank) {
   if (!shard_.active) throw LmnError(LMN_ERR_INTERNAL, "gather without a shard");
+  const bool group = ncols > 1 && shard_.coll.group_begin && shard_.coll.group_end;
+  if (group && shard_.coll.group_begin(shard_.coll.user) != 0) throw LmnError(LMN_ERR_INTERNAL, "shard group_begin failed");
   for (int c = 0; c < ncols; ++c) {
     int rc = shard_.coll.all_gather(shard_.coll.user, base + (uint64_t)c * col_stride, (size_t)words_per_rank * 4,
                                     (void*)(uintptr_t)stream_);
     if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
   }
+  if (group && shard_.coll.group_end(shard_.coll.user) != 0) throw LmnError(LMN_ERR_INTERNAL, "shard group_end failed");
 }
 
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
@@ -1917,6 +1920,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   static RcclApi& get() {
     static RcclApi api = [] {
@@ -1931,6 +1936,8 @@ struct RcclApi {
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
       }
       return a;
     }();
@@ -1948,6 +1955,8 @@ struct RcclTransport {
                                               (hipStream_t)stream);
     return r == ncclSuccess ? 0 : (int)r;
   }
+  static int group_begin(void*) { return RcclApi::get().GroupStart() == ncclSuccess ? 0 : 1; }
+  static int group_end(void*) { return RcclApi::get().GroupEnd() == ncclSuccess ? 0 : 1; }
 };
 void rccl_unique_id(uint8_t* out) {
   static_assert(sizeof(ncclUniqueId) <= LMN_RCCL_ID_BYTES, "ncclUniqueId larger than the ABI slot");
@@ -1971,7 +1980,10 @@ void Context::set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log
     delete t;
     throw LmnError(LMN_ERR_INTERNAL, "ncclCommInitRank failed");
   }
-  lmn_collective c{t, &RcclTransport::all_gather};
+  RcclApi& api = RcclApi::get();
+  const bool can_group = api.GroupStart && api.GroupEnd;
+  lmn_collective c{t, &RcclTransport::all_gather, can_group ? &RcclTransport::group_begin : nullptr,
+                   can_group ? &RcclTransport::group_end : nullptr};
   try {
     set_shard(rank, world, fri_min_log, &c);
   } catch (...) {
@@ -2000,7 +2012,7 @@ void Context::set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, con
   if (!coll || !coll->all_gather) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: missing all_gather");
   int g = 0;
   while ((1u << g) < world) ++g;
-  if (fri_min_log == 0) fri_min_log = 12;
+  if (fri_min_log == 0) fri_min_log = 16;
   // a split quotient column / FRI layer needs at least 4 rows per rank
   if ((int)fri_min_log < g + 1 || fri_min_log > 30) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: bad fri_min_log");
   lmn_sync(stream_);

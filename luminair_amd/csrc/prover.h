@@ -228,7 +228,7 @@ class Context {
     bool active = false;
     uint32_t rank = 0, world = 1;
     int g = 0;             // log2(world)
-    int fri_min_log = 12;  // FRI layers / quotient columns of at most 2^fri_min_log rows are replicated
+    int fri_min_log = 16;  // FRI layers / quotient columns of at most 2^fri_min_log rows are replicated
     lmn_collective coll{};
     void* rccl = nullptr;  // built-in RCCL transport (RcclTransport in prover.cpp)
   } shard_;

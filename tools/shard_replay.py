@@ -62,7 +62,7 @@ def record_worker(rank, world, port, name, path, q):
         ctx.upload_to(DeviceBuffer(ctx, buf, nbytes * world, owned=False), whole)
         if rank == 0:
             rec.append(whole)
-    ctx.set_shard(rank, world, all_gather)
+    ctx.set_shard(rank, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')))
     tabs = workload(name)
     bufs = [(k, ctx.upload(r), len(r)) for k, r in tabs]
     proof = ctx.prove_tables(bufs)
@@ -94,7 +94,7 @@ def replay(world, name, path, want_sha, reps):
             ctx.upload_to(DeviceBuffer(ctx, buf, nbytes * world, owned=False), rec[k])
         else:
             ctx.device_copy(buf, staged[k].ptr, nbytes * world)
-    ctx.set_shard(0, world, all_gather)
+    ctx.set_shard(0, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')))
     tabs = workload(name)
     bufs = [(k, ctx.upload(r), len(r)) for k, r in tabs]
     res = {"world": world, "all_gathers_per_proof": len(rec), "gathered_bytes_per_proof": int(sum(len(r) for r in rec))}
