@@ -201,7 +201,8 @@ def shard_proof_main(args, rank, local_rank, world):
 def main(argv=None):
     # RCCL prints a version banner on STDOUT when a communicator is created unless told otherwise; the contract is
     # ONE JSON line on stdout
-    os.environ.setdefault("NCCL_DEBUG", "NONE")
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":   # leave a real debug level alone
+        os.environ["NCCL_DEBUG"] = "NONE"
     args = parse_args(argv)
     rank, local_rank, world = dist_env()
     if world != args.gpus and world > 1:
