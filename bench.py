@@ -45,6 +45,7 @@ def parse_args(argv=None):
                          "proofs/s of independent proofs; --shard-workload picks the pie")
     ap.add_argument("--shard-workload", default="config5", choices=["config5", "config2a", "config3"],
                     help="config5: 256 x (Mul + SumReduce + Add), 2^24 rows; config2a: Add 2^log-rows; config3: 2^22 rows")
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-results (host_rows, config_2b, sharded_proof) and print the headline only")
     return ap.parse_args(argv)
@@ -214,7 +215,7 @@ def main(argv=None):
     import luminair_amd
     from luminair_amd import synthetic as syn
 
-    use_dist = world > 1
+    use_dist = world > 1 or args.force_dist   # --force-dist: the N > 1 code path on one rank (self-test)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
