@@ -212,3 +212,35 @@ def test_emu_trace_generation_error_paths(emu_ctx):
     assert emu_ctx.download(out, np.int32).tolist() == [1, 2, 1, 2, 1, 2]
     for b in (a, c1, mult, rows, out):
         b.free()
+
+
+def test_emu_shard_and_handle_argument_validation(emu_ctx):
+    """Error behaviour of the round-2 entry points: bad shard geometry, shape mismatches on device handles."""
+    E = backend.LuminairBackendError
+    noop = lambda buf, nbytes, stream: None
+    for rank, world, t in ((0, 3, 0), (2, 2, 0), (0, 16, 0), (0, 0, 0), (0, 8, 2), (0, 4, 40)):
+        with pytest.raises(E) as e:
+            emu_ctx.set_shard(rank, world, noop, t)
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    emu_ctx.clear_shard()                                  # a failed set_shard leaves the context unsharded
+    tabs = syn.config2_add_only(40, 2)
+    want = emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    emu_ctx.set_shard(0, 1, noop)                          # world 1: the collective is called but has nothing to move
+    assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
+    emu_ctx.clear_shard()
+    with pytest.raises(E):                                 # no RCCL in the emulation build
+        emu_ctx.set_shard_rccl(0, 1, bytes(128))
+    a = emu_ctx.col_from_cpu(np.zeros((4, 64), np.uint32))
+    b = emu_ctx.col_from_cpu(np.zeros((3, 64), np.uint32))
+    c = emu_ctx.col_from_cpu(np.zeros((4, 16), np.uint32))
+    for fn in (lambda: a.accumulate(b), lambda: a.accumulate(c), lambda: b.fold_line((1, 0, 0, 0)),
+               lambda: c.fold_circle_into_line(a, (1, 0, 0, 0)), lambda: b.decompose(), lambda: a.evaluate(5),
+               lambda: a.extend(5), lambda: a.eval_at_point(4, [0] * 8), lambda: a.evaluate_block(8, 4, 0),
+               lambda: a.evaluate_block(8, 1, 2), lambda: emu_ctx.commit([]), lambda: emu_ctx.col_zeros(0, 4),
+               lambda: emu_ctx.col_zeros(1, 40),
+               lambda: emu_ctx.col_accumulate_quotients([a, c], [(0, 0, (0, 0, 0, 0))], [[0] * 8], (1, 0, 0, 0))):
+        with pytest.raises(E) as e:
+            fn()
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    for x in (a, b, c):
+        x.free()

@@ -74,6 +74,23 @@ def _worker(rank, world, port, fri_min_log, q):
             ctx = _make_ctx(pinned)
             shard_context(ctx, fri_min_log=fri_min_log)
             return ctx
+        # errors surface identically on every rank (same transcript, same checks) and leave the contexts usable
+        from luminair_amd import backend, synthetic as syn
+        ctx = make(False)
+        bad = syn.config2_add_only(64, 9)[0][1].copy()
+        bad[3, 11] ^= 1                                  # out != lhs + rhs: ProverError(ConstraintsNotSatisfied)
+        try:
+            ctx.prove_tables([(0, bad, len(bad))])
+            raise AssertionError("a violated constraint went unnoticed")
+        except backend.LuminairBackendError as e:
+            assert e.code == backend.ERR_CONSTRAINTS
+        bad[3, 11] = 0x7fffffff                          # not a canonical M31 word
+        try:
+            ctx.prove_tables([(0, bad, len(bad))])
+            raise AssertionError("a non-canonical word went unnoticed")
+        except backend.LuminairBackendError as e:
+            assert e.code == backend.ERR_INVALID_ARGUMENT
+        ctx.close()
         q.put((rank, _prove_all(make)))
     finally:
         dist.destroy_process_group()
