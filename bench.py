@@ -421,7 +421,7 @@ def main(argv=None):
             line["host_rows"] = {"error": str(e)}
         try:
             from luminair_amd import backend as _bk
-            p2 = [luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED) for _ in range(min(inflight, 2))]
+            p2 = [luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED) for _ in range(inflight)]
             t2 = syn.config2_graph_faithful(1 << args.log_rows, 42)
             b2 = [[(k, q.ctx.upload(r), len(r)) for k, r in t2] for q in p2]
             for q, bb in zip(p2, b2):
