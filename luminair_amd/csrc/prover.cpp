@@ -595,12 +595,13 @@ void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uin
   if (!shard_.active) throw LmnError(LMN_ERR_INTERNAL, "gather without a shard");
   const bool group = ncols > 1 && shard_.coll.group_begin && shard_.coll.group_end;
   if (group && shard_.coll.group_begin(shard_.coll.user) != 0) throw LmnError(LMN_ERR_INTERNAL, "shard group_begin failed");
-  for (int c = 0; c < ncols; ++c) {
-    int rc = shard_.coll.all_gather(shard_.coll.user, base + (uint64_t)c * col_stride, (size_t)words_per_rank * 4,
-                                    (void*)(uintptr_t)stream_);
-    if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
-  }
-  if (group && shard_.coll.group_end(shard_.coll.user) != 0) throw LmnError(LMN_ERR_INTERNAL, "shard group_end failed");
+  int rc = 0;
+  for (int c = 0; c < ncols && rc == 0; ++c)
+    rc = shard_.coll.all_gather(shard_.coll.user, base + (uint64_t)c * col_stride, (size_t)words_per_rank * 4,
+                                (void*)(uintptr_t)stream_);
+  // an open group is always closed, also when one of its calls failed
+  if (group && shard_.coll.group_end(shard_.coll.user) != 0 && rc == 0) rc = -1;
+  if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
 }
 
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
