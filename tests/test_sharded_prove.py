@@ -163,7 +163,8 @@ def _gpu_cases():
     from luminair_amd import synthetic as syn
     c4, luts4 = syn.config4_black_scholes_shape()
     return [(syn.config2_add_only(1 << 15, 3), None, False), (syn.config3_mixed(13, 12, 12, 4), None, False),
-            (syn.config5_linear_layers(4, 16, 32, 5), None, False), (c4, luts4, True)]
+            (syn.config5_linear_layers(4, 16, 32, 5), None, False), (c4, luts4, True),
+            (syn.less_than_graph(3000, 6), None, True), (syn.config2_graph_faithful(1 << 13, 3), None, True)]
 
 
 def _gpu_prove_all(lib, shard=None):
