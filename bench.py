@@ -46,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--shard-workload", default="config5", choices=["config5", "config2a", "config3"],
                     help="config5: 256 x (Mul + SumReduce + Add), 2^24 rows; config2a: Add 2^log-rows; config3: 2^22 rows")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--emu-library", default=None,
+                    help="TEST ONLY: path of the host-emulation build (tests/emu): exercises the rank launch / barrier / "
+                         "aggregation path over gloo on a machine without a GPU; the line says so in `data`")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-results (host_rows, config_2b, sharded_proof) and print the headline only")
     return ap.parse_args(argv)
@@ -88,13 +91,25 @@ def aggregate(elapsed, world, steps_per_rank, reduce_max):
     return {"seconds": tmax, "value": world * steps_per_rank / tmax, "ms_per_step": 1e3 * tmax / steps_per_rank}
 
 
-def cpu_baseline(sample_log, full_log):
-    """The oracle's plain-C restatement (oracle/c/stark_kernels.c, OpenMP, driven by oracle/prover.py) timed on this
-    box on the same workload, in its own process (oracle/cpu_baseline.py says why): one cold proof (builds the
-    twiddle/domain tables, as the reference does per proof), three warm ones, and the reference's own published
-    32x32 Add shape.  Bounded: a few seconds of CPU work."""
+def physical_cores():
+    """(physical id, core id) pairs of /proc/cpuinfo; half the logical CPUs if that cannot be read"""
+    try:
+        seen, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    seen.add((phys, ln.split(":", 1)[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline_run(threads, sample_log, full_log):
     import subprocess
-    threads = max(1, min(64, (os.cpu_count() or 2) // 2))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="passive", OMP_PROC_BIND="close",
                OMP_PLACES="cores", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     out = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(sample_log), str(full_log)], cwd=ROOT, env=env,
@@ -102,24 +117,59 @@ def cpu_baseline(sample_log, full_log):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def cpu_baseline(sample_log, full_log):
+    """The oracle's plain-C restatement (oracle/c/stark_kernels.c, OpenMP, driven by oracle/prover.py) timed on this
+    box on the same workload, in its own process (oracle/cpu_baseline.py says why): one cold proof (builds the
+    twiddle/domain tables, as the reference does per proof), three warm ones, and the reference's own published
+    32x32 Add shape.  Run twice - on ALL physical cores of the host and on 64 pinned threads (one socket's worth;
+    the faster one on a 2-socket EPYC in round 2) - `value` is the better of the two, `cores` the threads it used,
+    `by_threads` both.  Bounded: a few seconds of CPU work each."""
+    phys = physical_cores()
+    runs = {}
+    for threads in sorted({phys, max(1, min(64, phys))}, reverse=True):
+        runs[threads] = cpu_baseline_run(threads, sample_log, full_log)
+    best = max(runs, key=lambda t: runs[t]["value"])
+    res = dict(runs[best])
+    res["host_physical_cores"] = phys
+    res["by_threads"] = {str(t): {"value": r["value"], "sample": r["sample"],
+                                  "reference_shape_32x32_add_ms": r["reference_shape_32x32_add_ms"]} for t, r in runs.items()}
+    return res
+
+
 def throughput(provers, bufs, steps, warmup, luts=None):
-    """proofs/s of `steps` proofs dealt round-robin over the in-flight contexts (no barrier: sub-results only)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """proofs/s of `steps` proofs dealt round-robin over the in-flight contexts (no barrier: sub-results only).
+    ONE driver thread per context: proof k runs on context k % n, and a context only ever sees its own thread
+    (round 2 dealt the warm-up proofs to a shared worker pool, which let two workers enter the same context at
+    once - the source of the `host_rows` ConstraintsNotSatisfied in BENCH_r02.json)."""
+    import threading
     n = len(provers)
-    with ThreadPoolExecutor(max_workers=n) as pool:
-        def one(i):
-            return provers[i].ctx.prove_tables(bufs[i], luts)
-        for f in [pool.submit(one, i % n) for i in range(warmup)]:
-            f.result()
-        t0 = time.perf_counter()
-        pending = []
-        for k in range(steps):
-            if len(pending) >= n:
-                pending.pop(0).result()
-            pending.append(pool.submit(one, k % n))
-        for f in pending:
-            f.result()
-        dt = time.perf_counter() - t0
+    start = threading.Barrier(n + 1)
+    errors = []
+
+    def drive(i):
+        try:
+            for _ in range((warmup + n - 1 - i) // n):
+                provers[i].ctx.prove_tables(bufs[i], luts)
+            start.wait()
+            for _ in range((steps + n - 1 - i) // n):
+                provers[i].ctx.prove_tables(bufs[i], luts)
+        except BaseException as e:  # noqa: BLE001 - reported by the caller
+            errors.append(e)
+            start.abort()
+
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    try:
+        start.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
     return {"value": steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
 
 
@@ -197,6 +247,28 @@ def shard_proof_main(args, rank, local_rank, world):
     for _, b, _ in bufs:
         b.free()
     dist.destroy_process_group()
+    return 0 if int(same.item()) else 1
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per
+    GPU, RCCL rendezvous on 127.0.0.1) exactly as the driver's torch.distributed.run line does, and pass their
+    single JSON line through.  Fails loudly if the box has fewer than N GPUs."""
+    import socket
+    import subprocess
+    if not args.emu_library:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible on this node" % (args.gpus, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(argv if argv is not None else sys.argv[1:])
+    return subprocess.run(cmd, env=dict(os.environ, LMN_BENCH_SELF_LAUNCHED="1")).returncode
 
 
 def main(argv=None):
@@ -205,30 +277,49 @@ def main(argv=None):
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":   # leave a real debug level alone
         os.environ["NCCL_DEBUG"] = "NONE"
     args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
     rank, local_rank, world = dist_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if args.shard_proof:
         return shard_proof_main(args, rank, local_rank, world)
     import numpy as np
     import torch
     import luminair_amd
+    from luminair_amd import backend as _bk
     from luminair_amd import synthetic as syn
 
+    emu = args.emu_library is not None            # test of the launch path only (no GPU, gloo, emulation build)
+    library = _bk.Library(args.emu_library) if emu else None
+    has_cuda = torch.cuda.is_available() and not emu
+    tdev = "cuda" if has_cuda else "cpu"
     use_dist = world > 1 or args.force_dist   # --force-dist: the N > 1 code path on one rank (self-test)
+    ranks_seen = 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = local_rank if torch.cuda.is_available() else 0
+        if has_cuda:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if has_cuda else "gloo", rank=rank, world_size=world)
+        # how many ranks the collective backend (RCCL under "nccl") really connects
+        ones = torch.ones(1, dtype=torch.int64, device=tdev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit("bench.py: the process group connects %d ranks, expected %d" % (ranks_seen, world))
+    dev = local_rank if has_cuda else 0
+    errors = []        # every sub-result failure lands here; a non-empty list makes the process exit non-zero
+
+    def mk_prover(**kw):
+        return luminair_amd.Prover(dev, library=library, **kw)
 
     # `inflight` independent prover contexts per GPU (own HIP stream + device arena each); a step is
     # still one whole proof, steps are dealt round-robin to the contexts and run concurrently
     from concurrent.futures import ThreadPoolExecutor
-    inflight = max(1, min(args.inflight, args.steps))
-    provers = [luminair_amd.Prover(dev) for _ in range(inflight)]
+    inflight = 1 if emu else max(1, min(args.inflight, args.steps))   # the emulation runtime is single-context
+    provers = [mk_prover() for _ in range(inflight)]
     prover = provers[0]
     tabs = syn.config2_add_only(1 << args.log_rows, 42 + rank)   # each rank proves its own trace
     if args.host_rows:
@@ -236,7 +327,8 @@ def main(argv=None):
     else:
         bufs = [[(k, p.ctx.upload(r), len(r)) for k, r in tabs] for p in provers]   # trace rows resident in HBM
     out = {}
-    pool = ThreadPoolExecutor(max_workers=inflight)
+    # one worker thread per context (a worker pool shared by the contexts could put two threads into one context)
+    pools = [ThreadPoolExecutor(max_workers=1) for _ in range(inflight)]
     pending = []
 
     def one(i):
@@ -245,12 +337,11 @@ def main(argv=None):
     counter = {"n": 0}
 
     def step():
-        # keep at most `inflight` proofs outstanding (ctypes releases the GIL inside lmn_prove)
+        # step k is queued on context k % inflight; every context works through its own queue on its own thread
+        # (ctypes releases the GIL inside lmn_prove), so a slow proof on one context never holds the others back
         i = counter["n"] % inflight
         counter["n"] += 1
-        if len(pending) >= inflight:
-            pending.pop(0).result()
-        pending.append(pool.submit(one, i))
+        pending.append(pools[i].submit(one, i))
 
     def drain():
         while pending:
@@ -263,16 +354,20 @@ def main(argv=None):
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if has_cuda:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     def device_sync():
         drain()
-        torch.cuda.synchronize()
+        if has_cuda:
+            torch.cuda.synchronize()
 
     def reduce_max(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -280,7 +375,7 @@ def main(argv=None):
     agg = aggregate(elapsed, world, args.steps, reduce_max)
     # single-proof latency (one proof alone on the GPU) and the per-kernel timings behind `roofline`
     lat = []
-    for _ in range(21):
+    for _ in range(5 if emu else 21):
         t0 = time.perf_counter()
         one(0)
         lat.append(1e3 * (time.perf_counter() - t0))
@@ -300,7 +395,7 @@ def main(argv=None):
     pmc = {}
     pmc_source = None
     try:
-        for cand in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+        for cand in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
             pth = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pth):
                 with open(pth) as f:
@@ -343,63 +438,94 @@ def main(argv=None):
     roofline = roof(dom)
     roofline_other = [roof(k) for k in fams if k != dom]
 
-    # whole-proof figure against SURVEY.md §8d's minimum-traffic model (48*C*N + 1500*N bytes, C = 27 columns)
+    # whole-proof figure against SURVEY.md §8d's minimum-traffic model of the WHOLE proof (48*C*N + 1500*N bytes, C = 27
+    # columns: every pass of every stage counted once - not the per-pass Merkle formula `roofline` uses for its launches)
     model_bytes = (48 * 27 + 1500) * float(1 << args.log_rows)
-    whole = {"model_bytes_per_proof": model_bytes, "achieved": model_bytes / (1e-3 * agg["ms_per_step"]) / 1e9 * world,
+    whole = {"byte_model": "SURVEY.md §8(d) whole-proof minimum-traffic model: 48*C*N + 1500*N bytes, C = 27, N = 2^%d "
+                           "(all stages; differs from the per-launch Merkle bytes behind `roofline`)" % args.log_rows,
+             "model_bytes_per_proof": model_bytes, "achieved": model_bytes / (1e-3 * agg["ms_per_step"]) / 1e9 * world,
              "peak": HBM_PEAK_GBS * world, "unit": "GB/s"}
     whole["frac"] = whole["achieved"] / whole["peak"]
+
+    def sub_result(name, fn):
+        try:
+            return fn()
+        except BaseException as e:  # noqa: BLE001 - the headline is still printed; the failure is made visible
+            errors.append("%s: %s: %s" % (name, type(e).__name__, e))
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    def variant_throughput(tables, variant, steps, what, n_ctx=None):
+        """proofs/s + solo latency of another workload on its own contexts (device-resident rows)"""
+        ps = [mk_prover(protocol_variant=variant) for _ in range(n_ctx or inflight)]
+        bs = [[(k, q.ctx.upload(r), len(r)) for k, r in tables] for q in ps]
+        try:
+            for q, bb in zip(ps, bs):
+                q.ctx.prove_tables(bb)
+            return dict(throughput(ps, bs, steps, len(ps)), workload=what,
+                        prove_latency_ms=solo_latency(ps[0].ctx, bs[0]), proofs_in_flight_per_gpu=len(ps))
+        finally:
+            for bb in bs:
+                for _, b_, _ in bb:
+                    b_.free()
+            for q in ps:
+                q.ctx.close()
 
     # the reference's own published shape (BASELINE.md §1: 32x32 Add, 1 024 Add rows + 2 048 Inputs rows,
     # 13.05 ms on a GitHub Actions runner) as a sanity anchor: solo GPU latency, median of 9
     anchor = None
     if rank == 0 and world == 1 and not args.no_anchor:
-        from luminair_amd import backend as _bk
-        ap = luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED)
-        atabs = [(k, r, len(r)) for k, r in syn.config2_graph_faithful(1024, 42)]
-        ap.ctx.prove_tables(atabs)
-        ts = []
-        for _ in range(9):
-            t0 = time.perf_counter()
+        def run_anchor():
+            ap = mk_prover(protocol_variant=_bk.VARIANT_PINNED)
+            atabs = [(k, r, len(r)) for k, r in syn.config2_graph_faithful(1024, 42)]
             ap.ctx.prove_tables(atabs)
-            ts.append(1e3 * (time.perf_counter() - t0))
-        anchor = {"workload": "32x32 Add graph: Add 2^10 rows + Inputs 2^11 rows, host rows (PCIe-inclusive)",
-                  "gpu_latency_ms": sorted(ts)[4], "reference_published_ms": 13.05,
-                  "reference_hardware": "GitHub Actions ubuntu-latest CPU (docs/snippets/benchmark-component.mdx:172)"}
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                ap.ctx.prove_tables(atabs)
+                ts.append(1e3 * (time.perf_counter() - t0))
+            ap.ctx.close()
+            return {"workload": "32x32 Add graph: Add 2^10 rows + Inputs 2^11 rows, host rows (PCIe-inclusive)",
+                    "gpu_latency_ms": sorted(ts)[4], "reference_published_ms": 13.05,
+                    "reference_hardware": "GitHub Actions ubuntu-latest CPU (docs/snippets/benchmark-component.mdx:172)"}
+        anchor = sub_result("reference_shape_anchor", run_anchor)
 
     # the step before the path (SURVEY.md §8f-3): `process_trace` of the Add node on device tensors
     trace_gen = None
-    if rank == 0:
-        import numpy as _np
-        n_rows = 1 << args.log_rows
-        rng = _np.random.default_rng(7)
-        dl = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(_np.int32))
-        dr = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(_np.int32))
-        rows_buf = prover.ctx.alloc(n_rows * 15 * 4)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            _, ob = prover.ctx.trace_elementwise(0, dl, dr, n_rows, node_id=2, input_ids=(0, 1), num_consumers=0,
-                                                 is_final_output=True, input_mults=(0, 0), rows=rows_buf)
-            ts.append(1e3 * (time.perf_counter() - t0))
-            ob.free()
-        for b_ in (dl, dr, rows_buf):
-            b_.free()
-        trace_gen = {"workload": "Add node process_trace on device tensors, 2^%d elements -> 15-column rows in HBM"
-                                 % args.log_rows, "ms": sorted(ts)[2],
-                     "reference_published_ms": 0.0959, "reference_workload": "32x32 Add trace generation (BASELINE.md §1)"}
+    if rank == 0 and not emu:
+        def run_trace_gen():
+            n_rows = 1 << args.log_rows
+            rng = np.random.default_rng(7)
+            dl = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(np.int32))
+            dr = prover.ctx.upload(rng.integers(-2048, 2048, size=n_rows).astype(np.int32))
+            rows_buf = prover.ctx.alloc(n_rows * 15 * 4)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                _, ob = prover.ctx.trace_elementwise(0, dl, dr, n_rows, node_id=2, input_ids=(0, 1), num_consumers=0,
+                                                     is_final_output=True, input_mults=(0, 0), rows=rows_buf)
+                ts.append(1e3 * (time.perf_counter() - t0))
+                ob.free()
+            for b_ in (dl, dr, rows_buf):
+                b_.free()
+            return {"workload": "Add node process_trace on device tensors, 2^%d elements -> 15-column rows in HBM"
+                                % args.log_rows, "ms": sorted(ts)[2],
+                    "reference_published_ms": 0.0959, "reference_workload": "32x32 Add trace generation (BASELINE.md §1)"}
+        trace_gen = sub_result("device_trace_generation", run_trace_gen)
 
     line = {
         "metric": "proofs/sec, 2^%d-row Add trace" % args.log_rows, "value": agg["value"], "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": agg["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31/QM31 field arithmetic)",
-        "data": "synthetic" + (" (host rows: PCIe-inclusive)" if args.host_rows else ""),
+        "data": ("EMULATION BUILD ON CPU - test of the rank launch path only, not a measurement" if emu else
+                 "synthetic" + (" (host rows: PCIe-inclusive)" if args.host_rows else "")),
         "config": {"workload": "BASELINE config 2a: single Add-op AIR, 2^%d trace rows per proof, PcsConfig default "
                                "(pow 5, blowup 2x, 3 queries), KAT protocol variant (the variant the reference's only "
                                "known-answer proof pins; Add's constraint forms are KAT-pinned, Mul's second "
                                "eval_fixed_mul slot and the Recip/Sqrt/Rem forms are unpinned and not used here)"
                                % args.log_rows,
                    "rows": 1 << args.log_rows, "proofs_per_rank": args.steps, "parallelism": "proof-sharded x%d" % world,
-                   "proofs_in_flight_per_gpu": inflight,
+                   "proofs_in_flight_per_gpu": inflight, "ranks_in_process_group": ranks_seen,
+                   "collective_backend": ("nccl (RCCL)" if has_cuda else "gloo") if use_dist else None,
                    "proof_bytes": len(out["proof"])},
         "prove_latency_ms": latency_ms,
         "prove_latency_p95_ms": latency_p95_ms,
@@ -408,44 +534,37 @@ def main(argv=None):
         "roofline_other": roofline_other,
         "whole_proof_vs_traffic_model": whole,
     }
-    if rank == 0 and not args.no_extras and not args.host_rows:
-        # sub-results next to the headline: the same workload with the trace rows handed over as
-        # host buffers (the reference API takes a host pie: 60 MiB over PCIe per proof), and config 2b = what
-        # gen_trace really emits for an Add node at HEAD (Add 2^20 rows consumed with multiplicity -1 + the Inputs
-        # table of 2^21 rows; PINNED protocol variant - parity unpinned)
-        try:
+    if rank == 0 and not args.no_extras and not args.host_rows and not emu:
+        # sub-results next to the headline: the same workload with the trace rows handed over as host buffers (the
+        # reference API takes a host pie: 60 MiB over PCIe per proof); config 2b = what gen_trace really emits for an
+        # Add node at HEAD (Add 2^20 rows consumed with multiplicity -1 + the Inputs table of 2^21 rows; PINNED
+        # protocol variant - parity unpinned); a Mul-only trace of the same size (the metric says
+        # "Add/Mul"); BASELINE config 3 (Add 2^21 + Mul 2^20 + Recip 2^20 rows, three components in one commitment)
+        def run_host_rows():
             hb = [[(k, r, len(r)) for k, r in tabs] for _ in provers]
-            line["host_rows"] = dict(throughput(provers, hb, 48, 8), note="trace rows as host buffers: PCIe-inclusive",
-                                     prove_latency_ms=solo_latency(prover.ctx, hb[0]))
-        except Exception as e:  # never lose the headline over a sub-result
-            line["host_rows"] = {"error": str(e)}
-        try:
-            from luminair_amd import backend as _bk
-            p2 = [luminair_amd.Prover(dev, protocol_variant=_bk.VARIANT_PINNED) for _ in range(inflight)]
-            t2 = syn.config2_graph_faithful(1 << args.log_rows, 42)
-            b2 = [[(k, q.ctx.upload(r), len(r)) for k, r in t2] for q in p2]
-            for q, bb in zip(p2, b2):
-                q.ctx.prove_tables(bb)
-            line["config_2b"] = dict(throughput(p2, b2, 32, 4),
-                                     workload="BASELINE config 2b (graph-faithful): Add 2^%d rows + Inputs 2^%d rows, "
-                                              "PINNED protocol variant (parity unpinned)" % (args.log_rows, args.log_rows + 1),
-                                     prove_latency_ms=solo_latency(p2[0].ctx, b2[0]), proofs_in_flight_per_gpu=len(p2))
-            for bb in b2:
-                for _, b_, _ in bb:
-                    b_.free()
-            for q in p2:
-                q.ctx.close()
-        except Exception as e:
-            line["config_2b"] = {"error": str(e)}
+            return dict(throughput(provers, hb, 48, 8), note="trace rows as host buffers: PCIe-inclusive",
+                        prove_latency_ms=solo_latency(prover.ctx, hb[0]))
+        line["host_rows"] = sub_result("host_rows", run_host_rows)
+        lr = args.log_rows
+        line["config_2b"] = sub_result("config_2b", lambda: variant_throughput(
+            syn.config2_graph_faithful(1 << lr, 42), _bk.VARIANT_PINNED, 32,
+            "BASELINE config 2b (graph-faithful): Add 2^%d rows + Inputs 2^%d rows, PINNED protocol variant (parity "
+            "unpinned)" % (lr, lr + 1)))
+        line["mul_only"] = sub_result("mul_only", lambda: variant_throughput(
+            syn.config2_mul_only(1 << lr, 42), _bk.VARIANT_KAT, 48,
+            "single Mul-op AIR, 2^%d trace rows, all multiplicities 0, KAT variant (16 columns; rem != 0, so Mul's "
+            "second eval_fixed_mul slot - restated as a zero slot - is unpinned)" % lr))
+        line["config_3"] = sub_result("config_3", lambda: variant_throughput(
+            syn.config3_mixed(lr + 1, lr, lr), _bk.VARIANT_KAT, 16,
+            "BASELINE config 3: Add 2^%d + Mul 2^%d + Recip 2^%d rows in one pie (three components, mixed-size trees; "
+            "Recip's constraint form unpinned)" % (lr + 1, lr, lr), n_ctx=min(inflight, 2)))
     if anchor:
         line["reference_shape_anchor"] = anchor
     if trace_gen:
         line["device_trace_generation"] = trace_gen
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows)
-        except Exception as e:  # never lose the headline over the baseline leg
-            line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
+        line["cpu_baseline"] = sub_result("cpu_baseline",
+                                          lambda: cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows))
     if use_dist and not args.no_extras and os.environ.get("LMN_BENCH_SHARDED_EXTRA", "1") != "0":
         # Sub-result at N > 1: latency of ONE 2^log_rows-row Add proof sharded over all N GPUs (the library's own RCCL
         # communicator on the prover stream), next to the solo latency above.  A watchdog makes sure the headline
@@ -455,40 +574,55 @@ def main(argv=None):
         def give_up():
             if rank == 0:
                 line["sharded_proof"] = {"error": "timed out (watchdog)"}
+                line["errors"] = errors + ["sharded_proof: timed out (watchdog)"]
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         dog = threading.Timer(float(os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "120")), give_up)
         dog.daemon = True
         dog.start()
-        res = {}
-        try:
+
+        def run_sharded():
             from luminair_amd.sharded import shard_context
-            sp = luminair_amd.Prover(dev)
+            sp = mk_prover()
             stabs = syn.config2_add_only(1 << args.log_rows, 42)            # the same table on every rank
             sb = [(k, sp.ctx.upload(r), len(r)) for k, r in stabs]
             want = sp.ctx.prove_tables(sb)
             shard_context(sp.ctx)
             got = sp.ctx.prove_tables(sb)
-            el = timed_region(lambda: sp.ctx.prove_tables(sb), 16, 2, barrier, torch.cuda.synchronize)
+            n_sh = 2 if emu else 16
+            el = timed_region(lambda: sp.ctx.prove_tables(sb), n_sh, 1 if emu else 2, barrier,
+                              torch.cuda.synchronize if has_cuda else (lambda: None))
             tmax = reduce_max(el)
-            res = {"workload": "ONE 2^%d-row Add proof sharded into row blocks over %d GPUs" % (args.log_rows, world),
-                   "prove_latency_ms": 1e3 * tmax / 16, "solo_unsharded_latency_ms": latency_ms,
-                   "bytes_identical_to_unsharded_proof": got == want, "scaling": "strong"}
+            same = torch.tensor([1 if got == want else 0], device=tdev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
             sp.ctx.clear_shard()
-        except Exception as e:
-            res = {"error": "%s: %s" % (type(e).__name__, e)}
+            if not int(same.item()):
+                raise RuntimeError("sharded proof bytes differ from the unsharded proof on some rank")
+            return {"workload": "ONE 2^%d-row Add proof sharded into row blocks over %d GPUs" % (args.log_rows, world),
+                    "prove_latency_ms": 1e3 * tmax / n_sh, "solo_unsharded_latency_ms": latency_ms,
+                    "bytes_identical_to_unsharded_proof": True, "scaling": "strong"}
+        line["sharded_proof"] = sub_result("sharded_proof", run_sharded)
         dog.cancel()
-        line["sharded_proof"] = res
+    # a failure on any rank must reach rank 0's line and every rank's exit status
+    n_err = len(errors)
+    if use_dist:
+        t = torch.tensor([n_err], dtype=torch.int64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t.item()) and not n_err:
+            errors.append("a sub-result failed on another rank")
+    line["errors"] = errors
     if rank == 0:
         print(json.dumps(line), flush=True)
-    pool.shutdown()
+    for pl in pools:
+        pl.shutdown()
     for bl in bufs:
         for _, b, _ in bl:
             if hasattr(b, "free"):
                 b.free()
     if use_dist:
         dist.destroy_process_group()
+    return 1 if errors else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -95,12 +95,14 @@ void lmn_free(void* p) { free(p); }
 
 int lmn_set_profiling(lmn_ctx* ctx, int enabled) {
   if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   ctx->impl->profiling = enabled != 0;
   return LMN_OK;
 }
 
 int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out) {
   if (!ctx || !out) return LMN_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> lock(const_cast<lmn_ctx*>(ctx)->mu);
   *out = ctx->impl->timings;
   return LMN_OK;
 }

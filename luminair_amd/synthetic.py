@@ -382,6 +382,15 @@ def config2_add_only(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, n
     return [(KIND_ADD, add_rows(lhs, rhs))]
 
 
+def config2_mul_only(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
+    """The Mul counterpart of config 2a (BASELINE's metric says "Add/Mul trace"): one Mul table, all multiplicities 0,
+    non-negative operands (avoids numerair's unverified sign convention for `rem`)."""
+    rng = np.random.default_rng(seed)
+    lhs = rng.integers(0, 2048, size=n_rows)
+    rhs = rng.integers(0, 2048, size=n_rows)
+    return [(KIND_MUL, mul_rows(lhs, rhs))]
+
+
 def config2_graph_faithful(n_rows: int = 1 << 20, seed: int = 42) -> List[Tuple[int, np.ndarray]]:
     """BASELINE config 2b (needs the PINNED variant): Add consumes both inputs with mult -1,
     an Inputs table of 2n rows yields them with multiplicity 1."""

@@ -57,3 +57,82 @@ def test_two_rank_sharded_bench_logic():
     assert abs(a0["seconds"] - a1["seconds"]) < 1e-9   # both ranks agree on the max-over-ranks time
     assert a0["seconds"] >= 5 * 0.02 * 0.9      # bounded below by the slow rank
     assert abs(a0["value"] - world * 5 / a0["seconds"]) < 1e-9   # whole-job proofs/s over all ranks
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` as the driver runs it (no torchrun environment) must START two ranks, not report
+    N = 1: end to end over gloo with the test-only emulation build (rank launch, barrier-bracketed region,
+    max-over-ranks aggregation, the `sharded_proof` sub-result over both ranks, exit status)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    if not os.path.exists(emu):
+        import subprocess
+        subprocess.run(["bash", os.path.join(root, "tests", "emu", "build_emu.sh")], check=True)
+    r, line = _run_bench(["--gpus", "2", "--emu-library", emu, "--log-rows", "5", "--steps", "4", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["config"]["ranks_in_process_group"] == 2 and line["config"]["collective_backend"] == "gloo"
+    assert line["errors"] == []
+    assert line["sharded_proof"]["bytes_identical_to_unsharded_proof"] is True
+    assert "EMULATION" in line["data"]              # never mistaken for a measurement
+    assert line["value"] > 0 and abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4 / 1e3)) < 1e-6 * line["value"]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """On a box with fewer than N GPUs `--gpus N` fails loudly instead of benchmarking one GPU as N = 1."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r, line = _run_bench(["--gpus", str(max(2, 2 * n)), "--steps", "2", "--warmup", "0"], timeout=300)
+    assert r.returncode != 0 and line is None
+    assert "GPU(s) visible" in r.stderr
+
+
+def test_throughput_never_puts_two_threads_into_one_context():
+    """bench.throughput(): one driver thread per context (round 2's shared worker pool entered a context twice)."""
+    import threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    class Ctx:
+        def __init__(self):
+            self.inside, self.calls, self.overlap, self.lock = 0, 0, 0, threading.Lock()
+
+        def prove_tables(self, bufs, luts=None):
+            with self.lock:
+                self.inside += 1
+                self.overlap = max(self.overlap, self.inside)
+            time.sleep(0.002 * (1 + self.calls % 3))
+            with self.lock:
+                self.inside -= 1
+                self.calls += 1
+            return b""
+
+    class P:
+        def __init__(self):
+            self.ctx = Ctx()
+
+    ps = [P() for _ in range(4)]
+    res = bench.throughput(ps, [None] * 4, 22, 9)
+    assert [p.ctx.overlap for p in ps] == [1, 1, 1, 1]
+    assert sum(p.ctx.calls for p in ps) == 22 + 9 and res["steps"] == 22
+
+    class Boom(Ctx):
+        def prove_tables(self, bufs, luts=None):
+            raise RuntimeError("ProverError(ConstraintsNotSatisfied)")
+    ps[2].ctx = Boom()
+    try:
+        bench.throughput(ps, [None] * 4, 8, 4)
+        raise AssertionError("a failing context must fail the sub-result")
+    except RuntimeError as e:
+        assert "ConstraintsNotSatisfied" in str(e)

@@ -244,3 +244,22 @@ def test_emu_shard_and_handle_argument_validation(emu_ctx):
         assert e.value.code == backend.ERR_INVALID_ARGUMENT
     for x in (a, b, c):
         x.free()
+
+
+def test_emu_one_context_from_several_threads_is_serialised(emu_ctx):
+    """Calls on one context from several threads are serialised by the context's lock (include/luminair_hip.h):
+    the misuse that corrupted round 2's `host_rows` sub-result (two pool workers inside one context) is now safe."""
+    import threading
+    tabs = [(k, r, len(r)) for k, r in syn.chain_graph(40, 11)]
+    want = emu_ctx.prove_tables(tabs)
+    bad = []
+
+    def work():
+        for _ in range(3):
+            if emu_ctx.prove_tables(tabs) != want:
+                bad.append(1)
+
+    ths = [threading.Thread(target=work) for _ in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad

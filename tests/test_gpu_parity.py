@@ -210,6 +210,63 @@ def test_gpu_four_contexts_full_size_soak(hip_lib_path):
             b.free()
 
 
+def test_gpu_four_contexts_host_rows_shared_and_private_buffers(hip_lib_path):
+    """The reference's calling convention (prover.rs:28-31,70: the pie is HOST data) at the bench's operating point:
+    four contexts, one driver thread each, 40 proofs each of the 2^20-row trace handed over as host buffers - first
+    all four contexts reading the SAME numpy buffer, then private copies, the first host-rows proof of every context
+    growing its arena inside the concurrent region.  Every proof must equal the device-rows proof (BENCH_r02's
+    `host_rows` ConstraintsNotSatisfied: tools/repro_host_rows.py)."""
+    import hashlib
+    import threading
+    tabs = syn.config2_add_only(1 << 20, 42)
+    provers = [luminair_amd.Prover(0) for _ in range(4)]
+    dev = [(k, provers[0].ctx.upload(r), len(r)) for k, r in tabs]
+    ref = hashlib.sha256(provers[0].ctx.prove_tables(dev)).hexdigest()
+    for label, bufs in (("shared", [[(k, r, len(r)) for k, r in tabs] for _ in provers]),
+                        ("private", [[(k, np.array(r, copy=True), len(r)) for k, r in tabs] for _ in provers])):
+        bad = []
+
+        def work(i):
+            for it in range(40):
+                try:
+                    if hashlib.sha256(provers[i].ctx.prove_tables(bufs[i])).hexdigest() != ref:
+                        bad.append((label, i, it, "bytes differ"))
+                except Exception as e:  # noqa: BLE001
+                    bad.append((label, i, it, str(e)))
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not bad, bad[:4]
+    for _, b, _ in dev:
+        b.free()
+
+
+def test_gpu_one_context_driven_by_several_threads_is_serialised(hip_lib_path):
+    """Misuse made safe: calls on ONE context from several threads are serialised by the context's lock
+    (include/luminair_hip.h) - round 2's bench put two pool workers into one context and got corrupted proofs and
+    GPU memory faults.  Three threads x 8 proofs on one context, host rows and device rows mixed."""
+    import threading
+    tabs = syn.config2_add_only(1 << 16, 5)
+    p = luminair_amd.Prover(0)
+    dev = [(k, p.ctx.upload(r), len(r)) for k, r in tabs]
+    host = [(k, r, len(r)) for k, r in tabs]
+    want = p.ctx.prove_tables(dev)
+    bad = []
+
+    def work(i):
+        for it in range(8):
+            if p.ctx.prove_tables(dev if (i + it) & 1 else host) != want:
+                bad.append((i, it))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad
+    for _, b, _ in dev:
+        b.free()
+
+
 def test_gpu_error_behaviour(gpu_prover):
     with pytest.raises(luminair_amd.LuminairError) as e:
         gpu_prover.prove(luminair_amd.LuminairPie([luminair_amd.TraceTable(luminair_amd.TraceTableKind.Add,
