@@ -477,9 +477,11 @@ class Context:
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._shard_cb = ALL_GATHER_FN(_cb)            # keep the trampoline alive as long as the context uses it
-        self._shard_coll = LmnCollective(None, self._shard_cb, None, None)
-        self._check(self.lib.lib.lmn_ctx_set_shard(self.handle, rank, world, fri_min_log, C.byref(self._shard_coll)))
+        cb = ALL_GATHER_FN(_cb)
+        coll = LmnCollective(None, cb, None, None)
+        self._check(self.lib.lib.lmn_ctx_set_shard(self.handle, rank, world, fri_min_log, C.byref(coll)))
+        # keep the trampoline alive as long as the context uses it (a rejected call keeps the previous one)
+        self._shard_cb, self._shard_coll = cb, coll
 
     def rccl_unique_id(self) -> bytes:
         buf = (C.c_uint8 * RCCL_ID_BYTES)()

@@ -256,6 +256,8 @@ void rccl_unique_id(uint8_t* out);
 int lmn_ctx_set_shard(lmn_ctx* ctx, uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
   if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] {
+    // validate first: a rejected call leaves the context's current sharding (and its RCCL transport) untouched
+    lmn::Context::check_shard_args(rank, world, fri_min_log, coll);
     ctx->impl->clear_shard();  // releases a previous built-in RCCL transport, if any
     ctx->impl->set_shard(rank, world, fri_min_log, coll);
   });
@@ -299,10 +301,11 @@ int lmn_lut_log_size(const lmn_range* ranges, uint32_t n_ranges, uint32_t* log_s
   uint64_t count = 0;
   if (!ranges || n_ranges == 0) return LMN_ERR_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < n_ranges; ++i) {
-    if (ranges[i].hi < ranges[i].lo) return LMN_ERR_INVALID_ARGUMENT;
+    // same bounds as lut_values(): Fixed<12> values inside (-2^30, 2^30), so hi - lo + 1 cannot overflow
+    if (ranges[i].hi < ranges[i].lo || ranges[i].lo <= -(1ll << 30) || ranges[i].hi >= (1ll << 30)) return LMN_ERR_INVALID_ARGUMENT;
     count += (uint64_t)(ranges[i].hi - ranges[i].lo + 1);
+    if (count > (1ull << 26)) return LMN_ERR_INVALID_ARGUMENT;
   }
-  if (count > (1ull << 26)) return LMN_ERR_INVALID_ARGUMENT;
   // calculate_log_size: ceil(count / 16) rounded up to a power of two, times 16 (LOG_N_LANES = 4)
   uint64_t packs = (count + 15) >> 4, p2 = 1;
   uint32_t lg = 0;
@@ -332,6 +335,10 @@ int lmn_lut_from_ranges(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_r
     } else if (lut_kind == LMN_LUT_EXP2) {
       y = std::exp2(x);
     } else {
+      // Divergence from the reference, on purpose: Log2PreProcessed::gen_column (preprocessed.rs:517-549) feeds
+      // x <= 0 to f64::log2 and stores the saturated cast of NaN / -inf; such a row can never be looked up by a
+      // valid trace (log2 of a non-positive input has no fixed-point value), so a layout that contains one is
+      // rejected here instead of committing to a meaningless LUT row.
       if (vals[i] <= 0) return LMN_ERR_INVALID_ARGUMENT;
       y = std::log2(x);
     }

@@ -35,6 +35,12 @@ static lmn_col* new_col(uint32_t ncols, uint32_t log_size) {
   return c;
 }
 
+// field words crossing the C ABI must be canonical M31 (< 2^31 - 1), as the verifier enforces for proof bytes
+static void check_canonical(const uint32_t* w, uint64_t n, const char* what) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (w[i] >= P31) throw LmnError(LMN_ERR_INVALID_ARGUMENT, std::string(what) + " is not a canonical M31 word");
+}
+
 // frees a freshly allocated handle when the op that fills it throws
 struct ColGuard {
   lmn_col* c;
@@ -133,6 +139,7 @@ lmn_col* Context::col_extend(const lmn_col* co, uint32_t log_size) {
   return out.release();
 }
 void Context::col_eval_at_point(const lmn_col* co, uint32_t column, const uint32_t pt[8], uint32_t out[4]) {
+  check_canonical(pt, 8, "eval_at_point: point");
   if (column >= co->ncols) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "eval_at_point: column index out of range");
   arena_.reserve(8u << 20);
   begin_op();
@@ -145,7 +152,25 @@ void Context::col_eval_at_point(const lmn_col* co, uint32_t column, const uint32
   out[3] = r[0].d;
 }
 
+// frees a tree handle (and its device slab) when the op that fills it throws
+struct TreeGuard {
+  lmn_tree* t;
+  explicit TreeGuard(lmn_tree* t_) : t(t_) {}
+  ~TreeGuard() {
+    if (t) {
+      if (t->slab) lmn_dev_free(t->slab);
+      delete t;
+    }
+  }
+  lmn_tree* release() {
+    lmn_tree* r = t;
+    t = nullptr;
+    return r;
+  }
+};
+
 lmn_tree* Context::col_commit(const lmn_col* const* cols, uint32_t n) {
+  set_device();
   std::vector<ColRef> sorted;
   uint32_t max_log = 0;
   for (uint32_t k = 0; k < n; ++k) {
@@ -162,11 +187,11 @@ lmn_tree* Context::col_commit(const lmn_col* const* cols, uint32_t n) {
   reset_event_log();
   DevMerkle m;
   build_merkle(m, sorted);
-  lmn_tree* t = new lmn_tree{nullptr, {}, m.max_log, {}};
+  TreeGuard tg(new lmn_tree{nullptr, {}, m.max_log, {}});
+  lmn_tree* t = tg.t;
   try {
     t->slab = (uint32_t*)lmn_dev_malloc((16ull << m.max_log) * 4);
   } catch (const LmnError& e) {
-    delete t;
     throw LmnError(LMN_ERR_OUT_OF_MEMORY, std::string("tree allocation failed: ") + e.what());
   }
   t->layers.assign(m.max_log + 1, nullptr);
@@ -180,7 +205,7 @@ lmn_tree* Context::col_commit(const lmn_col* const* cols, uint32_t n) {
   lmn_sync(stream_);
   m.finish_root();
   t->root = m.root;
-  return t;
+  return tg.release();
 }
 void Context::tree_layer_to_cpu(const lmn_tree* t, uint32_t layer_log, uint8_t* out) {
   set_device();
@@ -206,7 +231,8 @@ void Context::col_accumulate(lmn_col* dst, const lmn_col* src) {
 lmn_col* Context::col_accumulate_quotients(const lmn_col* const* cols, uint32_t n, const uint32_t* sample_col,
                                            const uint32_t* sample_point, const uint32_t* sample_values, uint32_t nsamples,
                                            const uint32_t* points_xy, uint32_t npoints, const uint32_t alpha[4]) {
-  if (n == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "accumulate_quotients: no columns");
+  set_device();
+  if (n == 0 || !cols[0]) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "accumulate_quotients: no columns / null column handle");
   const uint32_t log_size = cols[0]->log_size;
   if (log_size < 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "accumulate_quotients: domain too small");
   std::vector<const uint32_t*> d_cols;
@@ -215,6 +241,9 @@ lmn_col* Context::col_accumulate_quotients(const lmn_col* const* cols, uint32_t 
     for (uint32_t j = 0; j < cols[k]->ncols; ++j) d_cols.push_back(cols[k]->d + ((uint64_t)j << log_size));
   }
   const uint32_t ncols = (uint32_t)d_cols.size();
+  check_canonical(points_xy, 8ull * npoints, "accumulate_quotients: point");
+  check_canonical(sample_values, 4ull * nsamples, "accumulate_quotients: sample value");
+  check_canonical(alpha, 4, "accumulate_quotients: alpha");
   std::vector<QPt> pts(npoints);
   for (uint32_t p = 0; p < npoints; ++p) {
     const uint32_t* w = points_xy + 8 * p;
@@ -246,6 +275,7 @@ static void check_secure(const lmn_col* c, const char* what) {
   if (c->ncols != 4) throw LmnError(LMN_ERR_INVALID_ARGUMENT, std::string(what) + ": a secure column has 4 coordinate columns");
 }
 lmn_col* Context::col_fold_line(const lmn_col* src, const uint32_t alpha[4]) {
+  check_canonical(alpha, 4, "fold_line: alpha");
   check_secure(src, "fold_line");
   if (src->log_size < 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "fold_line: nothing to fold");
   ensure_twiddles((int)src->log_size + 1);
@@ -259,6 +289,7 @@ lmn_col* Context::col_fold_line(const lmn_col* src, const uint32_t alpha[4]) {
   return out.release();
 }
 void Context::col_fold_circle_into_line(lmn_col* dst, const lmn_col* src, const uint32_t alpha[4]) {
+  check_canonical(alpha, 4, "fold_circle_into_line: alpha");
   check_secure(src, "fold_circle_into_line");
   check_secure(dst, "fold_circle_into_line");
   if (src->log_size < 1 || dst->log_size + 1 != src->log_size)

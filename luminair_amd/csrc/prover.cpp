@@ -1969,9 +1969,11 @@ void rccl_unique_id(uint8_t* out) {
 }
 void Context::set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id_bytes) {
   LMN_HIP_CHECK(hipSetDevice(device_));
+  {
+    lmn_collective probe{nullptr, &RcclTransport::all_gather, nullptr, nullptr};
+    check_shard_args(rank, world, fri_min_log, &probe);  // a rejected call leaves the current sharding untouched
+  }
   clear_shard();
-  if (world == 0 || (world & (world - 1)) || world > 8 || rank >= world)
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: world must be 1, 2, 4 or 8 and rank < world");
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof id);
   RcclTransport* t = new RcclTransport();
@@ -2007,7 +2009,7 @@ void Context::set_shard_rccl(uint32_t, uint32_t, uint32_t, const uint8_t*) {
 static void rccl_release(void*) {}
 #endif
 
-void Context::set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
+void Context::check_shard_args(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
   if (world == 0 || (world & (world - 1)) || world > 8 || rank >= world)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: world must be 1, 2, 4 or 8 and rank < world");
   if (!coll || !coll->all_gather) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: missing all_gather");
@@ -2016,6 +2018,13 @@ void Context::set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, con
   if (fri_min_log == 0) fri_min_log = 16;
   // a split quotient column / FRI layer needs at least 4 rows per rank
   if ((int)fri_min_log < g + 1 || fri_min_log > 30) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "shard: bad fri_min_log");
+}
+
+void Context::set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
+  check_shard_args(rank, world, fri_min_log, coll);
+  int g = 0;
+  while ((1u << g) < world) ++g;
+  if (fri_min_log == 0) fri_min_log = 16;
   lmn_sync(stream_);
   void* keep = shard_.rccl;
   shard_ = Shard{};

@@ -135,6 +135,7 @@ class Context {
   void op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]);
 
   // single-proof sharding (lmn_ctx_set_shard / lmn_ctx_set_shard_rccl)
+  static void check_shard_args(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll);
   void set_shard(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll);
   void set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id);
   void clear_shard();

@@ -289,7 +289,13 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     for (int k = 0; k < 3; ++k)
       if (kLookupKind[k] < n_slots && p.claim[kLookupKind[k]] >= 0) present |= 1u << k;
     if (LMN_KIND_RANGE_CHECK_LOOKUP < n_slots && p.claim[LMN_KIND_RANGE_CHECK_LOOKUP] >= 0) present |= LMN_LOOKUP_RANGE_CHECK;
-    if (settings->has_lookups && settings->has_lookups != present) fail("settings.lookups do not match the proof's claim");
+    // The sin / exp2 / log2 LUTs are named by the settings and must match exactly; the 8-bit range-check LUT is
+    // generated by the library whenever LessThan is present, so settings may or may not announce it (the
+    // pre-expanded `lookups` form does not) - it only must not be announced when the claim lacks it.
+    const uint32_t lut_bits = LMN_LOOKUP_SIN | LMN_LOOKUP_EXP2 | LMN_LOOKUP_LOG2;
+    if (settings->has_lookups & ~present) fail("settings announce a lookup the proof's claim lacks");
+    if ((settings->has_lookups & lut_bits) && (settings->has_lookups & lut_bits) != (present & lut_bits))
+      fail("settings.lookups do not match the proof's claim");
     if (settings->n_luts && !settings->luts) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null luts pointer");
     for (uint32_t i = 0; i < settings->n_luts; ++i) {
       const lmn_lut& l = settings->luts[i];

@@ -339,7 +339,9 @@ class LuminairProof:
                     continue
             raise LuminairError("SerializationError", "not a LuminairProof")
         names = _CLAIM_FIELDS[:8] if kat_era else _CLAIM_FIELDS
-        claim = {n: ({"log_size": r.take("<I")[0]} if r.tag() else None) for n in names}
+        # `Claim<T> { log_size, _marker: PhantomData<T> }` (components/mod.rs:149-152): serde writes PhantomData as
+        # null and `Deserialize` insists on the field, so the JSON form carries `"_marker": null`
+        claim = {n: ({"log_size": r.take("<I")[0], "_marker": None} if r.tag() else None) for n in names}
         iclaim = {n: ({"claimed_sum": r.q()} if r.tag() else None) for n in names}
         pow_bits, log_blowup, log_last = r.take("<III")
         n_queries = r.take("<Q")[0]

@@ -263,3 +263,37 @@ def test_emu_one_context_from_several_threads_is_serialised(emu_ctx):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not bad
+
+
+def test_emu_advice_r2_boundary_fixes(emu_ctx):
+    """a rejected lmn_ctx_set_shard keeps the context's current sharding; a NULL first column handle
+    and non-canonical field words at the level-2 boundary are INVALID_ARGUMENT, not a crash / silent wrap."""
+    import ctypes as C
+    E = backend.LuminairBackendError
+    calls = []
+    tabs = [(k, r, len(r)) for k, r in syn.config2_add_only(40, 2)]
+    want = emu_ctx.prove_tables(tabs)
+    emu_ctx.set_shard(0, 1, lambda buf, nbytes, stream: calls.append(nbytes))
+    with pytest.raises(E):
+        emu_ctx.set_shard(5, 3, lambda *a: None)            # rejected ...
+    n0 = len(calls)
+    assert emu_ctx.prove_tables(tabs) == want and len(calls) > n0   # ... and the world-1 shard is still active
+    emu_ctx.clear_shard()
+    a = emu_ctx.col_from_cpu(np.zeros((4, 64), np.uint32))
+    lib = emu_ctx.lib.lib
+    arr = (C.c_void_p * 2)(None, a.handle)
+    sc = (C.c_uint32 * 1)(0)
+    sv = (C.c_uint32 * 4)(0, 0, 0, 0)
+    pts = (C.c_uint32 * 8)(*([0] * 8))
+    al = (C.c_uint32 * 4)(1, 0, 0, 0)
+    out = C.c_void_p()
+    rc = lib.lmn_col_accumulate_quotients(emu_ctx.handle, arr, 2, sc, sc, sv, 1, pts, 1, al, C.byref(out))
+    assert rc == backend.ERR_INVALID_ARGUMENT and not out.value
+    P = (1 << 31) - 1
+    for fn in (lambda: a.eval_at_point(0, [P] + [0] * 7), lambda: a.fold_line((P, 0, 0, 0)),
+               lambda: emu_ctx.col_accumulate_quotients([a], [(0, 0, (0, P + 5, 0, 0))], [[0] * 8], (1, 0, 0, 0)),
+               lambda: emu_ctx.col_accumulate_quotients([a], [(0, 0, (0, 0, 0, 0))], [[0] * 8], (1, 0, 0, 1 << 31))):
+        with pytest.raises(E) as e:
+            fn()
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    a.free()

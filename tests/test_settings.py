@@ -113,7 +113,14 @@ def test_proof_json_round_trip(kat_bytes, lib):
     p = luminair_amd.LuminairProof(kat_bytes)
     d = json.loads(p.to_json())
     assert list(d["claim"]) == ["add", "mul", "recip", "sin", "sin_lookup", "sum_reduce", "max_reduce", "sqrt"]
-    assert d["claim"]["add"] == {"log_size": 4} and d["claim"]["recip"] is None
+    # serde writes `_marker: PhantomData<T>` of `Claim<T>` (components/mod.rs:149-152) as null and requires it back
+    assert d["claim"]["add"] == {"log_size": 4, "_marker": None} and d["claim"]["recip"] is None
+    assert '"_marker": null' in p.to_json()
+    stripped = json.loads(p.to_json())
+    for c in stripped["claim"].values():
+        if c is not None:
+            del c["_marker"]            # JSON written by round 2's mirror (no _marker) is still accepted
+    assert luminair_amd.LuminairProof.from_json(json.dumps(stripped)).to_bincode() == kat_bytes
     assert d["proof"]["config"] == {"pow_bits": 5, "fri_config": {"log_blowup_factor": 1, "log_last_layer_degree_bound": 0,
                                                                    "n_queries": 3}}
     assert len(d["proof"]["commitments"]) == 4 and len(d["proof"]["commitments"][0]) == 32
@@ -131,3 +138,45 @@ def test_proof_json_round_trip(kat_bytes, lib):
     with pytest.raises(luminair_amd.LuminairError):
         luminair_amd.LuminairProof(kat_bytes[:-1]).to_json()
     ctx.close()
+
+
+def test_verify_with_lookups_form_settings_and_a_range_check_claim(lib):
+    """a sin + LessThan proof verified with the pre-expanded `lookups` form of the settings - which
+    names the sin LUT but not the library-generated 8-bit range-check LUT - must be accepted, as must settings that do
+    announce the range check; settings announcing a lookup the claim lacks are still rejected."""
+    ranges = {"sin": (-300, 200)}
+    tabs, luts = syn.activation_graph(30, 4, names=("sin",), ranges=ranges)
+    lt = syn.less_than_graph(30, 5)
+    # one pie: the sin graph's tables + the LessThan graph's (each graph's logup sums cancel on their own, and the
+    # relation is linear, so shared tensor ids do no harm)
+    merged = {}
+    for k, r in tabs + lt:
+        merged[k] = np.concatenate([merged[k], r]) if k in merged else r
+    tables = sorted(merged.items())
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    proof = luminair_amd.LuminairProof(ctx.prove_tables([(k, r, len(r)) for k, r in tables], luts))
+    ctx.close()
+    luminair_amd.verify(proof, None, backend.VARIANT_PINNED, library=lib)
+    luminair_amd.verify(proof, CircuitSettings(lookups={"sin": luts["sin"]}), backend.VARIANT_PINNED, library=lib)
+    luminair_amd.verify(proof, CircuitSettings(lookups={"sin": luts["sin"]}, range_check=RangeCheckLookup([8], 8, [0] * 256)),
+                        backend.VARIANT_PINNED, library=lib)
+    with pytest.raises(luminair_amd.LuminairError):     # exp2 announced, not in the claim
+        luminair_amd.verify(proof, CircuitSettings(lookups={"sin": luts["sin"], "exp2": luts["sin"]}),
+                            backend.VARIANT_PINNED, library=lib)
+    # a proof WITHOUT LessThan, verified with settings that announce the range check: rejected
+    ctx = backend.Context(0, cfg, lib)
+    p2 = luminair_amd.LuminairProof(ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts))
+    ctx.close()
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.verify(p2, CircuitSettings(lookups={"sin": luts["sin"]}, range_check=RangeCheckLookup([8], 8, [0] * 256)),
+                            backend.VARIANT_PINNED, library=lib)
+
+
+def test_lut_log_size_bounds_its_ranges(lib):
+    """`hi - lo + 1` on unbounded i64 ranges overflowed before the 2^26 cap applied."""
+    for rng in ([(-(1 << 62), (1 << 62))], [(-(1 << 63), (1 << 63) - 1)], [(0, 1 << 30)], [(-(1 << 30), 0)]):
+        with pytest.raises(backend.LuminairBackendError):
+            lib.lut_log_size(rng)
+    assert lib.lut_log_size([(-(1 << 30) + 1, -(1 << 30) + 16)]) == 4
