@@ -1,0 +1,277 @@
+// Third, independent measurement of the gfx950 VALU issue rate: round 2's microbenchmark printed
+// two figures that disagree by 1.8x (e.g. blake2s_G, 8 waves per SIMD: 0.446 wave-instructions/clk/SIMD from the
+// waves' own s_memtime stamps, 0.249 from wall time).  This tool records, for EVERY wave, its start and end shader
+// clock (s_memtime), its 100 MHz real-time stamps and WHERE it ran (HW_ID: SE / CU / SIMD, XCC_ID), and derives per
+// SIMD:
+//   per-wave   = instructions of the SIMD's waves / MEAN elapsed cycles of those waves      (round 2's first figure)
+//   makespan   = instructions of the SIMD's waves / (last end - first start) on that SIMD   (what the SIMD delivered)
+//   wall       = all instructions / (HIP-event time x measured shader clock) / SIMDs used   (round 2's second figure)
+// plus the placement proof (distinct XCCs / CUs / SIMDs, waves per SIMD min..max) and how far apart the waves of one
+// SIMD finish (oldest-first arbitration makes co-resident waves finish one after the other, so the MEAN elapsed time
+// of a SIMD's waves is shorter than the time the SIMD was busy: that is the whole discrepancy).
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench_reconcile.hip -o tools/bin/mb_reconcile && tools/bin/mb_reconcile
+// Under rocprofv3 (--pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace) run it with
+// `mb_reconcile pmc`: one launch per stream at 8 waves per SIMD only, so that kernel names map to streams.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+constexpr int ILP = 8;
+constexpr int UNROLL = 8;
+
+struct WaveRec {
+  uint64_t t0, t1, r0, r1;
+  uint32_t hw_id, xcc_id;
+};
+
+#define HWREG_ALL(id) ((31 << 11) | (id))
+__device__ __forceinline__ void stamp_begin(WaveRec& w) {
+  w.hw_id = __builtin_amdgcn_s_getreg(HWREG_ALL(4));    // HW_REG_HW_ID
+  w.xcc_id = __builtin_amdgcn_s_getreg(HWREG_ALL(20));  // HW_REG_XCC_ID
+  w.r0 = __builtin_amdgcn_s_memrealtime();
+  w.t0 = __builtin_readcyclecounter();
+}
+__device__ __forceinline__ void stamp_end(WaveRec& w, WaveRec* out) {
+  w.t1 = __builtin_readcyclecounter();
+  w.r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63u) == 0) out[(uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = w;
+}
+
+#define STREAM_KERNEL(name, BODY, INSTR_PER_ITER)                                                  \
+  __global__ void __launch_bounds__(256) name(uint32_t* out, WaveRec* recs, int iters) {           \
+    uint32_t v[ILP], w[ILP];                                                                       \
+    _Pragma("unroll") for (int k = 0; k < ILP; ++k) {                                              \
+      v[k] = threadIdx.x * 2654435761u + k;                                                        \
+      w[k] = threadIdx.x * 40503u + 977u * k + blockIdx.x;                                         \
+    }                                                                                              \
+    const uint32_t b = threadIdx.x | 1u, c = blockIdx.x + 7u;                                      \
+    (void)b; (void)c;                                                                              \
+    WaveRec rec;                                                                                   \
+    __syncthreads();                                                                               \
+    stamp_begin(rec);                                                                              \
+    for (int it = 0; it < iters; ++it) {                                                           \
+      _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                         \
+        _Pragma("unroll") for (int k = 0; k < ILP; ++k) { BODY; }                                  \
+      }                                                                                            \
+    }                                                                                              \
+    stamp_end(rec, recs);                                                                          \
+    uint32_t acc = 0;                                                                              \
+    _Pragma("unroll") for (int k = 0; k < ILP; ++k) acc ^= v[k] ^ w[k];                            \
+    if (acc == 0x12345678u) out[0] = acc;                                                          \
+  }                                                                                                \
+  static const int name##_ipi = (INSTR_PER_ITER);
+
+// one-instruction streams: ILP independent chains; second operands are loop constants shared by all chains
+STREAM_KERNEL(k_add_u32, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k]) : "v"(b)), ILP* UNROLL)
+STREAM_KERNEL(k_fma_f32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(c)), ILP* UNROLL)
+STREAM_KERNEL(k_add3_u32, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(c)), ILP* UNROLL)
+STREAM_KERNEL(k_alignbit_b32, asm volatile("v_alignbit_b32 %0, %0, %0, 12" : "+v"(v[k])), ILP* UNROLL)
+// the plain two-operand op with a DIFFERENT live register as second source in every chain (operand-cache question)
+STREAM_KERNEL(k_xor_distinct, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[k]) : "v"(w[k])), ILP* UNROLL)
+STREAM_KERNEL(k_add3_distinct, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(w[k]), "v"(w[(k + 1) % ILP])),
+              ILP* UNROLL)
+
+// the Blake2s quarter round as the Merkle kernel issues it: 12 instructions, 4 independent states per lane
+__global__ void __launch_bounds__(256) k_blake2s_G(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        asm volatile(
+            "v_add3_u32 %0, %0, %1, %4\n v_xor_b32 %3, %3, %0\n v_alignbit_b32 %3, %3, %3, 16\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_alignbit_b32 %1, %1, %1, 12\n"
+            "v_add3_u32 %0, %0, %1, %5\n v_xor_b32 %3, %3, %0\n v_alignbit_b32 %3, %3, %3, 8\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_alignbit_b32 %1, %1, %1, 7\n"
+            : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]), "+v"(d[k])
+            : "v"(mx), "v"(my));
+      }
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ipi = 4 * 4 * 12;
+
+// the same quarter round made of plain two-operand ops only (add3 -> 2 adds, rotation -> shift, shift, or; every
+// state has its own temporary): 22 instructions
+__global__ void __launch_bounds__(256) k_blake2s_G_plain(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4], t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+    t[k] = 0;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        asm volatile(
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %5\n v_xor_b32 %3, %3, %0\n v_lshrrev_b32 %4, 16, %3\n v_lshlrev_b32 %3, 16, %3\n v_or_b32 %3, %3, %4\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_lshrrev_b32 %4, 12, %1\n v_lshlrev_b32 %1, 20, %1\n v_or_b32 %1, %1, %4\n"
+            "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %6\n v_xor_b32 %3, %3, %0\n v_lshrrev_b32 %4, 8, %3\n v_lshlrev_b32 %3, 24, %3\n v_or_b32 %3, %3, %4\n"
+            "v_add_u32 %2, %2, %3\n v_xor_b32 %1, %1, %2\n v_lshrrev_b32 %4, 7, %1\n v_lshlrev_b32 %1, 25, %1\n v_or_b32 %1, %1, %4\n"
+            : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]), "+v"(d[k]), "+v"(t[k])
+            : "v"(mx), "v"(my));
+      }
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k] ^ t[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_plain_ipi = 4 * 4 * 22;
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                     \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+typedef void (*kern_t)(uint32_t*, WaveRec*, int);
+
+static void run(const char* label, kern_t k, int ipi, int W, int n_cu, int iters, uint32_t* d_out, WaveRec* d_recs,
+                bool verbose) {
+  const int blocks = n_cu * W;  // 256-thread workgroups: one wave per SIMD each, W workgroups per CU
+  const int waves = blocks * 4;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d_out, d_recs, 16);  // warm-up (code object, clocks)
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d_out, d_recs, iters);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipDeviceSynchronize());
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<WaveRec> r(waves);
+  CHECK(hipMemcpy(r.data(), d_recs, sizeof(WaveRec) * waves, hipMemcpyDeviceToHost));
+  const double instr_per_wave = (double)ipi * iters;
+  struct Simd {
+    int n = 0;
+    uint64_t first = ~0ull, last = 0, tmin = ~0ull, tmax = 0;
+    double sum_elapsed = 0;
+  };
+  std::map<uint64_t, Simd> simds;
+  std::map<uint64_t, int> cus, xccs;
+  double clk_ticks = 0, rt_ticks = 0;
+  for (auto& w : r) {
+    const uint64_t simd = (w.hw_id >> 4) & 3u, loc = (w.hw_id >> 8) & 0xFFu;  // cu_id[11:8] sh_id[12] se_id[15:13]
+    const uint64_t cu_key = ((uint64_t)(w.xcc_id & 0xF) << 8) | loc;
+    Simd& s = simds[(cu_key << 2) | simd];
+    s.n++;
+    s.first = std::min(s.first, w.t0);
+    s.last = std::max(s.last, w.t1);
+    s.tmin = std::min(s.tmin, w.t1 - w.t0);
+    s.tmax = std::max(s.tmax, w.t1 - w.t0);
+    s.sum_elapsed += (double)(w.t1 - w.t0);
+    cus[cu_key]++;
+    xccs[w.xcc_id & 0xF]++;
+    clk_ticks += (double)(w.t1 - w.t0);
+    rt_ticks += (double)(w.r1 - w.r0);
+  }
+  const double mhz = clk_ticks / rt_ticks * 100.0;  // s_memrealtime ticks at 100 MHz
+  double per_wave = 0, makespan = 0, spread = 0;
+  int nmin = 1 << 30, nmax = 0;
+  for (auto& kv : simds) {
+    const Simd& s = kv.second;
+    per_wave += s.n * instr_per_wave / (s.sum_elapsed / s.n);
+    makespan += s.n * instr_per_wave / (double)(s.last - s.first);
+    spread += (double)s.tmin / (double)s.tmax;
+    nmin = std::min(nmin, s.n);
+    nmax = std::max(nmax, s.n);
+  }
+  per_wave /= simds.size();
+  makespan /= simds.size();
+  spread /= simds.size();
+  const double wall = (double)waves * instr_per_wave / (ms * 1e-3 * mhz * 1e6) / (double)simds.size();
+  printf("%-18s w=%d  per-wave %.3f  makespan %.3f  wall %.3f   [clk %4.0f MHz, %.3f ms; %zu XCCs, %zu CUs, %zu SIMDs, "
+         "waves/SIMD %d..%d, shortest/longest wave on a SIMD %.2f]\n",
+         label, W, per_wave, makespan, wall, mhz, ms, xccs.size(), cus.size(), simds.size(), nmin, nmax, spread);
+  if (verbose) {
+    // one SIMD in detail: every wave's start and end relative to the SIMD's first start
+    const auto& kv = *simds.begin();
+    printf("    SIMD %llx:", (unsigned long long)kv.first);
+    std::vector<std::pair<uint64_t, uint64_t>> ws;
+    for (auto& w : r) {
+      const uint64_t simd = (w.hw_id >> 4) & 3u, loc = (w.hw_id >> 8) & 0xFFu;
+      if (((((uint64_t)(w.xcc_id & 0xF) << 8) | loc) << 2 | simd) == kv.first) ws.push_back({w.t0, w.t1});
+    }
+    std::sort(ws.begin(), ws.end());
+    for (auto& p : ws) printf("  [%llu..%llu]", (unsigned long long)(p.first - kv.second.first), (unsigned long long)(p.second - kv.second.first));
+    printf("  cycles\n");
+  }
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
+int main(int argc, char** argv) {
+  const bool pmc = argc > 1 && !strcmp(argv[1], "pmc");
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int n_cu = prop.multiProcessorCount;
+  uint32_t* d_out;
+  WaveRec* d_recs;
+  CHECK(hipMalloc(&d_out, 64));
+  CHECK(hipMalloc(&d_recs, sizeof(WaveRec) * (size_t)n_cu * 8 * 4));
+  printf("device %s  CUs %d  nominal clock %d MHz\n", prop.name, n_cu, prop.clockRate / 1000);
+  printf("wave-instructions / shader clock / SIMD.  per-wave: from the MEAN elapsed s_memtime of a SIMD's waves; makespan: from "
+         "first start to last end on the SIMD; wall: HIP events x measured clock\n");
+  struct S {
+    const char* label;
+    kern_t k;
+    int ipi;
+  } streams[] = {
+      {"add_u32", k_add_u32, k_add_u32_ipi},
+      {"fma_f32", k_fma_f32, k_fma_f32_ipi},
+      {"xor distinct-src", k_xor_distinct, k_xor_distinct_ipi},
+      {"add3_u32", k_add3_u32, k_add3_u32_ipi},
+      {"add3 distinct-src", k_add3_distinct, k_add3_distinct_ipi},
+      {"alignbit_b32", k_alignbit_b32, k_alignbit_b32_ipi},
+      {"blake2s_G", k_blake2s_G, k_blake2s_G_ipi},
+      {"blake2s_G plain", k_blake2s_G_plain, k_blake2s_G_plain_ipi},
+  };
+  for (auto& s : streams) {
+    const int iters = (int)(4096ll * 64 / s.ipi);
+    if (pmc) {
+      run(s.label, s.k, s.ipi, 8, n_cu, iters, d_out, d_recs, false);
+      continue;
+    }
+    for (int W : {1, 2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, iters, d_out, d_recs, W == 8 && (s.k == k_add3_u32 || s.k == k_blake2s_G));
+  }
+  return 0;
+}
