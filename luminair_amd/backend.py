@@ -99,11 +99,11 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
            "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
            "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
-           "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
+           "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_view", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
            "lmn_col_commit", "lmn_tree_root", "lmn_tree_log_size", "lmn_tree_layer_to_cpu", "lmn_tree_free",
            "lmn_col_accumulate", "lmn_col_accumulate_quotients", "lmn_col_fold_line", "lmn_col_fold_circle_into_line",
-           "lmn_col_decompose", "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
+           "lmn_col_decompose", "lmn_col_logup", "lmn_col_composition", "lmn_kind_constraints", "lmn_kind_relations", "lmn_ctx_set_shard", "lmn_rccl_unique_id", "lmn_ctx_set_shard_rccl", "lmn_ctx_clear_shard"]
 
 
 class LuminairBackendError(RuntimeError):
@@ -171,6 +171,7 @@ class Library:
         lib.lmn_col_log_size.restype = U32
         lib.lmn_col_device_ptr.argtypes = [VP]
         lib.lmn_col_device_ptr.restype = VP
+        lib.lmn_col_view.argtypes = [VP, VP, U32, U32, C.POINTER(VP)]
         lib.lmn_col_bit_reverse.argtypes = [VP, VP]
         lib.lmn_col_precompute_twiddles.argtypes = [VP, U32]
         lib.lmn_col_interpolate.argtypes = [VP, VP]
@@ -190,6 +191,12 @@ class Library:
         lib.lmn_col_fold_line.argtypes = [VP, VP, VP, C.POINTER(VP)]
         lib.lmn_col_fold_circle_into_line.argtypes = [VP, VP, VP, VP]
         lib.lmn_col_decompose.argtypes = [VP, VP, C.POINTER(VP), VP]
+        lib.lmn_col_logup.argtypes = [VP, U32, VP, VP, VP, C.POINTER(VP), VP]
+        lib.lmn_col_composition.argtypes = [VP, U32, VP, VP, VP, VP, VP, VP, U32, VP]
+        lib.lmn_kind_constraints.argtypes = [U32]
+        lib.lmn_kind_constraints.restype = U32
+        lib.lmn_kind_relations.argtypes = [U32]
+        lib.lmn_kind_relations.restype = U32
         lib.lmn_ctx_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(LmnCollective)]
         lib.lmn_rccl_unique_id.argtypes = [C.c_void_p]
         lib.lmn_ctx_set_shard_rccl.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -321,6 +328,10 @@ class Col:
         if self.handle:
             self.ctx.lib.lib.lmn_col_free(self.ctx.handle, self.handle)
             self.handle = None
+
+    def view(self, first: int, n: int) -> "Col":
+        """Non-owning handle over columns [first, first + n) (valid while this handle lives)."""
+        return self._new(self.ctx.lib.lib.lmn_col_view, first, n)
 
     def bit_reverse(self) -> "Col":
         self.ctx._check(self.ctx.lib.lib.lmn_col_bit_reverse(self.ctx.handle, self.handle))
@@ -464,6 +475,39 @@ class Context:
             self.handle, arr, len(cols), sc.ctypes.data, sp.ctypes.data, sv.ctypes.data, len(samples), pts.ctypes.data,
             len(points), al, C.byref(out)))
         return Col(self, out)
+
+    N_ELEMS = 5   # LMN_N_ELEMS: NodeElements, RangeCheck, Sin, Exp2, Log2
+
+    @staticmethod
+    def _elems_words(elems):
+        """elems: {set index: (z words, alpha words)} or a flat sequence of N_ELEMS * 8 words"""
+        if isinstance(elems, dict):
+            flat = [0] * (8 * Context.N_ELEMS)
+            for e, (z, a) in elems.items():
+                flat[8 * e:8 * e + 4] = [int(v) for v in z]
+                flat[8 * e + 4:8 * e + 8] = [int(v) for v in a]
+            elems = flat
+        if len(elems) != 8 * Context.N_ELEMS:
+            raise ValueError("elems: %d words expected" % (8 * Context.N_ELEMS))
+        return (C.c_uint32 * (8 * Context.N_ELEMS))(*[int(v) for v in elems])
+
+    def col_logup(self, kind: int, main: Col, pre: Optional[Col], elems) -> Tuple[Col, Tuple[int, int, int, int]]:
+        """`write_interaction_trace` of component `kind` on resident columns -> (interaction columns, claimed sum)."""
+        out = C.c_void_p()
+        claimed = (C.c_uint32 * 4)()
+        self._check(self.lib.lib.lmn_col_logup(self.handle, kind, main.handle, pre.handle if pre is not None else None,
+                                               self._elems_words(elems), C.byref(out), claimed))
+        return Col(self, out), tuple(int(v) for v in claimed)
+
+    def col_composition(self, kind: int, main_lde: Col, inter_lde: Col, pre_lde: Optional[Col], elems, claimed, coeffs,
+                        acc: Col) -> Col:
+        """acc += sum_k constraint_k * coeffs[k] / Z of component `kind` on its evaluation domain."""
+        cw = (C.c_uint32 * (4 * len(coeffs)))(*[int(v) for c in coeffs for v in c])
+        cl = (C.c_uint32 * 4)(*[int(v) for v in claimed])
+        self._check(self.lib.lib.lmn_col_composition(
+            self.handle, kind, main_lde.handle, inter_lde.handle, pre_lde.handle if pre_lde is not None else None,
+            self._elems_words(elems), cl, cw, len(coeffs), acc.handle))
+        return acc
 
     # ---- single-proof sharding (lmn_ctx_set_shard*)
     def set_shard(self, rank: int, world: int, all_gather, fri_min_log: int = 0):

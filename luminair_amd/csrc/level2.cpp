@@ -9,6 +9,7 @@
 struct lmn_col {
   uint32_t* d;
   uint32_t ncols, log_size;
+  bool view = false;  // aliases columns of another handle (lmn_col_view): does not own `d`
   uint64_t words() const { return (uint64_t)ncols << log_size; }
 };
 struct lmn_tree {
@@ -25,7 +26,7 @@ constexpr uint32_t COL_MAX_LOG = 27;  // 2^26-row traces have 2^27-row LDEs
 static lmn_col* new_col(uint32_t ncols, uint32_t log_size) {
   if (ncols == 0 || ncols > 4096 || log_size > COL_MAX_LOG)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "column handle: bad shape");
-  lmn_col* c = new lmn_col{nullptr, ncols, log_size};
+  lmn_col* c = new lmn_col{nullptr, ncols, log_size, false};
   try {
     c->d = (uint32_t*)lmn_dev_malloc(c->words() * 4);
   } catch (const LmnError& e) {
@@ -78,10 +79,18 @@ void Context::col_to_cpu(const lmn_col* c, uint32_t* host) {
 }
 void Context::col_free(lmn_col* c) {
   if (!c) return;
+  if (c->view) {
+    delete c;
+    return;
+  }
   set_device();
   lmn_sync(stream_);  // stream-ordered ops may still read it
   lmn_dev_free(c->d);
   delete c;
+}
+lmn_col* Context::col_view(const lmn_col* c, uint32_t first, uint32_t n) {
+  if (n == 0 || first >= c->ncols || n > c->ncols - first) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: column range out of bounds");
+  return new lmn_col{c->d + ((uint64_t)first << c->log_size), n, c->log_size, true};
 }
 
 void Context::col_bit_reverse(lmn_col* c) {
@@ -321,6 +330,112 @@ lmn_col* Context::col_decompose(const lmn_col* f, uint32_t lambda_out[4]) {
   return gg.release();
 }
 
+// ---- the per-component stages on handles (the same launches Context::prove makes)
+static const ComponentSpec* spec_or_throw(uint32_t kind, const char* what) {
+  const ComponentSpec* sp = component_spec((int)kind);
+  if (!sp) throw LmnError(LMN_ERR_INVALID_ARGUMENT, std::string(what) + ": unknown component kind");
+  return sp;
+}
+static QM31 q_words(const uint32_t* w) { return QM31{w[0], w[1], w[2], w[3]}; }
+
+lmn_col* Context::col_logup(uint32_t kind, const lmn_col* main, const lmn_col* pre, const uint32_t* elems,
+                            uint32_t claimed_out[4]) {
+  set_device();
+  const ComponentSpec* sp = spec_or_throw(kind, "logup");
+  if ((int)main->ncols != sp->n_cols) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "logup: wrong number of trace columns for this kind");
+  if (main->log_size < 4 || main->log_size > 26) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "logup: trace log size must be 4..26");
+  if (sp->n_pre && (!pre || (int)pre->ncols != sp->n_pre || pre->log_size != main->log_size))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "logup: this kind needs its preprocessed columns (same size as the trace)");
+  check_canonical(elems, 8ull * N_ELEMS, "logup: relation element");
+  const uint64_t n = 1ull << main->log_size;
+  const int nic = 4 * sp->n_rel;
+  const int nb = logup_num_blocks((uint32_t)n);
+  arena_.reserve(n * sizeof(QM31) + (size_t)nb * 16 + (size_t)logup_scan_num_blocks((int)main->log_size) * sizeof(QM31) + (4u << 20));
+  begin_op();
+  ColGuard out(new_col((uint32_t)nic, main->log_size));
+  LogupArgs a{};
+  a.k = sp->n_rel;
+  for (int j = 0; j < sp->n_rel; ++j) {
+    auto column = [&](int idx) -> const uint32_t* { return (sp->rel_pre[j] ? pre->d : main->d) + (uint64_t)idx * n; };
+    a.val[j] = column(sp->rel_val[j]);
+    a.id[j] = sp->rel_id[j] >= 0 ? column(sp->rel_id[j]) : nullptr;
+    a.mult[j] = main->d + (uint64_t)sp->rel_mult[j] * n;
+    a.neg[j] = sp->rel_neg[j];
+    a.z[j] = q_words(elems + 8 * sp->rel_elems[j]);
+    a.alpha[j] = q_words(elems + 8 * sp->rel_elems[j] + 4);
+  }
+  a.inter = out.c->d;
+  a.last_tmp = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
+  a.partials = arena_.alloc_words((size_t)nb * 4);
+  a.n = (uint32_t)n;
+  launch_logup_fracs(a, stream_);
+  QM31* d_cs = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
+  launch_logup_reduce(a.partials, nb, m_inv((uint32_t)(n % P31)), d_cs, stream_);
+  QM31* bsums = (QM31*)arena_.alloc_bytes((size_t)logup_scan_num_blocks((int)main->log_size) * sizeof(QM31));
+  launch_logup_scan(a.last_tmp, d_cs, (int)main->log_size, out.c->d + (uint64_t)(nic - 4) * n, bsums, stream_);
+  const QM31* cs = (const QM31*)stage_download(d_cs, 2 * sizeof(QM31));
+  lmn_sync(stream_);
+  claimed_out[0] = cs[0].a;
+  claimed_out[1] = cs[0].b;
+  claimed_out[2] = cs[0].c;
+  claimed_out[3] = cs[0].d;
+  return out.release();
+}
+
+void Context::col_composition(uint32_t kind, const lmn_col* main_lde, const lmn_col* inter_lde, const lmn_col* pre_lde,
+                              const uint32_t* elems, const uint32_t claimed[4], const uint32_t* coeffs, uint32_t n_coeffs,
+                              lmn_col* acc) {
+  set_device();
+  const ComponentSpec* sp = spec_or_throw(kind, "composition");
+  const int e = (int)main_lde->log_size, ls = e - 1;
+  if (ls < 4 || ls > 26) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "composition: evaluation domain log size must be 5..27");
+  if ((int)main_lde->ncols != sp->n_cols || (int)inter_lde->ncols != 4 * sp->n_rel || (int)inter_lde->log_size != e)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "composition: trace / interaction columns do not match this kind");
+  if (sp->n_pre && (!pre_lde || (int)pre_lde->ncols != sp->n_pre || (int)pre_lde->log_size != e))
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "composition: this kind needs its preprocessed columns on the evaluation domain");
+  if ((int)n_coeffs != sp->n_local + sp->n_rel) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "composition: one coefficient per constraint");
+  if (acc->ncols != 4 || (int)acc->log_size != e) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "composition: accumulator must be 4 x 2^(k+1)");
+  check_canonical(elems, 8ull * N_ELEMS, "composition: relation element");
+  check_canonical(claimed, 4, "composition: claimed sum");
+  check_canonical(coeffs, 4ull * n_coeffs, "composition: coefficient");
+  arena_.reserve(4u << 20);
+  begin_op();
+  const uint64_t E = 1ull << e;
+  CompositionArgs a{};
+  a.kind = sp->kind;
+  a.log_size = ls;
+  a.eval_log = e;
+  a.main = main_lde->d;
+  a.inter = inter_lde->d;
+  a.row0 = 0;
+  a.n_rows = (uint32_t)E;
+  a.stride = E;
+  a.prev_last = a.inter + (uint64_t)(4 * (sp->n_rel - 1)) * E;
+  a.out = acc->d;
+  a.accumulate = 1;
+  a.z = q_words(elems + 8 * ELEMS_NODE);
+  a.alpha = q_words(elems + 8 * ELEMS_NODE + 4);
+  for (int j = 0; j < sp->n_rel; ++j)
+    if (sp->rel_elems[j] != ELEMS_NODE) {
+      a.z2 = q_words(elems + 8 * sp->rel_elems[j]);
+      a.alpha2 = q_words(elems + 8 * sp->rel_elems[j] + 4);
+    }
+  a.pre = sp->n_pre >= 1 ? pre_lde->d : nullptr;
+  a.pre2 = sp->n_pre >= 2 ? pre_lde->d + E : nullptr;
+  const QM31 cl = q_words(claimed);
+  std::vector<QM31> cs{cl, q_mul_m(cl, m_inv((uint32_t)((1ull << ls) % P31)))};
+  a.claimed_shift = upload_vec(cs);
+  for (uint32_t k = 0; k < n_coeffs; ++k) a.coeff[k] = q_words(coeffs + 4 * k);
+  for (int b = 0; b < 2; ++b) {
+    Pt p = domain_point(e, (uint32_t)b << ls);
+    uint32_t x = p.x;
+    for (int k = 0; k < ls - 1; ++k) x = m_sub(m_dbl(m_sqr(x)), 1u);
+    a.zinv[b] = m_inv(x);
+  }
+  launch_composition(a, stream_);
+  lmn_sync(stream_);  // [claimed, shift] lives in the arena, which the next op resets
+}
+
 }  // namespace lmn
 
 // ------------------------------------------------------------------------------------ extern "C"
@@ -425,6 +540,33 @@ int lmn_col_fold_line(lmn_ctx* ctx, const lmn_col* src, const uint32_t alpha[4],
 int lmn_col_fold_circle_into_line(lmn_ctx* ctx, lmn_col* dst, const lmn_col* src, const uint32_t alpha[4]) {
   if (!ctx || !dst || !src || !alpha) return LMN_ERR_INVALID_ARGUMENT;
   return guard2(ctx, [&] { ctx->impl->col_fold_circle_into_line(dst, src, alpha); });
+}
+int lmn_col_view(lmn_ctx* ctx, const lmn_col* col, uint32_t first, uint32_t n, lmn_col** out) {
+  if (!ctx || !col || !out) return LMN_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guard2(ctx, [&] { *out = ctx->impl->col_view(col, first, n); });
+}
+int lmn_col_logup(lmn_ctx* ctx, uint32_t kind, const lmn_col* main, const lmn_col* pre, const uint32_t* elems,
+                  lmn_col** interaction_out, uint32_t claimed_sum_out[4]) {
+  if (!ctx || !main || !elems || !interaction_out || !claimed_sum_out) return LMN_ERR_INVALID_ARGUMENT;
+  *interaction_out = nullptr;
+  return guard2(ctx, [&] { *interaction_out = ctx->impl->col_logup(kind, main, pre, elems, claimed_sum_out); });
+}
+int lmn_col_composition(lmn_ctx* ctx, uint32_t kind, const lmn_col* main_lde, const lmn_col* inter_lde,
+                        const lmn_col* pre_lde, const uint32_t* elems, const uint32_t claimed_sum[4],
+                        const uint32_t* coeffs, uint32_t n_coeffs, lmn_col* acc) {
+  if (!ctx || !main_lde || !inter_lde || !elems || !claimed_sum || !coeffs || !acc) return LMN_ERR_INVALID_ARGUMENT;
+  return guard2(ctx, [&] {
+    ctx->impl->col_composition(kind, main_lde, inter_lde, pre_lde, elems, claimed_sum, coeffs, n_coeffs, acc);
+  });
+}
+uint32_t lmn_kind_constraints(uint32_t kind) {
+  const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
+  return s ? (uint32_t)(s->n_local + s->n_rel) : 0u;
+}
+uint32_t lmn_kind_relations(uint32_t kind) {
+  const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
+  return s ? (uint32_t)s->n_rel : 0u;
 }
 int lmn_col_decompose(lmn_ctx* ctx, const lmn_col* f, lmn_col** g_out, uint32_t lambda_out[4]) {
   if (!ctx || !f || !g_out || !lambda_out) return LMN_ERR_INVALID_ARGUMENT;

@@ -145,6 +145,7 @@ class Context {
   lmn_col* col_from_cpu(const uint32_t* host, uint32_t ncols, uint32_t log_size);
   void col_to_cpu(const lmn_col* c, uint32_t* host);
   void col_free(lmn_col* c);
+  lmn_col* col_view(const lmn_col* c, uint32_t first, uint32_t n);
   void col_bit_reverse(lmn_col* c);
   void col_precompute_twiddles(uint32_t log_size);
   void col_interpolate(lmn_col* c);
@@ -162,6 +163,10 @@ class Context {
   lmn_col* col_fold_line(const lmn_col* src, const uint32_t alpha[4]);
   void col_fold_circle_into_line(lmn_col* dst, const lmn_col* src, const uint32_t alpha[4]);
   lmn_col* col_decompose(const lmn_col* f, uint32_t lambda_out[4]);
+  lmn_col* col_logup(uint32_t kind, const lmn_col* main, const lmn_col* pre, const uint32_t* elems, uint32_t claimed_out[4]);
+  void col_composition(uint32_t kind, const lmn_col* main_lde, const lmn_col* inter_lde, const lmn_col* pre_lde,
+                       const uint32_t* elems, const uint32_t claimed[4], const uint32_t* coeffs, uint32_t n_coeffs,
+                       lmn_col* acc);
 
   void* upload(const void* host, size_t bytes);
   void* device_alloc(size_t bytes);
