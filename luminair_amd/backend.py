@@ -46,15 +46,15 @@ LUT_KINDS = {"sin": 0, "exp2": 1, "log2": 2}   # LMN_LUT_*
 
 class LmnView(C.Structure):
     """Strided view of a device tensor (`lmn_view`): shape of the op's output, strides in elements, 0 = expanded."""
-    _fields_ = [("ndim", C.c_uint32), ("shape", C.c_uint32 * 4), ("strides", C.c_int64 * 4)]
+    _fields_ = [("ndim", C.c_uint32), ("shape", C.c_uint32 * 4), ("strides", C.c_int64 * 4), ("offset", C.c_int64)]
 
     @staticmethod
-    def make(shape, strides) -> "LmnView":
+    def make(shape, strides, offset: int = 0) -> "LmnView":
         n = len(shape)
         if not 1 <= n <= 4:
             raise ValueError("views have 1..4 dimensions")
         return LmnView(n, (C.c_uint32 * 4)(*(list(shape) + [0] * (4 - n))),
-                       (C.c_int64 * 4)(*(list(strides) + [0] * (4 - n))))
+                       (C.c_int64 * 4)(*(list(strides) + [0] * (4 - n))), int(offset))
 
 
 class LmnNodeInfo(C.Structure):
@@ -97,7 +97,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
+           "lmn_trace_elementwise_v", "lmn_trace_contiguous", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
            "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
            "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_view", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
@@ -204,6 +204,8 @@ class Library:
         lib.lmn_trace_elementwise_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_void_p,
                                                 C.POINTER(LmnView), C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p,
                                                 C.c_uint64, C.c_void_p]
+        lib.lmn_trace_contiguous.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(LmnView), C.c_uint64,
+                                             C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_lut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_uint64,
                                       C.POINTER(LmnNodeInfo), C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p]
@@ -595,6 +597,21 @@ class Context:
                 self.handle, kind, lhs.ptr, C.byref(lhs_view) if lhs_view is not None else None,
                 rhs.ptr if rhs is not None else None, C.byref(rhs_view) if rhs_view is not None else None, n,
                 C.byref(info), rows.ptr, row_offset, out.ptr))
+        return rows, out
+
+    def trace_contiguous(self, inp: DeviceBuffer, in_size: int, out_size: int, node_id: int, input_id: int,
+                         num_consumers: int, is_final_output: bool = False, input_mult: int = -1,
+                         view: Optional[LmnView] = None, rows: Optional[DeviceBuffer] = None, row_offset: int = 0,
+                         out: Optional[DeviceBuffer] = None):
+        """`LuminairContiguous::process_trace` in the reference's row rule: max(in_size, out_size) rows."""
+        n_rows = max(in_size, out_size)
+        if rows is None:
+            rows = self.alloc((row_offset + n_rows) * 11 * 4)
+        out = out or self.alloc(out_size * 4)
+        info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
+                           (C.c_int32 * 2)(input_mult, 0))
+        self._check(self.lib.lib.lmn_trace_contiguous(self.handle, inp.ptr, in_size, C.byref(view) if view is not None else None,
+                                                      out_size, C.byref(info), rows.ptr, row_offset, out.ptr))
         return rows, out
 
     def trace_lut(self, kind: int, inp: DeviceBuffer, n: int, node_id: int, input_id: int, num_consumers: int,

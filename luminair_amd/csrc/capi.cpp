@@ -225,6 +225,12 @@ int lmn_trace_elementwise_v(lmn_ctx* ctx, uint32_t kind, const int32_t* lhs_dev,
   });
 }
 
+int lmn_trace_contiguous(lmn_ctx* ctx, const int32_t* input_dev, uint64_t in_size, const lmn_view* view, uint64_t out_size,
+                         const lmn_node_info* info, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !input_dev || !info || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
+  return guard(ctx, [&] { ctx->impl->trace_contiguous(input_dev, in_size, view, out_size, *info, rows_dev, row_offset, out_dev); });
+}
+
 int lmn_trace_lut(lmn_ctx* ctx, uint32_t kind, const int32_t* input_dev, const lmn_view* view, uint64_t n,
                   const lmn_node_info* info, const uint32_t* lut_col1_dev, int32_t lo, uint32_t lut_len,
                   uint32_t* mult_dev, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {

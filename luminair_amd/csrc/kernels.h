@@ -114,11 +114,15 @@ void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n
 struct TraceNode {
   uint32_t node_id, lhs_id, rhs_id;
   uint32_t lhs_mult, rhs_mult, out_mult;  // canonical M31
+  // Contiguous in the reference's own row rule (prim.rs:253-296, zip_longest over the input BUFFER and the output):
+  // phys_n = elements of the input buffer (0: the view rule), out_n = elements of the output
+  uint64_t phys_n = 0, out_n = 0;
 };
 struct TraceView {  // strided view; ndim == 0: contiguous
   uint32_t ndim;
   uint32_t shape[4];
   int64_t strides[4];
+  int64_t offset;
 };
 void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv, const int32_t* rhs, const TraceView& rv,
                               uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, uint32_t* aux,

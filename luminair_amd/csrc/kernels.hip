@@ -63,7 +63,7 @@ LMN_HD uint32_t fixed_to_m31(int64_t v) { return v >= 0 ? (uint32_t)v : (uint32_
 
 LMN_D uint64_t view_offset(const TraceView& v, uint64_t r) {
   if (v.ndim == 0) return r;
-  int64_t off = 0;
+  int64_t off = v.offset;
   for (int k = (int)v.ndim - 1; k >= 0; --k) {
     const uint64_t d = v.shape[k];
     off += (int64_t)(r % d) * v.strides[k];
@@ -95,9 +95,20 @@ LMN_KERNEL k_trace_elementwise(const int32_t* __restrict__ lhs, TraceView lv, co
   const uint64_t r = row0 + threadIdx.x;
   if (r < n) {
     uint32_t* t = tile + threadIdx.x * ST;
-    const int64_t a = lhs[view_offset(lv, r)];
-    const uint32_t idx = (uint32_t)r, last = r + 1 == n ? 1u : 0u;
-    if (KIND == 16 || KIND == 7) {
+    const bool ref_contig = KIND == 16 && nd.phys_n != 0;
+    const int64_t a = lhs[view_offset(lv, ref_contig ? r % nd.out_n : r)];
+    const uint32_t idx = (uint32_t)r, last = r + 1 == (ref_contig ? nd.phys_n : n) ? 1u : 0u;
+    if (ref_contig) {
+      // LuminairContiguous::process_trace as the reference writes it (prim.rs:253-296): row idx pairs the idx-th
+      // element of the input BUFFER (zero past its end) with the idx-th element of the OUTPUT (the view; past the
+      // output's end the index expression wraps), is_last_idx marks the buffer's last element.  Every buffer
+      // element is consumed exactly once, so slices and permutations of the input balance.
+      t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = idx; t[3] = last;
+      t[4] = nd.node_id; t[5] = nd.lhs_id; t[6] = idx + 1u;
+      t[7] = r < nd.phys_n ? fixed_to_m31((int64_t)lhs[r]) : 0u;
+      t[8] = fixed_to_m31(a); t[9] = nd.lhs_mult; t[10] = nd.out_mult;
+      if (out && r < nd.out_n) out[r] = (int32_t)a;
+    } else if (KIND == 16 || KIND == 7) {
       // Contiguous (prim.rs:229-301): out = input.  Sqrt (prim.rs:573-660): out = floor(sqrt(input * scale)),
       // rem = input * scale - out^2 (natural identity; numerair's form is unpinned)
       t[0] = nd.node_id; t[1] = nd.lhs_id; t[2] = idx; t[3] = last;

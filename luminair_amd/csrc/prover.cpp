@@ -316,6 +316,8 @@ static TraceView trace_view(const lmn_view* v, uint64_t n) {
     t.strides[k] = v->strides[k];
     prod *= v->shape[k];
   }
+  if (v->offset < 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: negative offset");
+  t.offset = v->offset;
   if (prod != n) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "view: shape does not match the element count");
   return t;
 }
@@ -366,6 +368,32 @@ void Context::trace_elementwise(uint32_t kind, const int32_t* lhs, const lmn_vie
   const TraceView tlv = trace_view(lv, n), trv = trace_view(rv, n);
   launch_trace_elementwise((int)kind, lhs, tlv, rhs, trv, n, nd, rows + row_offset * (uint64_t)sp->n_cols, out, aux,
                            stream_);  // stream-ordered with every later call on this context
+}
+
+// `LuminairContiguous::process_trace` in the reference's own row rule (prim.rs:229-301): max(in_size, out_size) rows
+void Context::trace_contiguous(const int32_t* input, uint64_t in_size, const lmn_view* view, uint64_t out_size,
+                               const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out) {
+#ifndef LMN_EMU
+  LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
+  if (in_size == 0 || out_size == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
+  if (in_size >= (1ull << 31) || out_size >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "tensor too large");
+  TraceNode nd = trace_node(info);
+  nd.phys_n = in_size;
+  nd.out_n = out_size;
+  const TraceView tv = trace_view(view, out_size);
+  if (view)  // every element the view addresses must lie inside the buffer
+    for (uint64_t corner = 0; corner < (1ull << view->ndim); ++corner) {
+      int64_t off = view->offset;
+      for (uint32_t k = 0; k < view->ndim; ++k)
+        if (corner >> k & 1) off += (int64_t)(view->shape[k] - 1) * view->strides[k];
+      if (off < 0 || (uint64_t)off >= in_size) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "contiguous: the view leaves the input buffer");
+    }
+  else if (out_size > in_size)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "contiguous: output larger than the input buffer without a view");
+  const uint64_t n = std::max(in_size, out_size);
+  launch_trace_elementwise(LMN_KIND_CONTIGUOUS, input, tv, nullptr, TraceView{}, n, nd, rows + row_offset * 11ull, out, nullptr,
+                           stream_);
 }
 
 // Twiddle tables for every canonic domain up to 2^max_domain_log (computed

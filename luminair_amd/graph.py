@@ -43,10 +43,12 @@ class GraphTensor:
 
 @dataclass
 class TensorView:
-    """A tensor seen through a shape with expanded dimensions (stride 0): luminal's `expand`."""
+    """A tensor seen through a shape with expanded dimensions (stride 0), slices (offset) or permuted strides: the
+    part of luminal's ShapeTracker the ops' index expressions need."""
     base: GraphTensor
     shape: Tuple[int, ...]
     strides: Tuple[int, ...]
+    offset: int = 0
 
     @property
     def size(self) -> int:
@@ -103,7 +105,63 @@ class DeviceGraph:
     def expand(t, axis: int, size: int) -> TensorView:
         """Insert an expanded dimension of `size` at `axis` (stride 0)."""
         v = _as_view(t)
-        return TensorView(v.base, v.shape[:axis] + (int(size),) + v.shape[axis:], v.strides[:axis] + (0,) + v.strides[axis:])
+        return TensorView(v.base, v.shape[:axis] + (int(size),) + v.shape[axis:], v.strides[:axis] + (0,) + v.strides[axis:],
+                          v.offset)
+
+    @staticmethod
+    def expand_dim(t, axis: int, size: int) -> TensorView:
+        """Broadcast an EXISTING dimension of size 1 to `size` (stride 0)."""
+        v = _as_view(t)
+        if v.shape[axis] != 1:
+            raise ValueError("expand_dim broadcasts a dimension of size 1")
+        return TensorView(v.base, v.shape[:axis] + (int(size),) + v.shape[axis + 1:],
+                          v.strides[:axis] + (0,) + v.strides[axis + 1:], v.offset)
+
+    @staticmethod
+    def luminal_expand(t, axis: int, size: int) -> TensorView:
+        """`GraphTensor::expand(axis, size)` as the reference's tests use it (crates/graph/src/tests/expansions.rs,
+        tests/mod.rs:80-110): a dimension of size 1 at `axis` is broadcast ((2,1).expand(1,3) -> (2,3)); where the
+        tensor has no such dimension a new expanded one is inserted ((2,3).expand(2,4) -> (2,3,4)).  Either way the
+        element -> buffer index map and the number of repetitions per element are the same."""
+        v = _as_view(t)
+        if axis < len(v.shape) and v.shape[axis] == 1:
+            return DeviceGraph.expand_dim(v, axis, size)
+        return DeviceGraph.expand(v, axis, size)
+
+    @staticmethod
+    def expand_to(t, shape) -> TensorView:
+        """`GraphTensor::expand_to(shape)`: broadcast every dimension of size 1 (leading dimensions are added)."""
+        v = _as_view(t)
+        shape = tuple(int(d) for d in shape)
+        vs, st = (1,) * (len(shape) - len(v.shape)) + v.shape, (0,) * (len(shape) - len(v.shape)) + v.strides
+        out = []
+        for have, want, stride in zip(vs, shape, st):
+            if have == want:
+                out.append(stride)
+            elif have == 1:
+                out.append(0)
+            else:
+                raise ValueError("expand_to: dimension %d cannot become %d" % (have, want))
+        return TensorView(v.base, shape, tuple(out), v.offset)
+
+    @staticmethod
+    def slice(t, ranges) -> TensorView:
+        """`GraphTensor::slice`: ranges = one (start, stop) per dimension (None = the whole dimension)."""
+        v = _as_view(t)
+        shape, off = [], v.offset
+        for d, stride, r in zip(v.shape, v.strides, ranges):
+            lo, hi = (0, d) if r is None else r
+            if not 0 <= lo < hi <= d:
+                raise ValueError("slice out of range")
+            shape.append(hi - lo)
+            off += lo * stride
+        return TensorView(v.base, tuple(shape), v.strides, off)
+
+    @staticmethod
+    def permute(t, axes) -> TensorView:
+        """`GraphTensor::permute`."""
+        v = _as_view(t)
+        return TensorView(v.base, tuple(v.shape[a] for a in axes), tuple(v.strides[a] for a in axes), v.offset)
 
     @staticmethod
     def broadcast_to(t, shape) -> TensorView:
@@ -145,7 +203,10 @@ class DeviceGraph:
         return self._unary(int(TraceTableKind.Sqrt), a)
 
     def contiguous(self, a) -> GraphTensor:
-        """Materialise a view (`LuminairContiguous`, prim.rs:229-301)."""
+        """Materialise a view (`LuminairContiguous`, prim.rs:229-301).  A view without expanded dimensions (slice,
+        permutation, identity) follows the reference's own row rule - one row per element of the input BUFFER,
+        `lmn_trace_contiguous`; a view WITH expanded dimensions consumes the view's element per output row instead
+        (the reference's rule cannot balance the logup there)."""
         return self._unary(int(TraceTableKind.Contiguous), a)
 
     def rem(self, a, b) -> GraphTensor:
@@ -201,10 +262,17 @@ class DeviceGraph:
         Context.prove_tables(tables, luts); buffers = every device allocation made (free them after proving)."""
         ctx = self.ctx
         K = TraceTableKind
-        view_of = lambda v: None if v.strides == _as_view(v.base).strides and v.shape == v.base.shape \
-            else backend.LmnView.make(v.shape, v.strides)
+        view_of = lambda v: None if v.strides == _as_view(v.base).strides and v.shape == v.base.shape and not v.offset \
+            else backend.LmnView.make(v.shape, v.strides, v.offset)
         reduces = (int(K.SumReduce), int(K.MaxReduce))
-        rows_of = lambda n: n.inputs[0].size if n.kind in reduces else n.out.size
+        ref_contig = lambda n: n.kind == int(K.Contiguous) and n.inputs[0].expansion == 1
+
+        def rows_of(n):
+            if n.kind in reduces:
+                return n.inputs[0].size
+            if ref_contig(n):
+                return max(n.inputs[0].base.size, n.out.size)
+            return n.out.size
         total: Dict[int, int] = {}
         for n in self.nodes:
             total[n.kind] = total.get(n.kind, 0) + rows_of(n)
@@ -257,6 +325,10 @@ class DeviceGraph:
                 _, t.buf = ctx.trace_less_than(ins[0].base.buf, ins[1].base.buf, t.size, node_id=t.node_id,
                                                input_ids=tuple(i.base.node_id for i in ins), range_check_mult=rc_mult,
                                                lhs_view=view_of(ins[0]), rhs_view=view_of(ins[1]), **common)
+            elif ref_contig(n):
+                v = n.inputs[0]
+                _, t.buf = ctx.trace_contiguous(v.base.buf, v.base.size, t.size, node_id=t.node_id,
+                                                input_id=v.base.node_id, view=view_of(v), **common)
             elif n.kind in _LUT_OF:
                 name = _LUT_OF[n.kind][0]
                 lo, hi, (c0, _) = self.luts[name]

@@ -126,6 +126,20 @@ def contiguous_rows(x, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndar
     return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
 
 
+def contiguous_rows_ref(phys, out, node=2, input_id=0, input_mult=-1, out_mult=0) -> np.ndarray:
+    """`LuminairContiguous::process_trace` exactly as the reference iterates (prim.rs:253-296, zip_longest of the input
+    BUFFER and the output): row idx = (idx-th buffer element or 0, idx-th output element, wrapping past the output's
+    end), max(len(phys), len(out)) rows, is_last_idx on the buffer's last element."""
+    phys, out = np.asarray(phys, np.int64).reshape(-1), np.asarray(out, np.int64).reshape(-1)
+    n = max(len(phys), len(out))
+    idx = np.arange(n, dtype=np.int64)
+    inp = np.concatenate([phys, np.zeros(n - len(phys), np.int64)])
+    cols = [np.full(n, node), np.full(n, input_id), idx, (idx == len(phys) - 1).astype(np.int64), np.full(n, node),
+            np.full(n, input_id), idx + 1, to_m31(inp), to_m31(out[idx % len(out)]), np.full(n, input_mult % P),
+            np.full(n, out_mult % P)]
+    return np.stack([np.asarray(c, dtype=np.int64) % P for c in cols], axis=1).astype(np.uint32)
+
+
 def sqrt_rows(inp, node=2, input_id=0, mults=(0, 0)) -> np.ndarray:
     """Fixed-point sqrt rows (`crates/graph/src/op/prim.rs:573-660`): out = floor(sqrt(input*scale)),
     rem = input*scale - out^2 (the natural identity; numerair's exact form is unpinned)."""

@@ -534,3 +534,30 @@ def test_gpu_level2_surface_alone_reproduces_proofs(hip_lib_path, kat_bytes):
         # and the whole-proof entry point agrees with both
         p = luminair_amd.Prover(0, protocol_variant=int(variant))
         assert p.prove(luminair_amd.LuminairPie.from_tables(tabs)).to_bincode() == want
+
+
+def _producer_scenarios():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import producer_scenarios as ps
+    return ps
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_gpu_reference_expansion_scenarios(hip_lib_path, idx):
+    """crates/graph/src/tests/expansions.rs:64-368 on the device-side producer: gen_trace on the MI355X, tables equal
+    the numpy mirror, lmn_prove, lmn_verify (logup sums cancel), outputs equal (tests/producer_scenarios.py)."""
+    from luminair_amd import backend
+    ps = _producer_scenarios()
+    ps.run_scenario(backend.default_library(), ps.EXPANSIONS[idx], 42 + idx)
+
+
+def test_gpu_reference_op_shape_matrix(hip_lib_path):
+    """crates/graph/src/tests/mod.rs:50-190 + tests/ops.rs: the binary shape matrix (3x4, 32x32, 17x13, scalar / row /
+    column broadcast) for Add and Mul, the unary shape set, the three-way reductions of a (1, 4, 100) tensor, LessThan
+    and Contiguous (sliced in the reference's own row rule, permuted, expanded)."""
+    from luminair_amd import backend
+    ps = _producer_scenarios()
+    for build in ps.OPS:
+        ps.run_scenario(backend.default_library(), build, 7)
