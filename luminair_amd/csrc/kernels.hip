@@ -1501,7 +1501,7 @@ LMN_D uint32_t coset_pos_to_storage(uint32_t i, int log_size) {
 
 constexpr int SCAN_PER_THREAD = 4;
 constexpr int SCAN_PER_BLOCK = TPB * SCAN_PER_THREAD;
-int logup_scan_num_blocks(int log_size) { return (int)cdiv(1ull << log_size, SCAN_PER_BLOCK); }
+int logup_scan_num_blocks(int log_size);
 
 // block-local inclusive scan of thread sums in LDS (Hillis-Steele over TPB QM31 values)
 LMN_D QM31 block_scan_inclusive(QM31 v, QM31* sh) {
@@ -1576,9 +1576,119 @@ LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
   }
 }
 
+// ---- coalesced coset-order scan (log_size >= SCAN2_MIN_LOG)
+// Coset positions 2m and 2m+1 hold circle-domain indices m and n-1-m = ~m, i.e. storage indices s = brev(m) (even)
+// and ~s (odd).  With m = mh * 2^A + ml, u = s >> 1 = brev_A(ml) << (k-1-A) | brev(mh): a block of 2^A consecutive
+// m (fixed mh) is a stride-2^(k-1-A) comb in storage.  A workgroup therefore takes the 2 * 2^C blocks whose brev(mh)
+// is (G << C) | x for G in {g, ~g} and all x < 2^C: their even elements are the even words of 2^A contiguous runs
+// of 2^(C+1) storage indices in region g, their odd partners the odd words of the runs in region ~g, and vice versa -
+// every line the workgroup touches is used completely, loads (AoS QM31) and stores (4 SoA columns) are contiguous
+// runs of 2^(C+1) elements.  Three launches: block totals, scan of the 2^(k-1-A) totals, prefix + write
+// (48 B per row of HBM traffic for 32 B of algorithmic bytes; the scattered version moved ~160 B per row).
+constexpr int SCAN2_A = 6, SCAN2_C = 4;
+constexpr int SCAN2_MIN_LOG = SCAN2_A + SCAN2_C + 2;
+constexpr int SCAN2_ELEMS = 2 << (SCAN2_A + SCAN2_C + 1);  // QM31 values per workgroup (4096 = 64 KB)
+static_assert(SCAN2_ELEMS == TPB * 16 && (1 << (SCAN2_C + 1)) * 8 == TPB, "one 8-lane group per block of positions");
+
+template <int MODE>
+LMN_KERNEL k_logup_scan2(const QM31* __restrict__ last_tmp, const QM31* __restrict__ claimed_shift, int log_size,
+                         uint32_t* __restrict__ out_cols, QM31* __restrict__ blocksums) {
+  LMN_DYN_SMEM(QM31, T);
+  constexpr int A = SCAN2_A, C = SCAN2_C;
+  const int gbits = log_size - 1 - A - C;                 // bits of the region index G
+  const uint32_t n = 1u << log_size;
+  const uint32_t g = blockIdx.x, gmask = (1u << gbits) - 1u;
+  const QM31 shift = claimed_shift[1];
+  // element e of the tile: ((Gi * 2^A + r) * 2^C + x) * 2 + parity  <->  storage 2u + parity,
+  // u = r << (k-1-A) | G << C | x   (r = brev_A(ml))
+  auto storage_of = [&](uint32_t e) {
+    const uint32_t par = e & 1u, x = (e >> 1) & ((1u << C) - 1u), r = (e >> (1 + C)) & ((1u << A) - 1u), gi = e >> (1 + C + A);
+    const uint32_t G = gi ? (~g & gmask) : g;
+    const uint32_t u = (r << (log_size - 1 - A)) | (G << C) | x;
+    return 2u * u + par;
+  };
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t e = (uint32_t)i * TPB + threadIdx.x;
+    T[e] = q_sub(last_tmp[storage_of(e)], shift);
+  }
+  __syncthreads();
+  // 8 lanes per block of 2^A positions pairs; lane `part` owns m = part*8 .. part*8+7 (16 elements)
+  const uint32_t blk = threadIdx.x >> 3, part = threadIdx.x & 7u;
+  const uint32_t gi = blk >> C, x = blk & ((1u << C) - 1u);
+  uint32_t slot[16];
+  QM31 v[16];
+  QM31 run = q_zero();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t ml = part * 8u + (uint32_t)j;
+    const uint32_t r = __brev(ml) >> (32 - A);
+    slot[2 * j] = (((gi << A) + r) << C | x) << 1;                                                  // storage 2u
+    slot[2 * j + 1] = ((((1u - gi) << A) + ((1u << A) - 1u - r)) << C | ((1u << C) - 1u - x)) << 1 | 1u;  // storage ~(2u)
+    run = q_add(run, T[slot[2 * j]]);
+    v[2 * j] = run;
+    run = q_add(run, T[slot[2 * j + 1]]);
+    v[2 * j + 1] = run;
+  }
+  // inclusive scan of the 8 lanes' sums (xor butterfly inside the 8-lane group)
+  QM31 pre = run, tot = run;
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    QM31 o;
+    o.a = lmn_shfl_xor(tot.a, d);
+    o.b = lmn_shfl_xor(tot.b, d);
+    o.c = lmn_shfl_xor(tot.c, d);
+    o.d = lmn_shfl_xor(tot.d, d);
+    if (part & (uint32_t)d) pre = q_add(pre, o);
+    tot = q_add(tot, o);
+  }
+  const uint32_t G = gi ? (~g & gmask) : g;
+  const uint32_t mh = __brev((G << C) | x) >> (32 - (gbits + C));
+  if (MODE == 0) {
+    if (part == 0) blocksums[mh] = tot;
+    return;
+  }
+  QM31 off = q_sub(pre, run);
+  if (mh > 0) off = q_add(off, blocksums[mh - 1]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) T[slot[j]] = q_add(v[j], off);
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t e = (uint32_t)i * TPB + threadIdx.x;
+    const QM31 t = T[e];
+    uint32_t* o = out_cols + storage_of(e);
+    o[0] = t.a;
+    o[(uint64_t)n] = t.b;
+    o[(uint64_t)2 * n] = t.c;
+    o[(uint64_t)3 * n] = t.d;
+  }
+}
+
+int logup_scan_num_blocks(int log_size) {
+  if (log_size >= SCAN2_MIN_LOG) return 1 << (log_size - 1 - SCAN2_A);   // one total per block of 2^A position pairs
+  return (int)cdiv(1ull << log_size, SCAN_PER_BLOCK);
+}
+
 void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_size, uint32_t* out_cols,
                        QM31* blocksums, lmn_stream_t s) {
+  static const bool scattered = getenv("LMN_LOGUP_SCAN_V1") != nullptr;   // ablation: the round-1 kernel
   int nb = logup_scan_num_blocks(log_size);
+  if (log_size >= SCAN2_MIN_LOG && !scattered) {
+    const dim3 grid(1u << (log_size - 2 - SCAN2_A - SCAN2_C));
+    const size_t smem = (size_t)SCAN2_ELEMS * sizeof(QM31);
+#ifndef LMN_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_logup_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_logup_scan2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr_done = true;
+    }
+#endif
+    LMN_LAUNCH(k_logup_scan2<0>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
+    LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(TPB), 0, s, blocksums, nb);
+    LMN_LAUNCH(k_logup_scan2<1>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
+    return;
+  }
+  if (scattered) nb = (int)cdiv(1ull << log_size, SCAN_PER_BLOCK);
   LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 0);
   LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(TPB), 0, s, blocksums, nb);
   LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 1);

@@ -45,6 +45,8 @@ def test_emu_reproduces_kat(emu_ctx, kat_bytes):
     # quotient column joins the layer
     ("add-2^11 (fold fused into leaf hashing)", syn.config2_add_only(1 << 11, 5)),
     ("mixed 2^11 + 2^10 (fused and plain folds)", [(0, syn.chain_graph(2000, 4)[0][1]), (1, syn.chain_graph(1000, 5)[1][1])]),
+    # traces of 2^12 rows and more: the coalesced coset-order prefix sum (k_logup_scan2) instead of the scattered one
+    ("chain-2^12 (coalesced logup scan)", syn.chain_graph(1 << 12, 7)),
 ])
 def test_emu_matches_oracle(emu_ctx, name, tabs):
     got, want = _both(emu_ctx, tabs)
