@@ -27,6 +27,11 @@ int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_
                 const TwPtrs& itw, lmn_stream_t s);
 int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
                int log_n, const TwPtrs& tw, lmn_stream_t s);
+// interpolate + extend by one bit in three launches (the strided passes of both transforms fused): evals (2^log_n) ->
+// coeffs (2^log_n, kept) and lde (2^(log_n+1)).  itw: inverse twiddles of domain log_n; tw_ext: twiddles of log_n + 1.
+bool fft_interp_extend_supported(int log_n);
+int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
+                         uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s);
 // forward transform restricted to block `block` of 2^log_blocks equal row blocks of the 2^log_n domain (tw = the
 // twiddles of the whole domain); dst receives 2^(log_n - log_blocks) words per column
 int launch_fft_block(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,

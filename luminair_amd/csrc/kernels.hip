@@ -441,10 +441,13 @@ LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_
   }
 }
 
+// sm_in / sm_out: LDS tile read by a stage that does not load from global / written by one that does not store to
+// global (the same buffer in the plain passes).  keep != nullptr: a to_global stage also leaves its (scaled) values in
+// that LDS tile (the fused interpolate + extend pass continues from them).
 template <int R, bool INV>
-LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t src_len, uint64_t base, int lo,
-                     int hi, int cb, int first_layer, uint32_t H, bool from_global, bool to_global, const TwPtrs& tw,
-                     uint32_t scale) {
+LMN_D void fft_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* col, const uint32_t* scol, uint64_t src_len,
+                     uint64_t base, int lo, int hi, int cb, int first_layer, uint32_t H, bool from_global, bool to_global,
+                     const TwPtrs& tw, uint32_t scale, uint32_t* keep = nullptr) {
   const int p = first_layer - lo + cb;           // bit position of the stage's first layer in the tile index
   const uint32_t tile_elems = 1u << (hi - lo + cb);
   const uint32_t ngroups = tile_elems >> R;
@@ -496,7 +499,7 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
     } else {
       const uint32_t pb = fft_lds_pad(e0);
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) v[j] = sm[pb + fft_lds_pad((uint32_t)j << p)];
+      for (int j = 0; j < (1 << R); ++j) v[j] = sm_in[pb + fft_lds_pad((uint32_t)j << p)];
     }
     const uint32_t m0 = e0 >> cb;
     radix_butterflies<R, INV>(v, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
@@ -513,11 +516,28 @@ LMN_D void fft_stage(uint32_t* sm, uint32_t* col, const uint32_t* scol, uint64_t
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) tdst[off0 + (uint32_t)j * gstride] = v[j];
       }
+      if (keep) {
+        const uint32_t pb = fft_lds_pad(e0);
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) keep[pb + fft_lds_pad((uint32_t)j << p)] = v[j];
+      }
     } else {
       const uint32_t pb = fft_lds_pad(e0);
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) sm[pb + fft_lds_pad((uint32_t)j << p)] = v[j];
+      for (int j = 0; j < (1 << R); ++j) sm_out[pb + fft_lds_pad((uint32_t)j << p)] = v[j];
     }
+  }
+}
+
+template <bool INV>
+LMN_D void fft_stage_dispatch(int R, const uint32_t* sm_in, uint32_t* sm_out, uint32_t* col, const uint32_t* scol,
+                              uint64_t src_len, uint64_t base, int lo, int hi, int cb, int first_layer, uint32_t H,
+                              bool from_global, bool to_global, const TwPtrs& tw, uint32_t scale, uint32_t* keep = nullptr) {
+  switch (R) {
+    case 1: fft_stage<1, INV>(sm_in, sm_out, col, scol, src_len, base, lo, hi, cb, first_layer, H, from_global, to_global, tw, scale, keep); break;
+    case 2: fft_stage<2, INV>(sm_in, sm_out, col, scol, src_len, base, lo, hi, cb, first_layer, H, from_global, to_global, tw, scale, keep); break;
+    case 3: fft_stage<3, INV>(sm_in, sm_out, col, scol, src_len, base, lo, hi, cb, first_layer, H, from_global, to_global, tw, scale, keep); break;
+    default: fft_stage<4, INV>(sm_in, sm_out, col, scol, src_len, base, lo, hi, cb, first_layer, H, from_global, to_global, tw, scale, keep); break;
   }
 }
 
@@ -545,13 +565,55 @@ LMN_KERNEL k_fft_staged(uint32_t* data, uint64_t col_stride, const uint32_t* src
     for (int k = 0; k < pl.nst; ++k) {
       const int s = INV ? k : pl.nst - 1 - k;
       const bool fg = k == 0, tg = k == pl.nst - 1;
-      switch (pl.R[s]) {
-        case 1: fft_stage<1, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
-        case 2: fft_stage<2, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
-        case 3: fft_stage<3, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
-        default: fft_stage<4, INV>(sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale); break;
-      }
+      fft_stage_dispatch<INV>(pl.R[s], sm, sm, col, scol, src_len, base, pl.lo, pl.hi, pl.cb, pl.first[s], H, fg, tg, tw, scale);
       __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused "interpolate then extend" pass (PolyOps::interpolate followed by PolyOps::evaluate on the blown-up domain, as
+// every committed column goes through: prover.rs:56-59,179,298).  The last pass of the inverse transform on 2^n points
+// (layers [lo, n), strided tile) and the first pass of the forward transform onto 2^(n+1) points touch the SAME
+// coefficient positions: the zero-extended coefficient vector makes the forward layer n the identity on both halves,
+// and layers [lo, n) of each half h are the tile's own layers with twiddle row H = h.  So one workgroup loads the
+// tile once, finishes the interpolation (coefficients go to HBM - the OODS evaluation needs them - and stay in LDS),
+// and runs the forward layers twice from LDS, writing both halves of the extended evaluation: one launch and one
+// read of the coefficients less per column than two separate passes.
+// ---------------------------------------------------------------------------------------------
+LMN_KERNEL k_fft_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* src, uint64_t src_stride,
+                               uint32_t* lde, uint64_t lde_stride, FftStagePlan pl, TwPtrs itw, TwPtrs tw, uint32_t scale,
+                               int ncols, int cpb) {
+  LMN_DYN_SMEM(uint32_t, sm);
+  const uint32_t tile_elems = 1u << (pl.hi - pl.lo + pl.cb);
+  uint32_t* A = sm;                                   // the coefficient tile (kept for the second half)
+  uint32_t* B = sm + fft_lds_pad(tile_elems) + 1u;    // exchange buffer of the stages
+  uint32_t tile = blockIdx.x;
+  if (pl.xcd_swizzle && (gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint64_t base = (uint64_t)tile << pl.cb;      // hi = n: the tile spans the whole column in its strided rows
+  const uint64_t n_words = 1ull << pl.hi;
+  for (int cc = 0; cc < cpb; ++cc) {
+    const int c = blockIdx.y * cpb + cc;
+    if (c >= ncols) break;
+    uint32_t* ccol = coeffs + (uint64_t)c * coeff_stride;
+    const uint32_t* scol = src + (uint64_t)c * src_stride;
+    uint32_t* lcol = lde + (uint64_t)c * lde_stride;
+    // inverse layers [lo, n): stages ascending; the last one scales, stores the coefficients and keeps them in A
+    for (int k = 0; k < pl.nst; ++k) {
+      const bool fg = k == 0, tg = k == pl.nst - 1;
+      fft_stage_dispatch<true>(pl.R[k], B, B, ccol, scol, n_words, base, pl.lo, pl.hi, pl.cb, pl.first[k], 0u, fg, tg, itw, scale,
+                               tg ? A : nullptr);
+      __syncthreads();
+    }
+    // forward layers [lo, n) of half h of the 2^(n+1)-point transform: stages descending, first one reads A
+    for (uint32_t h = 0; h < 2; ++h) {
+      for (int k = 0; k < pl.nst; ++k) {
+        const int s = pl.nst - 1 - k;
+        const bool tg = k == pl.nst - 1;
+        fft_stage_dispatch<false>(pl.R[s], k == 0 ? A : B, B, lcol + h * n_words, lcol, 0, base, pl.lo, pl.hi, pl.cb, pl.first[s], h,
+                                  false, tg, tw, 1u);
+        __syncthreads();
+      }
     }
   }
 }
@@ -598,6 +660,35 @@ static void split_stages(FftStagePlan& pl) {
   }
 }
 
+// one k_fft_staged launch: layers [p.lo, p.hi) of a 2^log_n transform
+template <bool INV>
+static void launch_staged_pass(uint32_t* data, uint64_t col_stride, const uint32_t* psrc, uint64_t pstride, uint64_t plen,
+                               const FftPass& p, int log_n, const TwPtrs& tw, uint32_t scale, int ncols, lmn_stream_t s,
+                               uint32_t block_index = 0) {
+  const int rbits = p.hi - p.lo;
+  const unsigned tiles = 1u << (log_n - rbits - p.cb);
+  FftStagePlan pl{};
+  pl.lo = p.lo;
+  pl.hi = p.hi;
+  pl.cb = p.cb;
+  split_stages(pl);
+  static const int env_xcd = getenv("LMN_FFT_XCD") ? atoi(getenv("LMN_FFT_XCD")) : 1;
+  pl.xcd_swizzle = (env_xcd && p.cb > 0) ? 1 : 0;
+  uint32_t tile_elems = 1u << (rbits + p.cb);
+  size_t smem = (size_t)4 * (tile_elems + (tile_elems >> 5) + 1);
+  // several columns per block when there are plenty of tiles: twiddles stay hot in L1/L2
+  int cpb = tiles >= 2048 ? 3 : (tiles >= 512 ? 2 : 1);
+  static const int env_cpb = getenv("LMN_FFT_CPB") ? atoi(getenv("LMN_FFT_CPB")) : 0;
+  static const int env_thr = getenv("LMN_FFT_THREADS") ? atoi(getenv("LMN_FFT_THREADS")) : 0;
+  if (env_cpb > 0) cpb = env_cpb;
+  if (cpb > ncols) cpb = ncols;
+  unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
+  int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
+  if (env_thr > 0) threads = env_thr;
+  LMN_LAUNCH(k_fft_staged<INV>, dim3(tiles, gy), dim3(threads), smem, s, data, col_stride, psrc, pstride, plen, pl, tw,
+             scale, ncols, cpb, block_index << (log_n - p.hi));
+}
+
 template <bool INV>
 static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int log_src,
                     int ncols, int log_n, const TwPtrs& tw, lmn_stream_t s, uint32_t block_index = 0) {
@@ -620,28 +711,47 @@ static int run_fft(uint32_t* data, uint64_t col_stride, const uint32_t* src, uin
                  p.lo, p.hi, p.cb, tw, scale);
       continue;
     }
-    FftStagePlan pl{};
-    pl.lo = p.lo;
-    pl.hi = p.hi;
-    pl.cb = p.cb;
-    split_stages(pl);
-    static const int env_xcd = getenv("LMN_FFT_XCD") ? atoi(getenv("LMN_FFT_XCD")) : 1;
-    pl.xcd_swizzle = (env_xcd && p.cb > 0) ? 1 : 0;
-    uint32_t tile_elems = 1u << (rbits + p.cb);
-    size_t smem = (size_t)4 * (tile_elems + (tile_elems >> 5) + 1);
-    // several columns per block when there are plenty of tiles: twiddles stay hot in L1/L2
-    int cpb = tiles >= 2048 ? 3 : (tiles >= 512 ? 2 : 1);
-    static const int env_cpb = getenv("LMN_FFT_CPB") ? atoi(getenv("LMN_FFT_CPB")) : 0;
-    static const int env_thr = getenv("LMN_FFT_THREADS") ? atoi(getenv("LMN_FFT_THREADS")) : 0;
-    if (env_cpb > 0) cpb = env_cpb;
-    if (cpb > ncols) cpb = ncols;
-    unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
-    int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
-    if (env_thr > 0) threads = env_thr;
-    LMN_LAUNCH(k_fft_staged<INV>, dim3(tiles, gy), dim3(threads), smem, s, data, col_stride, psrc, pstride, plen, pl,
-               tw, scale, ncols, cpb, block_index << (log_n - p.hi));
+    launch_staged_pass<INV>(data, col_stride, psrc, pstride, plen, p, log_n, tw, scale, ncols, s, block_index);
   }
   return np;
+}
+
+// interpolate (2^log_n evaluations -> coefficients, kept) + extend onto the 2^(log_n + 1) domain in three launches:
+// inverse low pass, the fused strided pass (k_fft_interp_extend), forward low pass.  Applies when both transforms
+// have exactly one strided pass of at most FFT_HIGH_BITS layers.
+bool fft_interp_extend_supported(int log_n) {
+  static const bool off = getenv("LMN_NO_FFT_FUSION") != nullptr;
+  return !off && log_n > FFT_LOW_BITS && log_n - FFT_LOW_BITS <= FFT_HIGH_BITS - 1;
+}
+int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
+                         uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
+  if (!fft_interp_extend_supported(log_n)) throw LmnError(-100, "interp_extend: unsupported size");
+  const FftPass low{0, FFT_LOW_BITS, 0};
+  launch_staged_pass<true>(coeffs, coeff_stride, evals, evals_stride, 1ull << log_n, low, log_n, itw, 1u, ncols, s);
+  FftStagePlan pl{};
+  pl.lo = FFT_LOW_BITS;
+  pl.hi = log_n;
+  pl.cb = FFT_HIGH_CB;
+  split_stages(pl);
+  pl.xcd_swizzle = 1;
+  const uint32_t tile_elems = 1u << (log_n - FFT_LOW_BITS + FFT_HIGH_CB);
+  const size_t smem = (size_t)8 * (tile_elems + (tile_elems >> 5) + 1);
+  const unsigned tiles = 1u << (FFT_LOW_BITS - FFT_HIGH_CB);
+  int cpb = 1;
+  const int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
+#ifndef LMN_EMU
+  if (smem > 64 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fft_interp_extend, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+  }
+#endif
+  LMN_LAUNCH(k_fft_interp_extend, dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(threads), smem, s, coeffs, coeff_stride,
+             coeffs, coeff_stride, lde, lde_stride, pl, itw, tw_ext, inv_pow2(log_n), ncols, cpb);
+  launch_staged_pass<false>(lde, lde_stride, lde, lde_stride, 2ull << log_n, low, log_n + 1, tw_ext, 1u, ncols, s);
+  return 3;
 }
 
 int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int ncols, int log_n,
@@ -1555,24 +1665,50 @@ LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restric
   }
 }
 
-// inclusive scan of the block totals in place (single block)
+// inclusive scan of the block totals in place (single block of up to 1024 lanes; lane t owns a contiguous run)
+constexpr int SCAN_SUMS_THREADS = 1024;
 LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
-  LMN_SHARED QM31 sh[TPB];
-  int per = (nblocks + TPB - 1) / TPB;
-  int b0 = threadIdx.x * per;
+  LMN_SHARED QM31 sh[SCAN_SUMS_THREADS];
+  const int T = (int)blockDim.x;
+  const int per = (nblocks + T - 1) / T;
+  const int b0 = threadIdx.x * per;
+  // pass 1: the lane's total (loads in independent batches of 8, so that they overlap)
   QM31 run = q_zero();
-  for (int k = 0; k < per; ++k) {
-    int b = b0 + k;
-    if (b < nblocks) {
-      run = q_add(run, blocksums[b]);
-      blocksums[b] = run;
+  for (int k0 = 0; k0 < per; k0 += 8) {
+    QM31 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = b0 + k0 + j;
+      v[j] = (k0 + j < per && b < nblocks) ? blocksums[b] : q_zero();
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) run = q_add(run, v[j]);
   }
-  QM31 incl = block_scan_inclusive(run, sh);
-  QM31 offset = q_sub(incl, run);
-  for (int k = 0; k < per; ++k) {
-    int b = b0 + k;
-    if (b < nblocks) blocksums[b] = q_add(blocksums[b], offset);
+  // Hillis-Steele over the lanes' totals
+  sh[threadIdx.x] = run;
+  __syncthreads();
+  for (int off = 1; off < T; off <<= 1) {
+    QM31 add = q_zero();
+    if ((int)threadIdx.x >= off) add = sh[threadIdx.x - off];
+    __syncthreads();
+    sh[threadIdx.x] = q_add(sh[threadIdx.x], add);
+    __syncthreads();
+  }
+  // pass 2: inclusive prefix inside the lane's run, starting from the lanes before it
+  QM31 acc = q_sub(sh[threadIdx.x], run);
+  for (int k0 = 0; k0 < per; k0 += 8) {
+    QM31 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = b0 + k0 + j;
+      v[j] = (k0 + j < per && b < nblocks) ? blocksums[b] : q_zero();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = b0 + k0 + j;
+      acc = q_add(acc, v[j]);
+      if (k0 + j < per && b < nblocks) blocksums[b] = acc;
+    }
   }
 }
 
@@ -1684,13 +1820,13 @@ void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_
     }
 #endif
     LMN_LAUNCH(k_logup_scan2<0>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
-    LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(TPB), 0, s, blocksums, nb);
+    LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb);
     LMN_LAUNCH(k_logup_scan2<1>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
     return;
   }
   if (scattered) nb = (int)cdiv(1ull << log_size, SCAN_PER_BLOCK);
   LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 0);
-  LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(TPB), 0, s, blocksums, nb);
+  LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb);
   LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 1);
 }
 

@@ -632,6 +632,23 @@ void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uin
   if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
 }
 
+uint32_t* Context::interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size) {
+  const uint64_t n = 1ull << log_size;
+  StageTimer t(this, g_log(this), stream_, C_FFT);
+  timings.fft_bytes += (uint64_t)ncols * 8ull * n;
+  timings.fft_butterflies += (uint64_t)ncols * (n / 2) * (uint64_t)log_size;
+  if (!shard_.active && cfg.log_blowup == 1 && fft_interp_extend_supported(log_size)) {
+    uint32_t* lde = arena_.alloc_words((size_t)ncols * 2 * n);
+    timings.fft_launches += launch_interp_extend(coeffs, n, evals, n, lde, 2 * n, ncols, log_size, itw(log_size),
+                                                 tw(log_size + 1), stream_);
+    timings.fft_bytes += (uint64_t)ncols * 12ull * n;                       // the extension: 4n read + 8n written
+    timings.fft_butterflies += (uint64_t)ncols * n * (uint64_t)log_size;  // 2^(k+1)/2 * k (the top layer is the identity)
+    return lde;
+  }
+  timings.fft_launches += launch_ifft(coeffs, n, evals, n, ncols, log_size, itw(log_size), stream_);
+  return nullptr;
+}
+
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
 // shard set, only this rank's aligned block of rows of every LDE is evaluated (launch_fft_block: the top
 // log2(world) layers collapse to a world-point combination at fixed row, the rest runs inside the block).
@@ -641,10 +658,15 @@ void Context::lde_and_merkle(DevTree& tree) {
   const int g = sh ? shard_.g : 0;
   size_t i = 0;
   while (i < tree.cols.size()) {
+    if (tree.cols[i].lde) {  // produced together with the interpolation (interpolate_for_commit)
+      ++i;
+      continue;
+    }
     size_t j = i;
     int log = tree.cols[i].log_size;
     uint64_t n = 1ull << log;
-    while (j < tree.cols.size() && tree.cols[j].log_size == log && tree.cols[j].coeffs == tree.cols[i].coeffs + (j - i) * n)
+    while (j < tree.cols.size() && !tree.cols[j].lde && tree.cols[j].log_size == log &&
+           tree.cols[j].coeffs == tree.cols[i].coeffs + (j - i) * n)
       ++j;
     int ncols = (int)(j - i);
     uint64_t L = (n << lb) >> g;  // rows held here
@@ -1205,15 +1227,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       uint64_t n = 1ull << ci.log_size;
       int nc = ci.spec->n_cols;
       uint32_t* coeffs = arena_.alloc_words((size_t)nc * n);
-      {
-        StageTimer t(this, log, stream_, C_FFT);
-        timings.fft_launches += launch_ifft(coeffs, n, ci.trace_evals, n, nc, ci.log_size, itw(ci.log_size), stream_);
-        timings.fft_bytes += (uint64_t)nc * 8ull * n;
-        timings.fft_butterflies += (uint64_t)nc * (n / 2) * (uint64_t)ci.log_size;
-      }
+      uint32_t* lde = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size);
       ci.main_start = off;
       off += nc;
-      for (int c = 0; c < nc; ++c) tree1.cols.push_back({ci.log_size, coeffs + (uint64_t)c * n, nullptr});
+      for (int c = 0; c < nc; ++c)
+        tree1.cols.push_back({ci.log_size, coeffs + (uint64_t)c * n, lde ? lde + (uint64_t)c * 2 * n : nullptr});
     }
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
@@ -1273,13 +1291,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       ci.inter_start = off;
       off += nic;
       // interaction evals -> coefficients in place, registered as tree-2 columns
-      {
-        StageTimer t(this, log, stream_, C_FFT);
-        timings.fft_launches += launch_ifft(ievals, n, ievals, n, nic, ci.log_size, itw(ci.log_size), stream_);
-        timings.fft_bytes += (uint64_t)nic * 8ull * n;
-        timings.fft_butterflies += (uint64_t)nic * (n / 2) * (uint64_t)ci.log_size;
-      }
-      for (int c = 0; c < nic; ++c) tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, nullptr});
+      uint32_t* ilde = interpolate_for_commit(ievals, ievals, nic, ci.log_size);
+      for (int c = 0; c < nic; ++c)
+        tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, ilde ? ilde + (uint64_t)c * 2 * n : nullptr});
     }
   }
   {
@@ -1376,6 +1390,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       for (auto& kv : sub) gather_columns(kv.second, 1ull << kv.first, 4, (1ull << kv.first) >> sg);
     // DomainEvaluationAccumulator::finalize: fold smaller sizes into larger ones
     uint32_t* cur = nullptr;  // coefficients, 4 x 2^cur_log
+    uint32_t* comp_lde = nullptr;
     int cur_log = 0;
     for (auto& kv : sub) {
       int e = kv.first;
@@ -1389,7 +1404,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         timings.fft_butterflies += 4ull * (E / 2) * (uint64_t)e;
         launch_secure_add(vals, ext, 4 * E, stream_);
       }
-      {
+      if (e == comp_log) {
+        comp_lde = interpolate_for_commit(vals, vals, 4, e);   // the last (largest) size: the committed polynomial
+      } else {
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_ifft(vals, E, vals, E, 4, e, itw(e), stream_);
         timings.fft_bytes += 4ull * 8ull * E;
@@ -1399,7 +1416,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       cur_log = e;
     }
     if (cur_log != comp_log) throw LmnError(LMN_ERR_INTERNAL, "composition size mismatch");
-    for (int k = 0; k < 4; ++k) tree3.cols.push_back({comp_log, cur + ((uint64_t)k << comp_log), nullptr});
+    for (int k = 0; k < 4; ++k)
+      tree3.cols.push_back({comp_log, cur + ((uint64_t)k << comp_log), comp_lde ? comp_lde + ((uint64_t)k << (comp_log + 1)) : nullptr});
   }
   {
     StageTimer st(this, log, stream_, C_COMP_COMMIT);

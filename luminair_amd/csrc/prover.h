@@ -196,6 +196,10 @@ class Context {
   void ensure_twiddles(int max_domain_log);
   TwPtrs tw(int domain_log) const;
   TwPtrs itw(int domain_log) const;
+  // evaluations -> coefficients (`coeffs` may equal `evals`).  Unsharded proofs of a supported size get the blown-up
+  // evaluation in the same three launches (launch_interp_extend): returns the LDE (ncols x 2^(log + log_blowup),
+  // arena) or nullptr when lde_and_merkle has to produce it.
+  uint32_t* interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size);
   // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
   void lde_and_merkle(DevTree& tree);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its

@@ -47,6 +47,9 @@ def test_emu_reproduces_kat(emu_ctx, kat_bytes):
     ("mixed 2^11 + 2^10 (fused and plain folds)", [(0, syn.chain_graph(2000, 4)[0][1]), (1, syn.chain_graph(1000, 5)[1][1])]),
     # traces of 2^12 rows and more: the coalesced coset-order prefix sum (k_logup_scan2) instead of the scattered one
     ("chain-2^12 (coalesced logup scan)", syn.chain_graph(1 << 12, 7)),
+    # columns of 2^13 rows and more: interpolation and extension share their strided pass (k_fft_interp_extend)
+    ("mixed 2^13 + 2^10 (fused interpolate+extend next to the plain passes)",
+     [(0, syn.chain_graph(5000, 4)[0][1]), (1, syn.chain_graph(1000, 5)[1][1])]),
 ])
 def test_emu_matches_oracle(emu_ctx, name, tabs):
     got, want = _both(emu_ctx, tabs)
