@@ -198,8 +198,10 @@ struct EvalJob {
 };
 constexpr int EVAL_LB = 10;
 // tables: for point p: lo table at lo_tab + p*2^EVAL_LB, hi table at hi_tab + p*hi_stride
+// shard_world > 1: only the chunks this rank owns are evaluated (zeros elsewhere): the reduction is a partial sum
 void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, const QM31* hi_tab, uint32_t hi_stride,
-                          int max_log, QM31* partial_out /* njobs x max_chunks */, int max_chunks, lmn_stream_t s);
+                          int max_log, QM31* partial_out /* njobs x max_chunks */, int max_chunks, lmn_stream_t s,
+                          uint32_t shard_rank = 0, uint32_t shard_world = 1);
 int eval_num_chunks(int log_n);
 void launch_eval_tables(const QM31* maps, int maps_stride, int npoints, QM31* lo_tab, QM31* hi_tab, uint32_t hi_n,
                         int hi_bits, lmn_stream_t s);

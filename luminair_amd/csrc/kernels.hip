@@ -2126,14 +2126,25 @@ LMN_HD int eval_num_chunks_hd(int log_n) {
 }
 int eval_num_chunks(int log_n) { return eval_num_chunks_hd(log_n); }
 
+// shard_world > 1 (single-proof sharding): the chunks of every job are dealt to the ranks in contiguous runs (a job
+// with fewer chunks than ranks gives one chunk to each of the first ranks); a rank writes zero for chunks it does
+// not own, so that the per-job reduction is this rank's PARTIAL sum - the ranks' partials are all-gathered (16 B per
+// job and rank) and added on the host.
 LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restrict__ lo_tab,
                            const QM31* __restrict__ hi_tab, uint32_t hi_stride, QM31* __restrict__ partial_out,
-                           int max_chunks) {
+                           int max_chunks, uint32_t shard_rank, uint32_t shard_world) {
   LMN_SHARED QM31 red[TPB];
   const EvalJob job = jobs[blockIdx.y];
   const int chunk = blockIdx.x;
   const int nchunks = eval_num_chunks_hd(job.log_n);
   if (chunk >= nchunks) return;
+  if (shard_world > 1) {
+    const uint32_t owner = (uint32_t)nchunks >= shard_world ? (uint32_t)chunk / ((uint32_t)nchunks / shard_world) : (uint32_t)chunk;
+    if (owner != shard_rank) {
+      if (threadIdx.x == 0) partial_out[(uint64_t)blockIdx.y * max_chunks + chunk] = q_zero();
+      return;
+    }
+  }
   const int lb = job.log_n < EVAL_LB ? job.log_n : EVAL_LB;
   const uint32_t lo_n = 1u << lb;
   const uint32_t total_hi = 1u << (job.log_n - lb);
@@ -2188,10 +2199,11 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
 }
 
 void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, const QM31* hi_tab, uint32_t hi_stride,
-                          int max_log, QM31* partial_out, int max_chunks, lmn_stream_t s) {
+                          int max_log, QM31* partial_out, int max_chunks, lmn_stream_t s, uint32_t shard_rank,
+                          uint32_t shard_world) {
   (void)max_log;
   LMN_LAUNCH(k_eval_at_point, dim3(max_chunks, njobs), dim3(TPB), 0, s, jobs, lo_tab, hi_tab, hi_stride, partial_out,
-             max_chunks);
+             max_chunks, shard_rank, shard_world);
 }
 
 // basis tables on the device: lo[p][j] = prod_{k<EVAL_LB} maps[p][k]^(bit k of j); hi[p][j] likewise

@@ -819,7 +819,7 @@ QM31 eval_composition_at_point(const std::vector<Instance>& inst,
 
 // ------------------------------------------------------------------------------------ OODS evaluation
 std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points,
-                                          int max_log) {
+                                          int max_log, bool split) {
   const int np = (int)points.size();
   const uint32_t lo_n = 1u << EVAL_LB;
   const int hi_bits = max_log > EVAL_LB ? max_log - EVAL_LB : 0;
@@ -843,13 +843,20 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
   QM31* d_lo = (QM31*)arena_.alloc_bytes((size_t)np * lo_n * sizeof(QM31));
   QM31* d_hi = (QM31*)arena_.alloc_bytes((size_t)np * hi_n * sizeof(QM31));
   QM31* d_part = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));
-  QM31* d_out = (QM31*)arena_.alloc_bytes(jobs.size() * sizeof(QM31));
+  split = split && shard_.active && shard_.world > 1;
+  const uint32_t W = split ? shard_.world : 1u, R = split ? shard_.rank : 0u;
+  const size_t nj = jobs.size();
+  QM31* d_out = (QM31*)arena_.alloc_bytes((size_t)W * nj * sizeof(QM31));   // slot r: rank r's partial sums
   launch_eval_tables(d_maps, nmaps, np, d_lo, d_hi, hi_n, hi_bits, stream_);
-  launch_eval_at_point(d_jobs, (int)jobs.size(), d_lo, d_hi, hi_n, max_log, d_part, max_chunks, stream_);
-  launch_eval_reduce(d_jobs, (int)jobs.size(), d_part, max_chunks, d_out, stream_);
-  const QM31* res = (const QM31*)stage_download(d_out, jobs.size() * sizeof(QM31));
+  launch_eval_at_point(d_jobs, (int)nj, d_lo, d_hi, hi_n, max_log, d_part, max_chunks, stream_, R, W);
+  launch_eval_reduce(d_jobs, (int)nj, d_part, max_chunks, d_out + (size_t)R * nj, stream_);
+  if (split) gather_columns((uint32_t*)d_out, 0, 1, nj * 4);
+  const QM31* res = (const QM31*)stage_download(d_out, (size_t)W * nj * sizeof(QM31));
   lmn_sync(stream_);
-  return std::vector<QM31>(res, res + jobs.size());
+  std::vector<QM31> out(res, res + nj);
+  for (uint32_t r = 1; r < W; ++r)
+    for (size_t j = 0; j < nj; ++j) out[j] = q_add(out[j], res[(size_t)r * nj + j]);
+  return out;
 }
 
 // ------------------------------------------------------------------------------------ decommit planning
@@ -1460,7 +1467,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     for (int t = 0; t < 4; ++t)
       for (size_t c = 0; c < trees[t]->cols.size(); ++c)
         for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p});
-    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log);
+    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true);
     size_t k = 0;
     for (int t = 0; t < 4; ++t) {
       sampled[t].resize(trees[t]->cols.size());

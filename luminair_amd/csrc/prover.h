@@ -218,7 +218,10 @@ class Context {
   QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                   const std::vector<std::vector<std::pair<int, QM31>>>& samples,
                                   const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);
-  std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log);
+  // split: a sharded proof evaluates 1/world of every polynomial's coefficient chunks per rank and all-gathers the
+  // partial sums (16 B per sample and rank)
+  std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log,
+                                   bool split = false);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
   void begin_op();

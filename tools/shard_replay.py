@@ -107,11 +107,23 @@ def replay(world, name, path, want_sha, reps):
             ctx.prove_tables(bufs)
             ts.append(1e3 * (time.perf_counter() - t0))
         res["rank0_ms_" + mode] = sorted(ts)[reps // 2]
-    # exchange model on top of `ideal`: every rank receives (world-1)/world of each all-gather; per-call latency 15 us,
-    # 150 GB/s effective all-gather receive bandwidth per GPU over xGMI (7 links x ~153 GB/s peak, ring per-link bound)
+    # where rank 0's time goes (HIP events of one profiled proof, `ideal` collective)
+    ctx.set_profiling(True)
+    ctx.prove_tables(bufs)
+    ctx.set_profiling(False)
+    res["rank0_stage_ms"] = {k: round(v, 4) for k, v in ctx.timings().items() if k.endswith("_ms")}
+    # exchange models on top of `ideal`: every rank receives (world-1)/world of each all-gather.
+    #  ring:   15 us per all-gather call, 150 GB/s receive bandwidth (one xGMI link per ring step: per-link bound)
+    #  direct: 15 us per GROUP of calls (the library batches the coordinate columns of one exchange in one RCCL
+    #          group: consecutive calls of equal size are counted once), (world-1) peers feeding the rank over their
+    #          own links at ~153 GB/s each (xGMI is point-to-point: 7 links per GPU on an 8-GPU node)
     recv = res["gathered_bytes_per_proof"] * (world - 1) / world
+    groups = sum(1 for i, r in enumerate(rec) if i == 0 or len(r) != len(rec[i - 1]))
+    res["all_gather_groups_per_proof"] = groups
     res["modelled_exchange_ms"] = 1e3 * (len(rec) * 15e-6 + recv / 150e9)
+    res["modelled_exchange_direct_links_ms"] = 1e3 * (groups * 15e-6 + recv / (153e9 * max(1, world - 1)))
     res["estimated_latency_ms"] = res["rank0_ms_ideal"] + res["modelled_exchange_ms"]
+    res["estimated_latency_direct_links_ms"] = res["rank0_ms_ideal"] + res["modelled_exchange_direct_links_ms"]
     ctx.close()
     return res
 
