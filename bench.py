@@ -70,19 +70,31 @@ def dist_env():
 
 
 def timed_region(step_fn, steps, warmup, barrier, device_sync):
-    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides."""
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides.  The cyclic garbage
+    collector is parked for the timed region (as timeit does): a generation-2 pass of the interpreter that happens to
+    fall into it holds the GIL for tens of milliseconds, during which no worker thread can hand its next proof to the
+    library - measured on the MI355X box as a one-off ~42 ms stall in a 40 ms region, for some (contexts, warmup)
+    pairs and not for others."""
+    import gc
     for _ in range(warmup):
         step_fn()
     device_sync()
-    barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
-    device_sync()
-    barrier()
-    device_sync()
-    return time.perf_counter() - t0
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        device_sync()
+        barrier()
+        device_sync()
+        return time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
 
 
 def aggregate(elapsed, world, steps_per_rank, reduce_max):
@@ -347,10 +359,12 @@ def main(argv=None):
         while pending:
             pending.pop(0).result()
 
-    # one-time context initialisation (twiddle tables, device arena) for EVERY in-flight context, so the
-    # W warmup + K timed steps below never include a context's first-use setup whatever W is
-    for i in range(inflight):
-        one(i)
+    # one-time initialisation for EVERY in-flight context ON ITS OWN WORKER THREAD (twiddle tables, device arena, and
+    # the worker's first HIP call, which sets up the runtime's per-thread state), so the W warmup + K timed steps
+    # below never include first-use setup whatever W is: with W < inflight some workers are otherwise first used
+    # inside the timed region (measured: 20 proofs on 8 contexts took 80 ms instead of 40)
+    for f in [pools[i].submit(one, i) for i in range(inflight)]:
+        f.result()
 
     def barrier():
         if use_dist:
@@ -405,7 +419,7 @@ def main(argv=None):
     except Exception:
         pass
     fams = {
-        "k_fft_staged": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"], ["k_fft_staged<false>", "k_fft_staged<true>"]),
+        "k_fft_staged": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"], ["k_fft_staged<false>", "k_fft_staged<true>", "k_fft_interp_extend"]),
         "k_merkle_fused": (tm["merkle_fused_ms"], tm["merkle_fused_bytes"], tm["merkle_fused_launches"],
                            ["k_merkle_fused", "k_merkle_fused<0>", "k_merkle_fused<1>", "k_merkle_fused<2>", "k_merkle_fused<3>"]),
     }
