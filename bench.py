@@ -169,17 +169,25 @@ def throughput(provers, bufs, steps, warmup, luts=None):
             errors.append(e)
             start.abort()
 
+    import gc
     threads = [threading.Thread(target=drive, args=(i,)) for i in range(n)]
-    for t in threads:
-        t.start()
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()            # as in timed_region: no generation-2 pass (GIL held for tens of ms) inside the measurement
     try:
-        start.wait()
-    except threading.BrokenBarrierError:
-        pass
-    t0 = time.perf_counter()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
+        for t in threads:
+            t.start()
+        try:
+            start.wait()
+        except threading.BrokenBarrierError:
+            pass
+        t0 = time.perf_counter()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     if errors:
         raise errors[0]
     return {"value": steps / dt, "unit": "proofs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
