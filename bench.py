@@ -33,8 +33,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 rows of the Add trace (default 20 = BASELINE config 2)")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="independent proofs in flight per GPU (one prover context + HIP stream each)")
+    ap.add_argument("--inflight", type=int, default=8,
+                    help="independent proofs in flight per GPU (one prover context + HIP stream + ~3 GB arena each); "
+                         "8 measured best on MI355X for both 20-step and 192-step regions (DESIGN.md section 7)")
     ap.add_argument("--host-rows", action="store_true",
                     help="hand the trace rows over as host buffers (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -579,7 +580,7 @@ def main(argv=None):
         line["config_3"] = sub_result("config_3", lambda: variant_throughput(
             syn.config3_mixed(lr + 1, lr, lr), _bk.VARIANT_KAT, 16,
             "BASELINE config 3: Add 2^%d + Mul 2^%d + Recip 2^%d rows in one pie (three components, mixed-size trees; "
-            "Recip's constraint form unpinned)" % (lr + 1, lr, lr), n_ctx=min(inflight, 2)))
+            "Recip's constraint form unpinned)" % (lr + 1, lr, lr), n_ctx=min(inflight, 4)))
     if anchor:
         line["reference_shape_anchor"] = anchor
     if trace_gen:
