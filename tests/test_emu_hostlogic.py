@@ -302,3 +302,31 @@ def test_emu_advice_r2_boundary_fixes(emu_ctx):
             fn()
         assert e.value.code == backend.ERR_INVALID_ARGUMENT
     a.free()
+
+
+@pytest.mark.parametrize("pow_bits,log_last_layer,n_queries,tabs", [
+    (10, 3, 20, syn.chain_graph(300, 3)),
+    (0, 5, 1, syn.config2_add_only(100, 1)),
+    (7, 0, 64, syn.config3_mixed(10, 9, 9, 8)),       # mixed-size trees
+    (5, 10, 3, syn.config2_add_only(1 << 11, 5)),      # last layer of 2^11 evaluations: the FRI loop ends above the tail kernel
+    (5, 9, 5, syn.config2_add_only(1 << 11, 6)),
+    (12, 2, 200, syn.linear_layer(20, 7, 2, True)),    # more queries than rows in the smallest tree
+])
+def test_emu_non_default_pcs_config_matches_oracle(root, pow_bits, log_last_layer, n_queries, tabs):
+    """`lmn_config` other than PcsConfig::default(): PoW bits, FRI last-layer degree bound and query count reach the
+    transcript, the FRI loop's end, the grind and the decommitment - byte-equal to the oracle under the same config,
+    and accepted by the product verifier only when it expects that config."""
+    from oracle.prover import PcsConfig
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    cfg = lib.default_config()
+    cfg.pow_bits, cfg.log_last_layer, cfg.n_queries = pow_bits, log_last_layer, n_queries
+    ctx = backend.Context(0, cfg, lib)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    ctx.close()
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs],
+                                   PcsConfig(pow_bits=pow_bits, log_last_layer=log_last_layer, n_queries=n_queries)))
+    assert got == want
+    lib.verify(got, backend.VARIANT_KAT, config=cfg)
+    if (pow_bits, log_last_layer, n_queries) != (5, 0, 3):
+        with pytest.raises(backend.LuminairBackendError):
+            lib.verify(got, backend.VARIANT_KAT)           # the default verifier expects PcsConfig::default()

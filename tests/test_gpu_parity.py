@@ -561,3 +561,27 @@ def test_gpu_reference_op_shape_matrix(hip_lib_path):
     ps = _producer_scenarios()
     for build in ps.OPS:
         ps.run_scenario(backend.default_library(), build, 7)
+
+
+@pytest.mark.parametrize("pow_bits,log_last_layer,n_queries,tabs", [
+    (10, 3, 20, syn.chain_graph(1 << 13, 3)),
+    (0, 5, 1, syn.config2_add_only(1 << 14, 1)),
+    (7, 0, 64, syn.config3_mixed(14, 13, 13, 8)),
+    (5, 10, 3, syn.config2_add_only(1 << 12, 5)),
+    (16, 9, 300, syn.config2_add_only(1 << 16, 6)),
+    (12, 2, 200, syn.linear_layer(64, 100, 13, True)),
+])
+def test_gpu_non_default_pcs_config_matches_oracle(hip_lib_path, c_oracle, pow_bits, log_last_layer, n_queries, tabs):
+    """`lmn_config` other than PcsConfig::default() on the MI355X: byte-equal to the (C) oracle under the same config,
+    accepted by `lmn_verify_with_config`, rejected by the default verifier."""
+    from luminair_amd import backend
+    from oracle.proof import to_bincode
+    from oracle.prover import PcsConfig, prove
+    p = luminair_amd.Prover(0, pow_bits=pow_bits, log_last_layer=log_last_layer, n_queries=n_queries)
+    got = p.ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    want = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs],
+                            PcsConfig(pow_bits=pow_bits, log_last_layer=log_last_layer, n_queries=n_queries), kernels=c_oracle))
+    assert got == want
+    backend.default_library().verify(got, backend.VARIANT_KAT, config=p.ctx.config)
+    with pytest.raises(backend.LuminairBackendError):
+        backend.default_library().verify(got, backend.VARIANT_KAT)
