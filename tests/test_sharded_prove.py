@@ -38,28 +38,35 @@ def _cases():
         ("2b-small (Inputs component)", syn.config2_graph_faithful(200, 3), None, True),
         ("less-than + range-check LUT", syn.less_than_graph(40, 5), None, True),
         ("sin/exp2 + LUT tree 0", act, luts, True),
+        # PcsConfig other than the default: (pow_bits, log_last_layer, n_queries)
+        ("chain, 20 queries, last layer 2^3 coefficients", syn.chain_graph(300, 3), None, False, (10, 3, 20)),
+        ("2a-small, 1 query, last layer 2^5 coefficients", syn.config2_add_only(300, 2), None, False, (0, 5, 1)),
     ]
 
 
 def _prove_all(make_ctx):
     out = []
     ctxs = {}
-    for name, tabs, luts, pinned in _cases():
-        if pinned not in ctxs:
-            ctxs[pinned] = make_ctx(pinned)
-        proof = ctxs[pinned].prove_tables([(k, r, len(r)) for k, r in tabs], luts)
+    for case in _cases():
+        name, tabs, luts, pinned = case[:4]
+        key = (pinned, case[4] if len(case) > 4 else None)
+        if key not in ctxs:
+            ctxs[key] = make_ctx(*key)
+        proof = ctxs[key].prove_tables([(k, r, len(r)) for k, r in tabs], luts)
         out.append((name, hashlib.sha256(proof).hexdigest(), len(proof)))
     for c in ctxs.values():
         c.close()
     return out
 
 
-def _make_ctx(pinned):
+def _make_ctx(pinned, pcs=None):
     from luminair_amd import backend
     lib = backend.Library(EMU)
     cfg = lib.default_config()
     if pinned:
         cfg.protocol_variant = backend.VARIANT_PINNED
+    if pcs:
+        cfg.pow_bits, cfg.log_last_layer, cfg.n_queries = pcs
     return backend.Context(0, cfg, lib)
 
 
@@ -70,8 +77,8 @@ def _worker(rank, world, port, fri_min_log, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        def make(pinned):
-            ctx = _make_ctx(pinned)
+        def make(pinned, pcs=None):
+            ctx = _make_ctx(pinned, pcs)
             shard_context(ctx, fri_min_log=fri_min_log)
             return ctx
         # errors surface identically on every rank (same transcript, same checks) and leave the contexts usable
