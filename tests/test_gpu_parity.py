@@ -585,3 +585,24 @@ def test_gpu_non_default_pcs_config_matches_oracle(hip_lib_path, c_oracle, pow_b
     backend.default_library().verify(got, backend.VARIANT_KAT, config=p.ctx.config)
     with pytest.raises(backend.LuminairBackendError):
         backend.default_library().verify(got, backend.VARIANT_KAT)
+
+
+def test_gpu_single_table_2_24_rows_equals_c_oracle_bytes(hip_lib_path, c_oracle):
+    """One Add table of 2^24 rows (16 x BASELINE config 2): every main / interaction column goes through three-pass
+    transforms (LDE of 2^25 rows, composition LDE of 2^26 rows), 2^26-leaf trees, the coalesced logup scan with 2^17
+    block totals - index widths the 2^23-row tables of config 5 do not reach.  SHA-256 against the C oracle's proof,
+    and the product verifier accepts it.  Rows stay on the device (960 MiB of trace)."""
+    from luminair_amd import backend
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.config2_add_only(1 << 24, 7)
+    p = luminair_amd.Prover(0)
+    bufs = [(k, p.ctx.upload(r), len(r)) for k, r in tabs]
+    got = p.ctx.prove_tables(bufs)
+    assert p.ctx.prove_tables(bufs) == got                        # deterministic at this size too
+    for _, b, _ in bufs:
+        b.free()
+    p.ctx.close()
+    backend.default_library().verify(got, backend.VARIANT_KAT)
+    want = to_bincode(prove(tabs, kernels=c_oracle))
+    assert len(got) == len(want) and _sha(got) == _sha(want)
