@@ -626,6 +626,9 @@ constexpr int FFT_HIGH_BITS = 10;   // strided high passes: 2^10 rows x 16 words
 constexpr int FFT_HIGH_CB = 4;
 
 static int plan_passes(int log_n, FftPass* out) {
+  // LMN_FFT_SPLIT (experiment): 0 = strided passes of equal depth (default), 1 = deepest first (10, then the rest),
+  // 2 = deepest last
+  static const int split = getenv("LMN_FFT_SPLIT") ? atoi(getenv("LMN_FFT_SPLIT")) : 0;
   int n = 0;
   int lo = 0;
   int hi = log_n < FFT_LOW_BITS ? log_n : FFT_LOW_BITS;
@@ -635,6 +638,8 @@ static int plan_passes(int log_n, FftPass* out) {
     int rem = log_n - lo;
     int npass = (rem + FFT_HIGH_BITS - 1) / FFT_HIGH_BITS;
     int take = (rem + npass - 1) / npass;
+    if (split == 1 && npass > 1) take = FFT_HIGH_BITS;
+    if (split == 2 && npass > 1) take = rem - (npass - 1) * FFT_HIGH_BITS;
     out[n++] = {lo, lo + take, FFT_HIGH_CB};
     lo += take;
   }
