@@ -11,6 +11,26 @@ namespace lmn {
 constexpr int TPB = 256;
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+#ifndef LMN_EMU
+}  // namespace lmn
+#include <mutex>
+#include <set>
+#include <utility>
+namespace lmn {
+// Kernels that use more than 64 KiB of dynamic LDS need the attribute once per (device, function): contexts of one
+// process may live on several GPUs and are created from several threads.
+static void allow_big_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  LMN_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, fn})) return;
+  LMN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, fn});
+}
+#endif
 LMN_D QM31 load_secure_col(const uint32_t* __restrict__ base, uint64_t stride, uint64_t i) {
   return QM31{base[i], base[stride + i], base[2 * stride + i], base[3 * stride + i]};
 }
@@ -745,13 +765,7 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
   int cpb = 1;
   const int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
 #ifndef LMN_EMU
-  if (smem > 64 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fft_interp_extend, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
-    }
-  }
+  if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_interp_extend, 160 * 1024);
 #endif
   LMN_LAUNCH(k_fft_interp_extend, dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(threads), smem, s, coeffs, coeff_stride,
              coeffs, coeff_stride, lde, lde_stride, pl, itw, tw_ext, inv_pow2(log_n), ncols, cpb);
@@ -1817,12 +1831,8 @@ void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_
     const dim3 grid(1u << (log_size - 2 - SCAN2_A - SCAN2_C));
     const size_t smem = (size_t)SCAN2_ELEMS * sizeof(QM31);
 #ifndef LMN_EMU
-    static bool attr_done = false;
-    if (!attr_done) {
-      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_logup_scan2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      LMN_HIP_CHECK(hipFuncSetAttribute((const void*)k_logup_scan2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      attr_done = true;
-    }
+    allow_big_lds((const void*)k_logup_scan2<0>, (int)smem);
+    allow_big_lds((const void*)k_logup_scan2<1>, (int)smem);
 #endif
     LMN_LAUNCH(k_logup_scan2<0>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
     LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb);
