@@ -93,7 +93,7 @@ class LmnTimings(C.Structure):
 
 
 EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
-           "lmn_ctx_destroy", "lmn_prove", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
+           "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
@@ -132,6 +132,8 @@ class Library:
         lib.lmn_ctx_destroy.argtypes = [C.c_void_p]
         lib.lmn_prove.argtypes = [C.c_void_p, C.POINTER(LmnTable), C.c_size_t, C.POINTER(LmnSettings),
                                   C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        lib.lmn_prove_submit.argtypes = [C.c_void_p, C.POINTER(LmnTable), C.c_size_t, C.POINTER(LmnSettings)]
+        lib.lmn_prove_wait.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         lib.lmn_free.argtypes = [C.c_void_p]
         lib.lmn_get_timings.argtypes = [C.c_void_p, C.POINTER(LmnTimings)]
         lib.lmn_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -662,9 +664,8 @@ class Context:
             row_offset, out.ptr))
         return rows, out
 
-    def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:
-        """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer;
-        luts: {"sin" | "exp2" | "log2": (col0, col1)} preprocessed LUT columns (uint32, 2^k words each)."""
+    def _marshal_tables(self, tables, luts):
+        """-> (LmnTable array, n, LmnSettings, objects that must stay alive while the library reads them)"""
         n = len(tables)
         arr = (LmnTable * max(n, 1))()
         keep = []
@@ -689,9 +690,34 @@ class Context:
             keep += [c0, c1]
             lut_arr[i] = LmnLut(LUT_KINDS[name], len(c0).bit_length() - 1, c0.ctypes.data, c1.ctypes.data)
         settings = LmnSettings(0, len(luts), lut_arr)
+        keep += [arr, lut_arr, settings]
+        return arr, n, settings, keep
+
+    def prove_tables(self, tables: Sequence[Tuple[int, object, int]], luts=None) -> bytes:
+        """tables: [(kind, rows, n_rows)] where rows is a uint32 ndarray (host) or a DeviceBuffer;
+        luts: {"sin" | "exp2" | "log2": (col0, col1)} preprocessed LUT columns (uint32, 2^k words each)."""
+        arr, n, settings, _keep = self._marshal_tables(tables, luts)
         out = C.POINTER(C.c_uint8)()
         out_len = C.c_size_t()
         self._check(self.lib.lib.lmn_prove(self.handle, arr, n, C.byref(settings), C.byref(out), C.byref(out_len)))
+        data = C.string_at(out, out_len.value)
+        self.lib.lib.lmn_free(out)
+        return data
+
+    def prove_submit(self, tables: Sequence[Tuple[int, object, int]], luts=None):
+        """`lmn_prove_submit`: start the proof on the context's own worker thread and return; collect it with
+        `prove_wait()`.  One thread keeps N proofs in flight with N contexts."""
+        arr, n, settings, keep = self._marshal_tables(tables, luts)
+        self._check(self.lib.lib.lmn_prove_submit(self.handle, arr, n, C.byref(settings)))
+        self._pending = keep          # borrowed by the library until prove_wait returns
+
+    def prove_wait(self) -> bytes:
+        out = C.POINTER(C.c_uint8)()
+        out_len = C.c_size_t()
+        try:
+            self._check(self.lib.lib.lmn_prove_wait(self.handle, C.byref(out), C.byref(out_len)))
+        finally:
+            self._pending = None
         data = C.string_at(out, out_len.value)
         self.lib.lib.lmn_free(out)
         return data

@@ -70,10 +70,99 @@ int lmn_ctx_create(int device, const lmn_config* cfg, lmn_ctx** out) {
   return LMN_OK;
 }
 
+static void async_stop(lmn_ctx* ctx) {
+  lmn_async* a = ctx->async;
+  if (!a) return;
+  {
+    std::unique_lock<std::mutex> lk(a->m);
+    a->cv.wait(lk, [&] { return a->state != lmn_async::SUBMITTED; });  // let a running proof finish
+    a->state = lmn_async::QUIT;
+  }
+  a->cv.notify_all();
+  if (a->worker.joinable()) a->worker.join();
+  delete a;
+  ctx->async = nullptr;
+}
+
 void lmn_ctx_destroy(lmn_ctx* ctx) {
   if (!ctx) return;
+  async_stop(ctx);
   delete ctx->impl;
   delete ctx;
+}
+
+// ---- asynchronous form of lmn_prove: the reference's callers are single-threaded (SURVEY.md §8b "threading"); with
+// submit / wait one thread keeps a proof in flight on each of several contexts
+int lmn_prove_submit(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
+  if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  if (!ctx->async) {
+    lmn_async* a = new lmn_async();
+    ctx->async = a;
+    a->worker = std::thread([ctx, a] {
+      for (;;) {
+        std::unique_lock<std::mutex> lk(a->m);
+        a->cv.wait(lk, [&] { return a->state == lmn_async::SUBMITTED || a->state == lmn_async::QUIT; });
+        if (a->state == lmn_async::QUIT) return;
+        const lmn_table* t = a->tables;
+        const size_t n = a->n_tables;
+        const lmn_settings* st = a->settings;
+        lk.unlock();
+        std::vector<uint8_t> bytes;
+        const int rc = guard(ctx, [&] { bytes = ctx->impl->prove(t, n, st); });
+        lk.lock();
+        a->rc = rc;
+        a->proof.swap(bytes);
+        a->state = lmn_async::DONE;
+        lk.unlock();
+        a->cv.notify_all();
+      }
+    });
+  }
+  lmn_async* a = ctx->async;
+  {
+    std::lock_guard<std::mutex> lk(a->m);
+    if (a->state != lmn_async::IDLE) {
+      ctx->last_error = "lmn_prove_submit: a submitted proof has not been collected with lmn_prove_wait";
+      return LMN_ERR_INVALID_ARGUMENT;
+    }
+    a->tables = tables;
+    a->n_tables = n_tables;
+    a->settings = settings;
+    a->state = lmn_async::SUBMITTED;
+  }
+  a->cv.notify_all();
+  return LMN_OK;
+}
+
+int lmn_prove_wait(lmn_ctx* ctx, uint8_t** proof_bincode, size_t* proof_len) {
+  if (!ctx || !proof_bincode || !proof_len) return LMN_ERR_INVALID_ARGUMENT;
+  *proof_bincode = nullptr;
+  *proof_len = 0;
+  lmn_async* a = ctx->async;
+  if (!a) {
+    ctx->last_error = "lmn_prove_wait: nothing was submitted";
+    return LMN_ERR_INVALID_ARGUMENT;
+  }
+  std::unique_lock<std::mutex> lk(a->m);
+  if (a->state == lmn_async::IDLE) {
+    ctx->last_error = "lmn_prove_wait: nothing was submitted";
+    return LMN_ERR_INVALID_ARGUMENT;
+  }
+  a->cv.wait(lk, [&] { return a->state == lmn_async::DONE; });
+  const int rc = a->rc;
+  if (rc == LMN_OK) {
+    uint8_t* p = (uint8_t*)malloc(a->proof.size() ? a->proof.size() : 1);
+    if (!p) {
+      a->state = lmn_async::IDLE;
+      return LMN_ERR_OUT_OF_MEMORY;
+    }
+    memcpy(p, a->proof.data(), a->proof.size());
+    *proof_bincode = p;
+    *proof_len = a->proof.size();
+  }
+  a->proof.clear();
+  a->state = lmn_async::IDLE;
+  return rc;
 }
 
 int lmn_prove(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_settings* settings,

@@ -1,10 +1,26 @@
 // Shared by the extern "C" translation units (capi.cpp, level2.cpp): the opaque context and the exception guard.
 #pragma once
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "prover.h"
+
+// lmn_prove_submit / lmn_prove_wait: one worker thread per context (created on first use) that runs the submitted proof
+struct lmn_async {
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv;
+  enum { IDLE, SUBMITTED, DONE, QUIT } state = IDLE;
+  const lmn_table* tables = nullptr;
+  size_t n_tables = 0;
+  const lmn_settings* settings = nullptr;
+  int rc = 0;
+  std::vector<uint8_t> proof;
+};
 
 struct lmn_ctx {
   lmn::Context* impl;
@@ -12,6 +28,7 @@ struct lmn_ctx {
   // Calls on ONE context are serialised (a context owns one stream, one arena and one pinned staging buffer);
   // different contexts run concurrently.  Recursive: a shard collective callback may call back into its context.
   std::recursive_mutex mu;
+  lmn_async* async = nullptr;
 };
 
 namespace lmn {

@@ -330,3 +330,31 @@ def test_emu_non_default_pcs_config_matches_oracle(root, pow_bits, log_last_laye
     if (pow_bits, log_last_layer, n_queries) != (5, 0, 3):
         with pytest.raises(backend.LuminairBackendError):
             lib.verify(got, backend.VARIANT_KAT)           # the default verifier expects PcsConfig::default()
+
+
+def test_emu_prove_submit_wait(root):
+    """`lmn_prove_submit` / `lmn_prove_wait`: the asynchronous form for single-threaded callers (the reference's
+    `prove` is a plain function call, prover.rs:28) - same bytes and same error codes as `lmn_prove`, one outstanding
+    submission per context, a context can be destroyed with an uncollected proof."""
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    ctx = backend.Context(0, None, lib)
+    tabs = [(k, r, len(r)) for k, r in syn.chain_graph(100, 3)]
+    want = ctx.prove_tables(tabs)
+    for _ in range(2):
+        ctx.prove_submit(tabs)
+        assert ctx.prove_wait() == want
+    ctx.prove_submit(tabs)
+    with pytest.raises(backend.LuminairBackendError) as e:      # one outstanding submission per context
+        ctx.prove_submit(tabs)
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    assert ctx.prove_wait() == want
+    with pytest.raises(backend.LuminairBackendError) as e:      # nothing to wait for
+        ctx.prove_wait()
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    ctx.prove_submit([(0, np.zeros((0, 15), np.uint32), 0)])    # errors surface at wait, as lmn_prove would report them
+    with pytest.raises(backend.LuminairBackendError) as e:
+        ctx.prove_wait()
+    assert e.value.code == backend.ERR_EMPTY_TRACE
+    assert ctx.prove_tables(tabs) == want                       # the synchronous form still works next to it
+    ctx.prove_submit(tabs)
+    ctx.close()                                                 # destroy with an uncollected proof: no hang, no leak

@@ -606,3 +606,32 @@ def test_gpu_single_table_2_24_rows_equals_c_oracle_bytes(hip_lib_path, c_oracle
     backend.default_library().verify(got, backend.VARIANT_KAT)
     want = to_bincode(prove(tabs, kernels=c_oracle))
     assert len(got) == len(want) and _sha(got) == _sha(want)
+
+
+def test_gpu_prove_submit_wait_from_one_thread(hip_lib_path):
+    """Eight contexts kept busy by ONE host thread with lmn_prove_submit / lmn_prove_wait (what a single-threaded
+    Rust caller of the reference's `prove` would do): every proof equals the synchronous one, and the single thread
+    reaches the multi-threaded throughput."""
+    import time
+    tabs = syn.config2_add_only(1 << 20, 42)
+    provers = [luminair_amd.Prover(0) for _ in range(8)]
+    bufs = [[(k, p.ctx.upload(r), len(r)) for k, r in tabs] for p in provers]
+    want = provers[0].ctx.prove_tables(bufs[0])
+    for p, b in zip(provers, bufs):
+        p.ctx.prove_tables(b)
+    rounds = 12
+    t0 = time.perf_counter()
+    for p, b in zip(provers, bufs):
+        p.ctx.prove_submit(b)
+    for r in range(rounds):
+        for p, b in zip(provers, bufs):
+            assert p.ctx.prove_wait() == want
+            if r + 1 < rounds:
+                p.ctx.prove_submit(b)
+    dt = time.perf_counter() - t0
+    rate = rounds * len(provers) / dt
+    print("one host thread, 8 contexts, submit/wait: %.1f proofs/s" % rate)
+    assert rate > 300            # the multi-threaded bench reaches ~500; a serial caller would get ~340
+    for bl in bufs:
+        for _, b, _ in bl:
+            b.free()
