@@ -8,7 +8,7 @@ gfx950 behind the C ABI of `include/luminair_hip.h`; there is no CPU fallback.
 from .pie import (CircuitSettings, ExecutionResources, Lookup, LookupLayout, LuminairError, LuminairPie, LuminairProof,
                   Metadata, RangeCheckLookup, TraceTable, TraceTableKind)
 from .graph import DeviceGraph
-from .prover import Prover, prove, verify
+from .prover import Prover, ProverPool, prove, verify
 
 __all__ = ["Lookup", "LookupLayout", "RangeCheckLookup", "CircuitSettings", "ExecutionResources", "LuminairError", "LuminairPie", "LuminairProof", "Metadata",
-           "TraceTable", "TraceTableKind", "Prover", "prove", "verify", "DeviceGraph"]
+           "TraceTable", "TraceTableKind", "Prover", "ProverPool", "prove", "verify", "DeviceGraph"]

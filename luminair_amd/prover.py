@@ -49,6 +49,51 @@ class Prover:
         return self.ctx.timings()
 
 
+class ProverPool:
+    """`n` prover contexts on one GPU driven from ONE thread with `lmn_prove_submit` / `lmn_prove_wait`: the way a
+    single-threaded caller of the reference's `prove` keeps the chip busy (about eight proofs in flight on an MI355X,
+    DESIGN.md section 7).  `prove_many` returns the proofs in input order."""
+
+    def __init__(self, device: int = 0, n: int = 8, protocol_variant: int = backend.VARIANT_KAT, library=None, **pcs):
+        self.provers = [Prover(device, protocol_variant, library, **pcs) for _ in range(max(1, n))]
+
+    def prove_many(self, pies, settings: Optional[CircuitSettings] = None):
+        out, in_flight = [], []          # in_flight: context indices in submit order
+        n = len(self.provers)
+
+        def collect(k):
+            try:
+                return LuminairProof(self.provers[k].ctx.prove_wait())
+            except backend.LuminairBackendError as e:
+                raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
+
+        try:
+            for i, pie in enumerate(pies):
+                k = i % n
+                if len(in_flight) == n:
+                    out.append(collect(in_flight.pop(0)))        # context k holds the oldest submission
+                tables = [(int(t.kind), t.rows, t.n_rows) for t in pie.trace_tables]
+                luts = settings.lut_columns(self.provers[k].ctx.lib) if settings is not None else None
+                try:
+                    self.provers[k].ctx.prove_submit(tables, luts)
+                except backend.LuminairBackendError as e:
+                    raise LuminairError(_ERR_VARIANT.get(e.code, "Internal"), str(e), e.code) from e
+                in_flight.append(k)
+            while in_flight:
+                out.append(collect(in_flight.pop(0)))
+        finally:
+            for k in in_flight:              # an error above: drain what is still running before the buffers go away
+                try:
+                    self.provers[k].ctx.prove_wait()
+                except backend.LuminairBackendError:
+                    pass
+        return out
+
+    def close(self):
+        for p in self.provers:
+            p.ctx.close()
+
+
 _default: Optional[Prover] = None
 
 

@@ -358,3 +358,18 @@ def test_emu_prove_submit_wait(root):
     assert ctx.prove_tables(tabs) == want                       # the synchronous form still works next to it
     ctx.prove_submit(tabs)
     ctx.close()                                                 # destroy with an uncollected proof: no hang, no leak
+
+
+def test_emu_prover_pool_prove_many(root):
+    """`ProverPool.prove_many`: proofs come back in input order, errors surface as LuminairError, the pool stays usable."""
+    import luminair_amd
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    pool = luminair_amd.ProverPool(0, n=1, library=lib)       # the emulation runtime is single-context
+    pies = [luminair_amd.LuminairPie.from_tables(syn.chain_graph(40 + 7 * i, i)) for i in range(3)]
+    want = [pool.provers[0].prove(p).to_bincode() for p in pies]
+    assert [p.to_bincode() for p in pool.prove_many(pies)] == want
+    bad = luminair_amd.LuminairPie([luminair_amd.TraceTable(luminair_amd.TraceTableKind.Add, np.zeros((0, 15), np.uint32))])
+    with pytest.raises(luminair_amd.LuminairError):
+        pool.prove_many([pies[0], bad, pies[1]])
+    assert [p.to_bincode() for p in pool.prove_many(pies[:2])] == want[:2]
+    pool.close()

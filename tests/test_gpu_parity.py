@@ -635,3 +635,13 @@ def test_gpu_prove_submit_wait_from_one_thread(hip_lib_path):
     for bl in bufs:
         for _, b, _ in bl:
             b.free()
+
+
+def test_gpu_prover_pool_prove_many(hip_lib_path):
+    """`ProverPool.prove_many` on the MI355X: 8 contexts, 24 different pies from one thread, proofs in input order and
+    equal to the synchronous proofs."""
+    pool = luminair_amd.ProverPool(0, n=8)
+    pies = [luminair_amd.LuminairPie.from_tables(syn.chain_graph(3000 + 257 * i, i)) for i in range(24)]
+    want = [pool.provers[0].prove(p).to_bincode() for p in pies]
+    assert [p.to_bincode() for p in pool.prove_many(pies)] == want
+    pool.close()
