@@ -1,0 +1,15 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r3z
+mkdir -p $OUT
+( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2; grep real $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for i in 1 2 3; do
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_cmd_$i.json 2> $OUT/driver_cmd_$i.err; echo "driver rc=$?"
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r3z/driver_cmd_*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1], round(d["value"],1), "lat", round(d["prove_latency_ms"],3), "errors", d["errors"])
+PY
