@@ -426,6 +426,10 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            slab = getattr(self, "_graph_slab", None)      # DeviceGraph's cached allocation (luminair_amd/graph.py)
+            if slab is not None:
+                slab.free()
+                self._graph_slab = None
             self.lib.lib.lmn_ctx_destroy(self.handle)
             self.handle = None
 

@@ -28,6 +28,32 @@ _NCOLS = {0: 15, 1: 16, 2: 13, 3: 12, 5: 14, 6: 15, 7: 13, 8: 16, 9: 12, 11: 12,
 _LUT_OF = {3: ("sin", 4), 9: ("exp2", 10), 11: ("log2", 12)}     # op kind -> (LUT name, lookup-table kind)
 
 
+class _SlabLease(backend.DeviceBuffer):
+    """The one device allocation of a gen_trace call.  `free()` hands it back to the context's one-slot cache instead
+    of hipFree, so that a stream of small graphs on one context does not pay a hipMalloc / hipFree pair (~0.1 ms) per
+    graph; a lease that is still in use is never handed out again (the cache only holds returned slabs)."""
+
+    def free(self):
+        if self.ptr and self.owned:
+            cached = getattr(self.ctx, "_graph_slab", None)
+            if cached is None or cached.nbytes < self.nbytes:
+                if cached is not None:
+                    cached.free()
+                self.ctx._graph_slab = backend.DeviceBuffer(self.ctx, self.ptr, self.nbytes)
+            else:
+                backend.DeviceBuffer.free(self)
+        self.ptr = 0
+
+
+def _lease_slab(ctx, need: int) -> _SlabLease:
+    cached = getattr(ctx, "_graph_slab", None)
+    if cached is not None and cached.nbytes >= need:
+        ctx._graph_slab = None
+        return _SlabLease(ctx, cached.ptr, cached.nbytes)
+    b = ctx.alloc(need)
+    return _SlabLease(ctx, b.ptr, b.nbytes)
+
+
 @dataclass
 class GraphTensor:
     node_id: int
@@ -279,9 +305,34 @@ class DeviceGraph:
         # one allocation for all tables and tensors (hipMalloc per node would dominate small graphs); the trace
         # calls are stream-ordered, so nothing waits until the tables are proved or a tensor is read back
         al = lambda nbytes: (nbytes + 255) & ~255
-        need = sum(al(total[k] * _NCOLS[k] * 4) for k in total) + sum(al(n.out.size * 4) for n in self.nodes) + \
-            sum(al(n.host.size * 4) for n in self.nodes if n.host is not None)
-        slab = ctx.alloc(need)
+        # host data that has to reach the device: graph inputs, LUT output columns, zeroed multiplicity tables - packed
+        # into ONE staging array and uploaded with one copy (one synchronisation instead of one per tensor)
+        stage_parts, stage_off, cursor_h = [], {}, [0]
+
+        def stage(key, arr):
+            a = np.ascontiguousarray(arr).reshape(-1).view(np.uint32)
+            stage_off[key] = (cursor_h[0], a.nbytes)
+            pad = (al(a.nbytes) - a.nbytes) // 4
+            stage_parts.append(a)
+            if pad:
+                stage_parts.append(np.zeros(pad, dtype=np.uint32))
+            cursor_h[0] += al(a.nbytes)
+
+        for n in self.nodes:
+            if n.host is not None:
+                stage(("in", n.out.node_id), n.host.astype(np.int32, copy=False))
+        luts_out = {}
+        for kind in sorted(total):
+            if kind in _LUT_OF:
+                name, _ = _LUT_OF[kind]
+                lo, hi, (c0, c1) = self.luts[name]
+                stage(("lut1", name), c1)
+                stage(("lutm", name), np.zeros(len(c0), dtype=np.uint32))
+                luts_out[name] = (c0, c1)
+        if int(K.LessThan) in total:
+            stage(("rc",), np.zeros(256, dtype=np.uint32))
+        need = sum(al(total[k] * _NCOLS[k] * 4) for k in total) + sum(al(n.out.size * 4) for n in self.nodes) + cursor_h[0]
+        slab = _lease_slab(ctx, need)
         cursor = [0]
 
         def carve(nbytes):
@@ -289,29 +340,29 @@ class DeviceGraph:
             cursor[0] += al(nbytes)
             return v
 
+        staged = carve(cursor_h[0]) if cursor_h[0] else None
+        if staged is not None:
+            ctx.upload_to(staged, np.concatenate(stage_parts))
+        dev_of = lambda key: staged.view(*stage_off[key])
         tables = {k: carve(total[k] * _NCOLS[k] * 4) for k in total}
         offset = {k: 0 for k in total}
         bufs = [slab]
-        lut_dev, lut_tables, luts_out = {}, {}, {}
+        lut_dev, lut_tables = {}, {}
         for kind in sorted(total):
             if kind in _LUT_OF:
                 name, lookup_kind = _LUT_OF[kind]
-                lo, hi, (c0, c1) = self.luts[name]
-                lut_dev[name] = (ctx.upload(c1), ctx.upload(np.zeros(len(c0), dtype=np.uint32)))   # outputs, multiplicities
-                bufs += list(lut_dev[name])
-                lut_tables[lookup_kind] = (lut_dev[name][1], len(c0))
-                luts_out[name] = (c0, c1)
+                lut_dev[name] = (dev_of(("lut1", name)), dev_of(("lutm", name)))   # outputs, multiplicities
+                lut_tables[lookup_kind] = (lut_dev[name][1], len(self.luts[name][2][0]))
         rc_mult = None
         if int(K.LessThan) in total:
-            rc_mult = ctx.upload(np.zeros(256, dtype=np.uint32))
-            bufs.append(rc_mult)
+            rc_mult = dev_of(("rc",))
             lut_tables[int(K.RangeCheckLookup)] = (rc_mult, 256)
         for n in self.nodes:
             t = n.out
             common = dict(num_consumers=t.consumers, is_final_output=t.is_output, rows=tables[n.kind],
                           row_offset=offset[n.kind], out=carve(t.size * 4))
             if n.kind == int(K.Inputs):
-                src = ctx.upload_to(carve(n.host.size * 4), n.host.reshape(-1))
+                src = dev_of(("in", t.node_id))
                 _, t.buf = ctx.trace_elementwise(n.kind, src, None, t.size, node_id=t.node_id, input_ids=(),
                                                  input_mults=(), **common)
             elif n.kind in reduces:
