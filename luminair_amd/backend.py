@@ -97,7 +97,7 @@ EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_col
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
-           "lmn_trace_elementwise_v", "lmn_trace_contiguous", "lmn_trace_lut", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
+           "lmn_trace_elementwise_v", "lmn_trace_contiguous", "lmn_trace_lut", "lmn_trace_lut_ranges", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
            "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
            "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_view", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
@@ -211,6 +211,9 @@ class Library:
         lib.lmn_trace_lut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_uint64,
                                       C.POINTER(LmnNodeInfo), C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p]
+        lib.lmn_trace_lut_ranges.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(LmnView), C.c_uint64,
+                                             C.POINTER(LmnNodeInfo), C.c_void_p, C.POINTER(LmnRange), C.c_uint32, C.c_void_p,
+                                             C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lmn_trace_less_than.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(LmnView), C.c_void_p, C.POINTER(LmnView),
                                             C.c_uint64, C.POINTER(LmnNodeInfo), C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.c_void_p]
@@ -621,18 +624,25 @@ class Context:
         return rows, out
 
     def trace_lut(self, kind: int, inp: DeviceBuffer, n: int, node_id: int, input_id: int, num_consumers: int,
-                  lut_col1: DeviceBuffer, lo: int, lut_len: int, mult: DeviceBuffer, is_final_output: bool = False,
-                  input_mult: int = -1, view: Optional[LmnView] = None, rows: Optional[DeviceBuffer] = None,
-                  row_offset: int = 0, out: Optional[DeviceBuffer] = None):
-        """`process_trace` of a Sin / Exp2 / Log2 node; `mult` (the lookup component's table) is updated in place."""
+                  lut_col1: DeviceBuffer, lo: int = 0, lut_len: int = 0, mult: DeviceBuffer = None,
+                  is_final_output: bool = False, input_mult: int = -1, view: Optional[LmnView] = None,
+                  rows: Optional[DeviceBuffer] = None, row_offset: int = 0, out: Optional[DeviceBuffer] = None,
+                  ranges: Optional[Sequence[Tuple[int, int]]] = None):
+        """`process_trace` of a Sin / Exp2 / Log2 node; `mult` (the lookup component's table) is updated in place.
+        The LUT enumerates either the single range lo .. lo + lut_len - 1 or `ranges` (ascending, disjoint)."""
         if rows is None:
             rows = self.alloc((row_offset + n) * 12 * 4)
         out = out or self.alloc(n * 4)
         info = LmnNodeInfo(node_id, (C.c_uint32 * 2)(input_id, 0), num_consumers, 1 if is_final_output else 0,
                            (C.c_int32 * 2)(input_mult, 0))
-        self._check(self.lib.lib.lmn_trace_lut(self.handle, kind, inp.ptr, C.byref(view) if view is not None else None, n,
-                                               C.byref(info), lut_col1.ptr, lo, lut_len, mult.ptr, rows.ptr, row_offset,
-                                               out.ptr))
+        vp = C.byref(view) if view is not None else None
+        if ranges is None:
+            self._check(self.lib.lib.lmn_trace_lut(self.handle, kind, inp.ptr, vp, n, C.byref(info), lut_col1.ptr, lo,
+                                                   lut_len, mult.ptr, rows.ptr, row_offset, out.ptr))
+        else:
+            arr = (LmnRange * len(ranges))(*[LmnRange(int(a), int(b)) for a, b in ranges])
+            self._check(self.lib.lib.lmn_trace_lut_ranges(self.handle, kind, inp.ptr, vp, n, C.byref(info), lut_col1.ptr,
+                                                          arr, len(ranges), mult.ptr, rows.ptr, row_offset, out.ptr))
         return rows, out
 
     def trace_sum_reduce(self, inp: DeviceBuffer, front: int, dim: int, back: int, node_id: int, input_id: int,

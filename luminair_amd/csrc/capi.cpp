@@ -323,9 +323,19 @@ int lmn_trace_contiguous(lmn_ctx* ctx, const int32_t* input_dev, uint64_t in_siz
 int lmn_trace_lut(lmn_ctx* ctx, uint32_t kind, const int32_t* input_dev, const lmn_view* view, uint64_t n,
                   const lmn_node_info* info, const uint32_t* lut_col1_dev, int32_t lo, uint32_t lut_len,
                   uint32_t* mult_dev, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
+  if (!ctx || !input_dev || !info || !lut_col1_dev || !mult_dev || !rows_dev || lut_len == 0) return LMN_ERR_INVALID_ARGUMENT;
+  const lmn_range one{(int64_t)lo, (int64_t)lo + (int64_t)lut_len - 1};
+  return guard(ctx, [&] {
+    ctx->impl->trace_lut(kind, input_dev, view, n, *info, lut_col1_dev, &one, 1, mult_dev, rows_dev, row_offset, out_dev);
+  });
+}
+
+int lmn_trace_lut_ranges(lmn_ctx* ctx, uint32_t kind, const int32_t* input_dev, const lmn_view* view, uint64_t n,
+                         const lmn_node_info* info, const uint32_t* lut_col1_dev, const lmn_range* ranges, uint32_t n_ranges,
+                         uint32_t* mult_dev, uint32_t* rows_dev, uint64_t row_offset, int32_t* out_dev) {
   if (!ctx || !input_dev || !info || !lut_col1_dev || !mult_dev || !rows_dev) return LMN_ERR_INVALID_ARGUMENT;
   return guard(ctx, [&] {
-    ctx->impl->trace_lut(kind, input_dev, view, n, *info, lut_col1_dev, lo, lut_len, mult_dev, rows_dev, row_offset, out_dev);
+    ctx->impl->trace_lut(kind, input_dev, view, n, *info, lut_col1_dev, ranges, n_ranges, mult_dev, rows_dev, row_offset, out_dev);
   });
 }
 

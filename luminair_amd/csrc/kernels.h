@@ -132,9 +132,18 @@ struct TraceView {  // strided view; ndim == 0: contiguous
 void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv, const int32_t* rhs, const TraceView& rv,
                               uint64_t n, const TraceNode& nd, uint32_t* rows, int32_t* out, uint32_t* aux,
                               lmn_stream_t s);
-// LUT op rows + LUT multiplicities; *err_flag (device word) is set when an input falls outside the LUT range
+// The value ranges a LUT enumerates, ascending and disjoint (`LookupLayout::ranges` after `coalesce_ranges`,
+// crates/graph/src/graph.rs:665-691): LUT row of value v in range r = base[r] + (v - lo[r])
+// (`LookupLayout::find_index`, crates/air/src/preprocessed.rs:60-77).
+constexpr int LUT_MAX_RANGES = 16;
+struct LutRanges {
+  int n;
+  int32_t lo[LUT_MAX_RANGES], hi[LUT_MAX_RANGES];
+  uint32_t base[LUT_MAX_RANGES];
+};
+// LUT op rows + LUT multiplicities; *err_flag (device word) is set when an input falls outside every range
 void launch_trace_lut(const int32_t* input, const TraceView& view, uint64_t n, const TraceNode& nd,
-                      const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                      const uint32_t* lut_col1, const LutRanges& ranges, uint32_t* mult, uint32_t* rows,
                       int32_t* out, uint32_t* err_flag, lmn_stream_t s);
 
 void launch_trace_reduce(bool is_max, const int32_t* input, uint64_t front, uint64_t dim, uint64_t back,

@@ -325,7 +325,7 @@ void launch_trace_elementwise(int kind, const int32_t* lhs, const TraceView& lv,
 // Sin / Exp2 / Log2 rows (sin/table.rs: node, input, idx, is_last, next_node, next_input, next_idx, input, out,
 // input_mult, out_mult, lookup_mult) with out read from the LUT's output column, plus the LUT multiplicities.
 LMN_KERNEL k_trace_lut(const int32_t* __restrict__ input, TraceView view, uint64_t n, TraceNode nd,
-                       const uint32_t* __restrict__ lut1, int32_t lo, uint32_t lut_len, uint32_t* __restrict__ mult,
+                       const uint32_t* __restrict__ lut1, LutRanges rg, uint32_t* __restrict__ mult,
                        uint32_t* __restrict__ rows, int32_t* __restrict__ out, uint32_t* __restrict__ err_flag) {
   constexpr int NC = 12, ST = 13;
   LMN_SHARED uint32_t tile[TPB * ST];
@@ -333,9 +333,12 @@ LMN_KERNEL k_trace_lut(const int32_t* __restrict__ input, TraceView view, uint64
   const uint64_t r = row0 + threadIdx.x;
   if (r < n) {
     const int64_t a = input[view_offset(view, r)];
-    const int64_t li = a - (int64_t)lo;
+    // LookupLayout::find_index: the range that holds `a` (few ranges: a linear scan of block-uniform bounds)
+    int64_t li = -1;
+    for (int k = 0; k < rg.n; ++k)
+      if (a >= (int64_t)rg.lo[k] && a <= (int64_t)rg.hi[k]) li = (int64_t)rg.base[k] + (a - (int64_t)rg.lo[k]);
     uint32_t ow = 0u;
-    if (li < 0 || li >= (int64_t)lut_len) {
+    if (li < 0) {
       *err_flag = 1u;
     } else {
       ow = lut1[li];
@@ -355,9 +358,9 @@ LMN_KERNEL k_trace_lut(const int32_t* __restrict__ input, TraceView view, uint64
 }
 
 void launch_trace_lut(const int32_t* input, const TraceView& view, uint64_t n, const TraceNode& nd,
-                      const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                      const uint32_t* lut_col1, const LutRanges& ranges, uint32_t* mult, uint32_t* rows,
                       int32_t* out, uint32_t* err_flag, lmn_stream_t s) {
-  LMN_LAUNCH(k_trace_lut, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, input, view, n, nd, lut_col1, lo, lut_len, mult, rows, out,
+  LMN_LAUNCH(k_trace_lut, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, input, view, n, nd, lut_col1, ranges, mult, rows, out,
              err_flag);
 }
 

@@ -342,7 +342,7 @@ static TraceView trace_view(const lmn_view* v, uint64_t n) {
 
 // `process_trace` of a Sin / Exp2 / Log2 node on a device tensor; fills the LUT multiplicity column too
 void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* view, uint64_t n, const lmn_node_info& info,
-                        const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                        const uint32_t* lut_col1, const lmn_range* ranges, uint32_t n_ranges, uint32_t* mult, uint32_t* rows,
                         uint64_t row_offset, int32_t* out) {
 #ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
@@ -350,11 +350,26 @@ void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* vie
   if (kind != LMN_KIND_SIN && kind != LMN_KIND_EXP2 && kind != LMN_KIND_LOG2)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: kind must be Sin, Exp2 or Log2");
   if (n == 0) throw LmnError(LMN_ERR_EMPTY_TRACE, "TraceError::EmptyTrace");
-  if (n >= (1ull << 31) || lut_len == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (n >= (1ull << 31)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (!ranges || n_ranges == 0 || n_ranges > (uint32_t)LUT_MAX_RANGES)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: 1..16 value ranges");
+  LutRanges rg{};
+  rg.n = (int)n_ranges;
+  uint64_t base = 0;
+  for (uint32_t k = 0; k < n_ranges; ++k) {
+    // ascending, disjoint, inside the Fixed<12> range the LUT generator accepts (coalesce_ranges' output)
+    if (ranges[k].hi < ranges[k].lo || ranges[k].lo <= -(1ll << 30) || ranges[k].hi >= (1ll << 30) ||
+        (k > 0 && ranges[k].lo <= ranges[k - 1].hi))
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: ranges must be ascending, disjoint and inside (-2^30, 2^30)");
+    rg.lo[k] = (int32_t)ranges[k].lo;
+    rg.hi[k] = (int32_t)ranges[k].hi;
+    rg.base[k] = (uint32_t)base;
+    base += (uint64_t)(ranges[k].hi - ranges[k].lo + 1);
+    if (base > (1ull << 26)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: LUT larger than 2^26 rows");
+  }
   const TraceView tv = trace_view(view, n);
-  // bad_flag_ is zero between calls; the kernel sets it when an input misses the LUT range
-  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, lo, lut_len, mult, rows + row_offset * 12ull, out, bad_flag_,
-                   stream_);
+  // bad_flag_ is zero between calls; the kernel sets it when an input misses every range
+  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, rg, mult, rows + row_offset * 12ull, out, bad_flag_, stream_);
   uint32_t err = 0;
   lmn_d2h(&err, bad_flag_, 4, stream_);
   lmn_sync(stream_);

@@ -181,7 +181,7 @@ class Context {
   void trace_contiguous(const int32_t* input, uint64_t in_size, const lmn_view* view, uint64_t out_size,
                         const lmn_node_info& info, uint32_t* rows, uint64_t row_offset, int32_t* out);
   void trace_lut(uint32_t kind, const int32_t* input, const lmn_view* view, uint64_t n, const lmn_node_info& info,
-                 const uint32_t* lut_col1, int32_t lo, uint32_t lut_len, uint32_t* mult, uint32_t* rows,
+                 const uint32_t* lut_col1, const lmn_range* ranges, uint32_t n_ranges, uint32_t* mult, uint32_t* rows,
                  uint64_t row_offset, int32_t* out);
   void device_free(void* p);
 

@@ -110,6 +110,7 @@ class DeviceGraph:
         self.nodes: List[_Node] = []
         self._next_id = 0
         self.luts: Dict[str, tuple] = {}
+        self.lut_ranges: Dict[str, list] = {}      # LUTs declared with several ranges (set_lut_ranges)
 
     def _tensor(self, shape) -> GraphTensor:
         t = GraphTensor(self._next_id, tuple(int(s) for s in shape))
@@ -260,10 +261,20 @@ class DeviceGraph:
         graph.rs:61-159); the columns are generated on the host as the reference does (f64 math)."""
         from . import synthetic
         self.luts[name] = (int(lo), int(hi), synthetic.make_lut(name, int(lo), int(hi)))
+        self.lut_ranges.pop(name, None)
+
+    def set_lut_ranges(self, name: str, ranges):
+        """A LUT over SEVERAL value ranges - what `gen_circuit_settings` yields when the graph applies the function
+        on disjoint input ranges (one padded range per op, coalesced: graph.rs:61-159, 665-691).  `ranges`: ascending,
+        disjoint (lo, hi) pairs; columns from `lmn_lut_from_ranges` (`SinPreProcessed::gen_column` and siblings)."""
+        rg = [(int(a), int(b)) for a, b in ranges]
+        cols = self.ctx.lib.lut_from_ranges(name, rg)
+        self.luts[name] = (rg[0][0], rg[-1][1], cols)
+        self.lut_ranges[name] = rg
 
     def _lut_op(self, kind, a) -> GraphTensor:
         if _LUT_OF[kind][0] not in self.luts:
-            raise ValueError("declare the LUT range with set_lut(%r, lo, hi) first" % _LUT_OF[kind][0])
+            raise ValueError("declare the LUT range with set_lut(%r, lo, hi) or set_lut_ranges first" % _LUT_OF[kind][0])
         v = self._consume(a)
         t = self._tensor(v.shape)
         self.nodes.append(_Node(kind, t, [v]))
@@ -386,7 +397,7 @@ class DeviceGraph:
                 v = n.inputs[0]
                 _, t.buf = ctx.trace_lut(n.kind, v.base.buf, t.size, node_id=t.node_id, input_id=v.base.node_id,
                                          lut_col1=lut_dev[name][0], lo=lo, lut_len=hi - lo + 1, mult=lut_dev[name][1],
-                                         view=view_of(v), **common)
+                                         view=view_of(v), ranges=self.lut_ranges.get(name), **common)
             else:
                 ins = n.inputs
                 _, t.buf = ctx.trace_elementwise(

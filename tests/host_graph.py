@@ -77,8 +77,15 @@ def host_tables(g):
             a = read_view(vals, n.inputs[0])
             rows, c = syn.unary_lut_rows(name, a, lo, t.node_id, ids[0], (-1, om))
             out = np.rint(syn._LUT_FN[name](a / S) * S).astype(np.int64)
-            cnt = lut_counts.setdefault(lk, np.zeros(hi - lo + 1, dtype=np.int64))
-            cnt[:len(c)] += c
+            ranges = g.lut_ranges.get(name) or [(lo, hi)]
+            n_vals = sum(b - a_ + 1 for a_, b in ranges)
+            cnt = lut_counts.setdefault(lk, np.zeros(n_vals, dtype=np.int64))
+            # LookupLayout::find_index (preprocessed.rs:60-77): values of earlier ranges first
+            base = 0
+            for a_, b in ranges:
+                sel = a[(a >= a_) & (a <= b)]
+                cnt[base:base + (b - a_ + 1)] += np.bincount(sel - a_, minlength=b - a_ + 1)
+                base += b - a_ + 1
         else:
             raise ValueError("host mirror: kind %d" % kind)
         vals[t.node_id] = np.asarray(out, dtype=np.int64).reshape(-1)

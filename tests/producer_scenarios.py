@@ -211,11 +211,20 @@ def contiguous_expanded(g, rng):
     return [g.mul(b, g.input(rnd(rng, (3, 4))))]
 
 
+def lut_over_several_ranges(g, rng):
+    """Two Sin nodes on disjoint input ranges -> one LUT over the coalesced ranges.  The ranges are the ones of the
+    reference's own unit test of `LookupLayout::find_index` (crates/air/src/preprocessed.rs:581-634)."""
+    g.set_lut_ranges("sin", [(-100, -50), (0, 10), (200, 210)])
+    x = g.input(np.concatenate([rng.integers(-100, -49, size=20), rng.integers(0, 11, size=12)]).reshape(4, 8))
+    y = g.input(np.concatenate([rng.integers(200, 211, size=9), rng.integers(-100, -49, size=7)]).reshape(4, 4))
+    return [g.sin(x), g.sin(y)]
+
+
 OPS = ([binary_case(op, sa, sb) for op in ("add", "mul") for sa, sb in BINARY_SHAPES]
        + [unary_case(op, s) for op in ("sin", "sqrt", "exp2", "recip") for s in UNARY_SHAPES]
        + [reduce_case("sum"), reduce_case("max")]
        + [less_than_case(s) for s in ((4, 4), (17, 3), (3, 4))]
-       + [contiguous_slice, contiguous_permuted, contiguous_expanded])
+       + [contiguous_slice, contiguous_permuted, contiguous_expanded, lut_over_several_ranges])
 
 
 def run_scenario(lib, build, seed, device=0):

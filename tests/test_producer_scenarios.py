@@ -30,3 +30,44 @@ _CPU_OPS = [f for f in ps.OPS if "32x32" not in f.__name__]
 @pytest.mark.parametrize("build", _CPU_OPS, ids=lambda f: f.__name__)
 def test_op_shape_matrix(lib, build):
     ps.run_scenario(lib, build, 7)
+
+
+def test_lut_index_matches_the_reference_unit_test(lib):
+    """`LookupLayout::find_index` on the device (`lmn_trace_lut_ranges`) against the reference's own unit-test vector
+    (crates/air/src/preprocessed.rs:581-634: ranges (-100,-50), (0,10), (200,210); values in the gaps have no index)."""
+    import numpy as np
+    from luminair_amd.graph import DeviceGraph
+    ranges = [(-100, -50), (0, 10), (200, 210)]
+    expected = {-100: 0, -75: 25, -50: 50, 0: 51, 5: 56, 10: 61, 200: 62, 205: 67, 210: 72}
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    g = DeviceGraph(ctx)
+    g.set_lut_ranges("sin", ranges)
+    vals = np.array(sorted(expected), dtype=np.int64)
+    g.output(g.sin(g.input(vals)))
+    tables, luts, bufs = g.gen_trace()
+    mult = {k: ctx.download(b.view(0, n * 4)) for k, b, n in tables}[4]          # the SinLookup table
+    assert len(mult) == 128 and int(mult.sum()) == len(vals)                       # 73 values -> 2^7 rows
+    assert sorted(np.nonzero(mult)[0].tolist()) == sorted(expected.values())
+    c0 = luts["sin"][0]
+    for v, idx in expected.items():
+        assert int(c0[idx]) == (v % ((1 << 31) - 1))                               # the LUT's value column agrees
+    for b in bufs:
+        b.free()
+    for gap in (-49, 11, 199, -101, 211):
+        g2 = DeviceGraph(ctx)
+        g2.set_lut_ranges("sin", ranges)
+        g2.output(g2.sin(g2.input(np.array([gap, 0, 5]))))
+        with pytest.raises(backend.LuminairBackendError) as e:
+            g2.gen_trace()
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    # ranges out of order / overlapping / too many are rejected at the boundary
+    for bad in ([(0, 10), (-5, -1)], [(0, 10), (10, 20)], [(i * 10, i * 10 + 5) for i in range(17)]):
+        g3 = DeviceGraph(ctx)
+        g3.luts["sin"] = (bad[0][0], bad[-1][1], luts["sin"])
+        g3.lut_ranges["sin"] = bad
+        g3.output(g3.sin(g3.input(np.array([bad[0][0]]))))
+        with pytest.raises(backend.LuminairBackendError):
+            g3.gen_trace()
+    ctx.close()
