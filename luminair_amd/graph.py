@@ -273,8 +273,6 @@ class DeviceGraph:
         self.lut_ranges[name] = rg
 
     def _lut_op(self, kind, a) -> GraphTensor:
-        if _LUT_OF[kind][0] not in self.luts:
-            raise ValueError("declare the LUT range with set_lut(%r, lo, hi) or set_lut_ranges first" % _LUT_OF[kind][0])
         v = self._consume(a)
         t = self._tensor(v.shape)
         self.nodes.append(_Node(kind, t, [v]))
@@ -330,6 +328,9 @@ class DeviceGraph:
             cursor_h[0] += al(a.nbytes)
 
         for n in self.nodes:
+            if n.kind in _LUT_OF and _LUT_OF[n.kind][0] not in self.luts:
+                raise ValueError("no LUT for %r: call gen_circuit_settings() (or set_lut / set_lut_ranges) before gen_trace"
+                                 % _LUT_OF[n.kind][0])
             if n.host is not None:
                 stage(("in", n.out.node_id), n.host.astype(np.int32, copy=False))
         luts_out = {}
@@ -410,3 +411,104 @@ class DeviceGraph:
 
     def read(self, t: GraphTensor) -> np.ndarray:
         return self.ctx.download(t.buf, np.int32).reshape(t.shape)
+
+    # ---- gen_circuit_settings (crates/graph/src/graph.rs:61-159): a HOST dry run, as in the reference
+    def _dry_run(self) -> Dict[int, np.ndarray]:
+        """Every node's values as Fixed<12> integers, computed on the host with the same integer rules as the device
+        kernels (`Operator::process` in the reference: plain CPU execution, no trace)."""
+        S = 4096
+        fn = {int(TraceTableKind.Sin): np.sin, int(TraceTableKind.Exp2): np.exp2, int(TraceTableKind.Log2): np.log2}
+        K = TraceTableKind
+        vals: Dict[int, np.ndarray] = {}
+
+        def view(v):
+            base = vals[v.base.node_id].reshape(-1)
+            idx = np.full(v.shape, v.offset, dtype=np.int64)
+            for ax, (d, st) in enumerate(zip(v.shape, v.strides)):
+                shp = [1] * len(v.shape)
+                shp[ax] = d
+                idx = idx + (np.arange(d, dtype=np.int64) * st).reshape(shp)
+            return base[idx.reshape(-1)]
+
+        for n in self.nodes:
+            k = n.kind
+            if k == int(K.Inputs):
+                out = n.host.astype(np.int64).reshape(-1)
+            elif k in (int(K.Add), int(K.Mul), int(K.Rem), int(K.LessThan)):
+                a, b = view(n.inputs[0]), view(n.inputs[1])
+                out = a + b if k == int(K.Add) else (a * b) >> 12 if k == int(K.Mul) else a % b if k == int(K.Rem) \
+                    else np.where(a < b, S, 0)
+            elif k == int(K.Recip):
+                out = (S * S) // view(n.inputs[0])
+            elif k == int(K.Sqrt):
+                a = view(n.inputs[0])
+                out = np.array([int(np.floor(np.sqrt(float(x) * S))) for x in a], dtype=np.int64)
+                out = np.where(out * out > a * S, out - 1, out)
+                out = np.where((out + 1) * (out + 1) <= a * S, out + 1, out)
+            elif k == int(K.Contiguous):
+                out = view(n.inputs[0])
+            elif k in (int(K.SumReduce), int(K.MaxReduce)):
+                a = n.inputs[0].base
+                x = np.moveaxis(vals[a.node_id].reshape(a.shape), n.axis, -1).reshape(-1, a.shape[n.axis])
+                out = x.sum(axis=1) if k == int(K.SumReduce) else x.max(axis=1)
+            elif k in fn:
+                out = np.rint(fn[k](view(n.inputs[0]) / S) * S).astype(np.int64)
+            else:
+                raise ValueError("dry run: kind %d" % k)
+            vals[n.out.node_id] = np.asarray(out, dtype=np.int64).reshape(-1)
+        return vals
+
+    def gen_circuit_settings(self):
+        """`LuminairGraph::gen_circuit_settings` (crates/graph/src/graph.rs:61-159): dry-run the graph, give every
+        Sin / Exp2 / Log2 node the min..max of its source BUFFER padded by 10 % of the span
+        (`compute_padded_range_from_srcs` / `buffer_range`, crates/graph/src/utils.rs:44-82), coalesce overlapping or
+        adjacent ranges per function (`coalesce_ranges`, graph.rs:665-691), and announce the 8-bit range check when a
+        LessThan node exists.  Declares the LUTs on this graph (`set_lut_ranges`) and returns the `CircuitSettings` in
+        the reference's own (serialisable) form.  Unpinned: `Fixed::from_f64` of the padded bounds is taken as
+        round-to-nearest (numerair is un-vendored); a log2 range whose padding reaches <= 0 is clipped at the smallest
+        positive value (the reference would emit LUT rows from log2 of a non-positive number there)."""
+        from .pie import CircuitSettings, Lookup, LookupLayout, RangeCheckLookup
+        S = 4096.0
+        vals = self._dry_run()
+        per_fn = {"sin": [], "exp2": [], "log2": []}
+        for n in self.nodes:
+            if n.kind in _LUT_OF:
+                buf = vals[n.inputs[0].base.node_id]
+                lo_f, hi_f = float(buf.min()) / S, float(buf.max()) / S
+                delta = (hi_f - lo_f) * 0.10
+                rnd = lambda x: int(np.floor(abs(x) * S + 0.5)) * (1 if x >= 0 else -1)
+                lo, hi = rnd(lo_f - delta), rnd(hi_f + delta)
+                name = _LUT_OF[n.kind][0]
+                if name == "log2":
+                    lo = max(lo, 1)
+                per_fn[name].append((lo, hi))
+        layouts = {}
+        for name, rg in per_fn.items():
+            if not rg:
+                continue
+            rg.sort()
+            merged = [list(rg[0])]
+            for lo, hi in rg[1:]:
+                if lo <= merged[-1][1] + 1:
+                    merged[-1][1] = max(merged[-1][1], hi)
+                else:
+                    merged.append([lo, hi])
+            merged = [tuple(r) for r in merged]
+            self.set_lut_ranges(name, merged)
+            log_size = self.ctx.lib.lut_log_size(merged)
+            layouts[name] = Lookup(LookupLayout(merged, log_size), [0] * (1 << log_size))
+        rc = RangeCheckLookup([8], 8, [0] * 256) if any(n.kind == int(TraceTableKind.LessThan) for n in self.nodes) else None
+        return CircuitSettings(layouts=layouts or None, range_check=rc)
+
+    def fill_multiplicities(self, settings, tables) -> None:
+        """What `gen_trace(&mut settings)` leaves in the settings' `AtomicMultiplicityColumn`s: the lookup tables'
+        multiplicity columns (downloaded from the device tables `gen_trace` returned)."""
+        kinds = {"sin": 4, "exp2": 10, "log2": 12}
+        by_kind = {k: (b, n) for k, b, n in tables}
+        for name, lk in (settings.layouts or {}).items():
+            if kinds[name] in by_kind:
+                b, n = by_kind[kinds[name]]
+                lk.multiplicities = [int(v) for v in self.ctx.download(b.view(0, n * 4))]
+        if settings.range_check is not None and 14 in by_kind:
+            b, n = by_kind[14]
+            settings.range_check.multiplicities = [int(v) for v in self.ctx.download(b.view(0, n * 4))]

@@ -71,3 +71,49 @@ def test_lut_index_matches_the_reference_unit_test(lib):
         with pytest.raises(backend.LuminairBackendError):
             g3.gen_trace()
     ctx.close()
+
+
+def test_gen_circuit_settings_mirror(lib):
+    """`gen_circuit_settings` -> `gen_trace(&mut settings)` -> `prove(trace, settings)` -> `verify(proof, settings)` as
+    the reference's tests drive it (crates/graph/src/tests/mod.rs:26-44), on a graph whose two Sin nodes see disjoint
+    input ranges (-> one LUT over two coalesced ranges), an Exp2 node and a LessThan node (-> the range check)."""
+    import numpy as np
+    import luminair_amd
+    from luminair_amd.graph import DeviceGraph
+    from luminair_amd.pie import CircuitSettings
+    from host_graph import host_tables
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED
+    ctx = backend.Context(0, cfg, lib)
+    rng = np.random.default_rng(3)
+    g = DeviceGraph(ctx)
+    x = g.input(rng.integers(-900, -600, size=(3, 4)))
+    y = g.input(rng.integers(700, 950, size=(3, 4)))
+    s1, s2 = g.sin(x), g.sin(y)
+    e = g.exp2(g.add(s1, s2))
+    out = g.output(g.less_than(e, g.input(rng.integers(0, 8192, size=(3, 4)))))
+    settings = g.gen_circuit_settings()
+    sin_ranges = settings.layouts["sin"].layout.ranges
+    assert len(sin_ranges) == 2 and sin_ranges[0][1] < sin_ranges[1][0]          # disjoint: not coalesced
+    for (lo, hi), src in zip(sin_ranges, (x, y)):                                 # 10 % padding around the buffer's span
+        v = g.nodes[src.node_id].host
+        span = int(v.max()) - int(v.min())
+        assert lo <= int(v.min()) - span // 10 + 1 and hi >= int(v.max()) + span // 10 - 1
+        assert lo >= int(v.min()) - span // 10 - 1 and hi <= int(v.max()) + span // 10 + 1
+    assert len(settings.layouts["exp2"].layout.ranges) == 1 and settings.range_check is not None
+    tables, luts, bufs = g.gen_trace()
+    want, vals = host_tables(g)
+    for k, buf, n in tables:
+        assert np.array_equal(ctx.download(buf.view(0, n * want[k].shape[1] * 4)).reshape(n, -1), want[k]), k
+    assert np.array_equal(g.read(out).reshape(-1), vals[out.node_id])
+    g.fill_multiplicities(settings, tables)
+    assert sum(settings.layouts["sin"].multiplicities) == 24 and sum(settings.range_check.multiplicities) == 48
+    # the settings (reference form: ranges + multiplicities) survive bincode, feed the prover and the verifier
+    settings2 = CircuitSettings.from_bincode(settings.to_bincode())
+    assert settings2.layouts["sin"].layout.ranges == sin_ranges
+    proof = ctx.prove_tables(tables, settings2.lut_columns(lib))
+    assert proof == ctx.prove_tables(tables, luts)
+    luminair_amd.verify(luminair_amd.LuminairProof(proof), settings2, backend.VARIANT_PINNED, library=lib)
+    for b in bufs:
+        b.free()
+    ctx.close()
