@@ -100,6 +100,12 @@ inline float lmn_event_elapsed_ms(lmn_event_t a, lmn_event_t b) {
   LMN_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
   return ms;
 }
+inline lmn_event_t lmn_event_create_sync() {   // ordering only (no timestamps)
+  hipEvent_t e;
+  LMN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+inline void lmn_stream_wait_event(lmn_stream_t s, lmn_event_t e) { LMN_HIP_CHECK(hipStreamWaitEvent(s, e, 0)); }
 
 #else  // ------------------------------------------------------------------ LMN_EMU (tests only)
 #include <barrier>
@@ -186,4 +192,6 @@ inline void lmn_event_record(lmn_event_t e, lmn_stream_t) {
   *e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 inline float lmn_event_elapsed_ms(lmn_event_t a, lmn_event_t b) { return (float)(*b - *a); }
+inline lmn_event_t lmn_event_create_sync() { return new double(0.0); }
+inline void lmn_stream_wait_event(lmn_stream_t, lmn_event_t) {}
 #endif

@@ -203,6 +203,12 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
       LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     }
   }
+  if (getenv("LMN_FRI_OVERLAP") && atoi(getenv("LMN_FRI_OVERLAP")) != 0) {
+    LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    ev_fork_ = lmn_event_create_sync();
+    ev_join_ = lmn_event_create_sync();
+    have_stream2_ = true;
+  }
 #else
   stream_ = 0;
 #endif
@@ -232,6 +238,12 @@ Context::~Context() {
   if (bad_flag_) lmn_dev_free(bad_flag_);
   if (pin_base_) lmn_host_free_pinned(pin_base_);
 #ifndef LMN_EMU
+  if (have_stream2_) {
+    (void)hipStreamSynchronize(stream2_);
+    (void)hipStreamDestroy(stream2_);
+    lmn_event_destroy(ev_fork_);
+    lmn_event_destroy(ev_join_);
+  }
   (void)hipStreamDestroy(stream_);
 #endif
 }
@@ -526,6 +538,10 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
     int level = max_log;
     while (level >= 0) {
       auto& lc = per_level[level];
+      if (level == wait_before_level_) {   // this level's columns were produced on the second stream
+        lmn_stream_wait_event(stream_, wait_before_level_ev_);
+        wait_before_level_ = -1;
+      }
       // runs of contiguous equal-size columns
       MerkleSegs sg{};
       int nseg = 0;
@@ -1096,6 +1112,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   EventLog* log = g_log(this);
   log->reset();
   memset(&timings, 0, sizeof timings);
+  wait_before_level_ = -1;
 
   // ---- validate + size
   struct TableInfo {
@@ -1584,7 +1601,19 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
           a.out_stride = L;
         }
       }
-      launch_quotients(a, stream_);
+      // unsharded proofs with two LDE sizes: the second (smaller) size is computed on the second stream, next to the
+      // leaf hashing of the first size's quotient columns; build_merkle_levels waits for it before level `ls`
+      const bool overlap = have_stream2_ && !sh && sizes.size() == 2 && ls == sizes[1];
+      if (overlap) {
+        lmn_event_record(ev_fork_, stream_);            // everything enqueued so far (incl. the entry-table upload)
+        lmn_stream_wait_event(stream2_, ev_fork_);
+        launch_quotients(a, stream2_);
+        lmn_event_record(ev_join_, stream2_);
+        wait_before_level_ev_ = ev_join_;
+        wait_before_level_ = ls;
+      } else {
+        launch_quotients(a, stream_);
+      }
       if (sh && !qs) gather_columns(vals, L, 4, Lb);
       quots.push_back({ls, vals, qs});
     }

@@ -251,6 +251,13 @@ class Context {
 
   int device_;
   lmn_stream_t stream_{};
+  // second stream + ordering events: the quotient kernel of the smaller LDE size runs next to the leaf hashing of
+  // the larger one in the first FRI layer (LMN_FRI_OVERLAP=1, experiment)
+  lmn_stream_t stream2_{};
+  lmn_event_t ev_fork_{}, ev_join_{};
+  bool have_stream2_ = false;
+  lmn_event_t wait_before_level_ev_{};
+  int wait_before_level_ = -1;    // build_merkle_levels: make stream_ wait for wait_before_level_ev_ before this level
   Arena arena_;
   int tw_max_log_ = 0;
   // twiddle tables: Y[m] (m>=1), X[k] (k>=2), forward + inverse, device pointers
