@@ -66,6 +66,30 @@ __device__ __forceinline__ void stamp_end(WaveRec& w, WaveRec* out) {
   }                                                                                                \
   static const int name##_ipi = (INSTR_PER_ITER);
 
+#define STREAM_KERNEL_U(name, BODY, INSTR_PER_ITER, UNR)                                                  \
+  __global__ void __launch_bounds__(256) name(uint32_t* out, WaveRec* recs, int iters) {           \
+    uint32_t v[ILP], w[ILP];                                                                       \
+    _Pragma("unroll") for (int k = 0; k < ILP; ++k) {                                              \
+      v[k] = threadIdx.x * 2654435761u + k;                                                        \
+      w[k] = threadIdx.x * 40503u + 977u * k + blockIdx.x;                                         \
+    }                                                                                              \
+    const uint32_t b = threadIdx.x | 1u, c = blockIdx.x + 7u;                                      \
+    (void)b; (void)c;                                                                              \
+    WaveRec rec;                                                                                   \
+    __syncthreads();                                                                               \
+    stamp_begin(rec);                                                                              \
+    for (int it = 0; it < iters; ++it) {                                                           \
+      _Pragma("unroll") for (int u = 0; u < (UNR); ++u) {                                         \
+        _Pragma("unroll") for (int k = 0; k < ILP; ++k) { BODY; }                                  \
+      }                                                                                            \
+    }                                                                                              \
+    stamp_end(rec, recs);                                                                          \
+    uint32_t acc = 0;                                                                              \
+    _Pragma("unroll") for (int k = 0; k < ILP; ++k) acc ^= v[k] ^ w[k];                            \
+    if (acc == 0x12345678u) out[0] = acc;                                                          \
+  }                                                                                                \
+  static const int name##_ipi = (INSTR_PER_ITER);
+
 // one-instruction streams: ILP independent chains; second operands are loop constants shared by all chains
 STREAM_KERNEL(k_add_u32, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k]) : "v"(b)), ILP* UNROLL)
 STREAM_KERNEL(k_fma_f32, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(c)), ILP* UNROLL)
@@ -151,6 +175,372 @@ __global__ void __launch_bounds__(256) k_blake2s_G_plain(uint32_t* out, WaveRec*
   if (acc == 0x12345678u) out[0] = acc;
 }
 static const int k_blake2s_G_plain_ipi = 4 * 4 * 22;
+
+
+// dependence questions (round 3, second pass): ONE fully dependent chain of the plain op per lane, two chains, and a
+// 1:1 mix of a half-rate and a full-rate op in independent chains
+STREAM_KERNEL(k_add_dep1, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[0]) : "v"(b)), ILP* UNROLL)
+STREAM_KERNEL(k_add_dep2, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k & 1]) : "v"(b)), ILP* UNROLL)
+STREAM_KERNEL(k_add_dep4, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k & 3]) : "v"(b)), ILP* UNROLL)
+STREAM_KERNEL(k_mix_add3_xor,
+              if (k & 1) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(c));
+              else asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[k]) : "v"(w[k])), ILP* UNROLL)
+
+// which property of the "plain" quarter round keeps it at 0.25?  single ops it uses, its op sequence on independent chains,
+// and the code-size question (the same independent add stream with a 4 KB loop body)
+STREAM_KERNEL(k_or_b32, asm volatile("v_or_b32 %0, %0, %1" : "+v"(v[k]) : "v"(b)), ILP* UNROLL)
+STREAM_KERNEL(k_lshl_c, asm volatile("v_lshlrev_b32 %0, 7, %0" : "+v"(v[k])), ILP* UNROLL)
+STREAM_KERNEL(k_lshr_c, asm volatile("v_lshrrev_b32 %0, 12, %0" : "+v"(v[k])), ILP* UNROLL)
+STREAM_KERNEL(k_lshr_2reg, asm volatile("v_lshrrev_b32 %1, 12, %0\n v_xor_b32 %0, %0, %1" : "+v"(v[k]), "+v"(w[k])), 2 * ILP* UNROLL)
+STREAM_KERNEL(k_rot_seq, asm volatile("v_xor_b32 %0, %0, %2\n v_lshrrev_b32 %1, 12, %0\n v_lshlrev_b32 %0, 20, %0\n v_or_b32 %0, %0, %1\n v_add_u32 %0, %0, %2"
+                                      : "+v"(v[k]), "+v"(w[k]) : "v"(b)), 5 * ILP* UNROLL)
+STREAM_KERNEL_U(k_add_u32_big, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[k]) : "v"(b)), ILP * 128, 128)
+STREAM_KERNEL_U(k_add_dep1_big, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[0]) : "v"(b)), ILP * 128, 128)
+
+// ---- generated: the same quarter rounds with the independent states of a lane interleaved instruction by instruction
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv4(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4], t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+    t[k] = 0;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %4, %16\n v_add3_u32 %1, %1, %5, %16\n v_add3_u32 %2, %2, %6, %16\n v_add3_u32 %3, %3, %7, %16\n"
+            "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n v_alignbit_b32 %15, %15, %15, 16\n"
+            "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n v_alignbit_b32 %7, %7, %7, 12\n"
+            "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %17\n v_add3_u32 %2, %2, %6, %17\n v_add3_u32 %3, %3, %7, %17\n"
+            "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n v_alignbit_b32 %15, %15, %15, 8\n"
+            "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n v_alignbit_b32 %7, %7, %7, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k] ^ t[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv4_ipi = 16 * 12;
+
+__global__ void __launch_bounds__(256) k_blake2s_G_plain_ilv4(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4], t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+    t[k] = 0;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile(
+            "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %5\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_add_u32 %0, %0, %20\n v_add_u32 %1, %1, %20\n v_add_u32 %2, %2, %20\n v_add_u32 %3, %3, %20\n"
+            "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "v_lshrrev_b32 %16, 16, %12\n v_lshrrev_b32 %17, 16, %13\n v_lshrrev_b32 %18, 16, %14\n v_lshrrev_b32 %19, 16, %15\n"
+            "v_lshlrev_b32 %12, 16, %12\n v_lshlrev_b32 %13, 16, %13\n v_lshlrev_b32 %14, 16, %14\n v_lshlrev_b32 %15, 16, %15\n"
+            "v_or_b32 %12, %12, %16\n v_or_b32 %13, %13, %17\n v_or_b32 %14, %14, %18\n v_or_b32 %15, %15, %19\n"
+            "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "v_lshrrev_b32 %16, 12, %4\n v_lshrrev_b32 %17, 12, %5\n v_lshrrev_b32 %18, 12, %6\n v_lshrrev_b32 %19, 12, %7\n"
+            "v_lshlrev_b32 %4, 20, %4\n v_lshlrev_b32 %5, 20, %5\n v_lshlrev_b32 %6, 20, %6\n v_lshlrev_b32 %7, 20, %7\n"
+            "v_or_b32 %4, %4, %16\n v_or_b32 %5, %5, %17\n v_or_b32 %6, %6, %18\n v_or_b32 %7, %7, %19\n"
+            "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %5\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_add_u32 %0, %0, %21\n v_add_u32 %1, %1, %21\n v_add_u32 %2, %2, %21\n v_add_u32 %3, %3, %21\n"
+            "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "v_lshrrev_b32 %16, 8, %12\n v_lshrrev_b32 %17, 8, %13\n v_lshrrev_b32 %18, 8, %14\n v_lshrrev_b32 %19, 8, %15\n"
+            "v_lshlrev_b32 %12, 24, %12\n v_lshlrev_b32 %13, 24, %13\n v_lshlrev_b32 %14, 24, %14\n v_lshlrev_b32 %15, 24, %15\n"
+            "v_or_b32 %12, %12, %16\n v_or_b32 %13, %13, %17\n v_or_b32 %14, %14, %18\n v_or_b32 %15, %15, %19\n"
+            "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "v_lshrrev_b32 %16, 7, %4\n v_lshrrev_b32 %17, 7, %5\n v_lshrrev_b32 %18, 7, %6\n v_lshrrev_b32 %19, 7, %7\n"
+            "v_lshlrev_b32 %4, 25, %4\n v_lshlrev_b32 %5, 25, %5\n v_lshlrev_b32 %6, 25, %6\n v_lshlrev_b32 %7, 25, %7\n"
+            "v_or_b32 %4, %4, %16\n v_or_b32 %5, %5, %17\n v_or_b32 %6, %6, %18\n v_or_b32 %7, %7, %19\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k] ^ t[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_plain_ilv4_ipi = 16 * 22;
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv8(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[8], b[8], c[8], d[8], t[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+    t[k] = 0;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %8, %32\n v_add3_u32 %1, %1, %9, %32\n v_add3_u32 %2, %2, %10, %32\n v_add3_u32 %3, %3, %11, %32\n v_add3_u32 %4, %4, %12, %32\n v_add3_u32 %5, %5, %13, %32\n v_add3_u32 %6, %6, %14, %32\n v_add3_u32 %7, %7, %15, %32\n"
+            "v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "v_alignbit_b32 %24, %24, %24, 16\n v_alignbit_b32 %25, %25, %25, 16\n v_alignbit_b32 %26, %26, %26, 16\n v_alignbit_b32 %27, %27, %27, 16\n v_alignbit_b32 %28, %28, %28, 16\n v_alignbit_b32 %29, %29, %29, 16\n v_alignbit_b32 %30, %30, %30, 16\n v_alignbit_b32 %31, %31, %31, 16\n"
+            "v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "v_alignbit_b32 %8, %8, %8, 12\n v_alignbit_b32 %9, %9, %9, 12\n v_alignbit_b32 %10, %10, %10, 12\n v_alignbit_b32 %11, %11, %11, 12\n v_alignbit_b32 %12, %12, %12, 12\n v_alignbit_b32 %13, %13, %13, 12\n v_alignbit_b32 %14, %14, %14, 12\n v_alignbit_b32 %15, %15, %15, 12\n"
+            "v_add3_u32 %0, %0, %8, %33\n v_add3_u32 %1, %1, %9, %33\n v_add3_u32 %2, %2, %10, %33\n v_add3_u32 %3, %3, %11, %33\n v_add3_u32 %4, %4, %12, %33\n v_add3_u32 %5, %5, %13, %33\n v_add3_u32 %6, %6, %14, %33\n v_add3_u32 %7, %7, %15, %33\n"
+            "v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "v_alignbit_b32 %24, %24, %24, 8\n v_alignbit_b32 %25, %25, %25, 8\n v_alignbit_b32 %26, %26, %26, 8\n v_alignbit_b32 %27, %27, %27, 8\n v_alignbit_b32 %28, %28, %28, 8\n v_alignbit_b32 %29, %29, %29, 8\n v_alignbit_b32 %30, %30, %30, 8\n v_alignbit_b32 %31, %31, %31, 8\n"
+            "v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "v_alignbit_b32 %8, %8, %8, 7\n v_alignbit_b32 %9, %9, %9, 7\n v_alignbit_b32 %10, %10, %10, 7\n v_alignbit_b32 %11, %11, %11, 7\n v_alignbit_b32 %12, %12, %12, 7\n v_alignbit_b32 %13, %13, %13, 7\n v_alignbit_b32 %14, %14, %14, 7\n v_alignbit_b32 %15, %15, %15, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k] ^ t[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv8_ipi = 16 * 12;
+
+
+// runs of RUN fast-class instructions (v_xor_b32) alternating with runs of RUN slow-class ones (v_add3_u32), ILP independent
+// chains; PRIO 0: no priority changes, 1: slow runs at s_setprio 3 / fast runs at 0, 2: the opposite
+template <int PRIO, int RUN>
+__global__ void __launch_bounds__(256) k_phase(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t v[ILP], w[ILP];
+#pragma unroll
+  for (int k = 0; k < ILP; ++k) {
+    v[k] = threadIdx.x * 2654435761u + k;
+    w[k] = threadIdx.x * 40503u + 977u * k + blockIdx.x;
+  }
+  const uint32_t b = threadIdx.x | 1u, c = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+    if (PRIO == 1) asm volatile("s_setprio 0");
+    if (PRIO == 2) asm volatile("s_setprio 3");
+#pragma unroll
+    for (int u = 0; u < RUN / ILP; ++u) {
+#pragma unroll
+      for (int k = 0; k < ILP; ++k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[k]) : "v"(w[k]));
+    }
+    if (PRIO == 1) asm volatile("s_setprio 3");
+    if (PRIO == 2) asm volatile("s_setprio 0");
+#pragma unroll
+    for (int u = 0; u < RUN / ILP; ++u) {
+#pragma unroll
+      for (int k = 0; k < ILP; ++k) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(b), "v"(c));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < ILP; ++k) acc ^= v[k] ^ w[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// ---- generated: interleaved quarter rounds with s_setprio around the runs of slow-class / fast-class instructions
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv4_prio1(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  asm volatile("s_setprio 3");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %4, %16\n v_add3_u32 %1, %1, %5, %16\n v_add3_u32 %2, %2, %6, %16\n v_add3_u32 %3, %3, %7, %16\n"
+            "s_setprio 0\n v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "s_setprio 3\n v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n v_alignbit_b32 %15, %15, %15, 16\n"
+            "s_setprio 0\n v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "s_setprio 3\n v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n v_alignbit_b32 %7, %7, %7, 12\n"
+            "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %17\n v_add3_u32 %2, %2, %6, %17\n v_add3_u32 %3, %3, %7, %17\n"
+            "s_setprio 0\n v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "s_setprio 3\n v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n v_alignbit_b32 %15, %15, %15, 8\n"
+            "s_setprio 0\n v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "s_setprio 3\n v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n v_alignbit_b32 %7, %7, %7, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv4_prio1_ipi = 16 * 12;
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv4_prio2(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  asm volatile("s_setprio 0");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %4, %16\n v_add3_u32 %1, %1, %5, %16\n v_add3_u32 %2, %2, %6, %16\n v_add3_u32 %3, %3, %7, %16\n"
+            "s_setprio 3\n v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "s_setprio 0\n v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n v_alignbit_b32 %15, %15, %15, 16\n"
+            "s_setprio 3\n v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "s_setprio 0\n v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n v_alignbit_b32 %7, %7, %7, 12\n"
+            "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %17\n v_add3_u32 %2, %2, %6, %17\n v_add3_u32 %3, %3, %7, %17\n"
+            "s_setprio 3\n v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+            "s_setprio 0\n v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n v_alignbit_b32 %15, %15, %15, 8\n"
+            "s_setprio 3\n v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+            "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+            "s_setprio 0\n v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n v_alignbit_b32 %7, %7, %7, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv4_prio2_ipi = 16 * 12;
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv8_prio1(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[8], b[8], c[8], d[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  asm volatile("s_setprio 3");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %8, %32\n v_add3_u32 %1, %1, %9, %32\n v_add3_u32 %2, %2, %10, %32\n v_add3_u32 %3, %3, %11, %32\n v_add3_u32 %4, %4, %12, %32\n v_add3_u32 %5, %5, %13, %32\n v_add3_u32 %6, %6, %14, %32\n v_add3_u32 %7, %7, %15, %32\n"
+            "s_setprio 0\n v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "s_setprio 3\n v_alignbit_b32 %24, %24, %24, 16\n v_alignbit_b32 %25, %25, %25, 16\n v_alignbit_b32 %26, %26, %26, 16\n v_alignbit_b32 %27, %27, %27, 16\n v_alignbit_b32 %28, %28, %28, 16\n v_alignbit_b32 %29, %29, %29, 16\n v_alignbit_b32 %30, %30, %30, 16\n v_alignbit_b32 %31, %31, %31, 16\n"
+            "s_setprio 0\n v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "s_setprio 3\n v_alignbit_b32 %8, %8, %8, 12\n v_alignbit_b32 %9, %9, %9, 12\n v_alignbit_b32 %10, %10, %10, 12\n v_alignbit_b32 %11, %11, %11, 12\n v_alignbit_b32 %12, %12, %12, 12\n v_alignbit_b32 %13, %13, %13, 12\n v_alignbit_b32 %14, %14, %14, 12\n v_alignbit_b32 %15, %15, %15, 12\n"
+            "v_add3_u32 %0, %0, %8, %33\n v_add3_u32 %1, %1, %9, %33\n v_add3_u32 %2, %2, %10, %33\n v_add3_u32 %3, %3, %11, %33\n v_add3_u32 %4, %4, %12, %33\n v_add3_u32 %5, %5, %13, %33\n v_add3_u32 %6, %6, %14, %33\n v_add3_u32 %7, %7, %15, %33\n"
+            "s_setprio 0\n v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "s_setprio 3\n v_alignbit_b32 %24, %24, %24, 8\n v_alignbit_b32 %25, %25, %25, 8\n v_alignbit_b32 %26, %26, %26, 8\n v_alignbit_b32 %27, %27, %27, 8\n v_alignbit_b32 %28, %28, %28, 8\n v_alignbit_b32 %29, %29, %29, 8\n v_alignbit_b32 %30, %30, %30, 8\n v_alignbit_b32 %31, %31, %31, 8\n"
+            "s_setprio 0\n v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "s_setprio 3\n v_alignbit_b32 %8, %8, %8, 7\n v_alignbit_b32 %9, %9, %9, 7\n v_alignbit_b32 %10, %10, %10, 7\n v_alignbit_b32 %11, %11, %11, 7\n v_alignbit_b32 %12, %12, %12, 7\n v_alignbit_b32 %13, %13, %13, 7\n v_alignbit_b32 %14, %14, %14, 7\n v_alignbit_b32 %15, %15, %15, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv8_prio1_ipi = 16 * 12;
+
+__global__ void __launch_bounds__(256) k_blake2s_G_ilv8_prio2(uint32_t* out, WaveRec* recs, int iters) {
+  uint32_t a[8], b[8], c[8], d[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = threadIdx.x + k;
+    b[k] = threadIdx.x * 3u + k;
+    c[k] = threadIdx.x * 5u + k;
+    d[k] = threadIdx.x * 7u + k;
+  }
+  const uint32_t mx = threadIdx.x | 1u, my = blockIdx.x + 7u;
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  asm volatile("s_setprio 0");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile(
+            "v_add3_u32 %0, %0, %8, %32\n v_add3_u32 %1, %1, %9, %32\n v_add3_u32 %2, %2, %10, %32\n v_add3_u32 %3, %3, %11, %32\n v_add3_u32 %4, %4, %12, %32\n v_add3_u32 %5, %5, %13, %32\n v_add3_u32 %6, %6, %14, %32\n v_add3_u32 %7, %7, %15, %32\n"
+            "s_setprio 3\n v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "s_setprio 0\n v_alignbit_b32 %24, %24, %24, 16\n v_alignbit_b32 %25, %25, %25, 16\n v_alignbit_b32 %26, %26, %26, 16\n v_alignbit_b32 %27, %27, %27, 16\n v_alignbit_b32 %28, %28, %28, 16\n v_alignbit_b32 %29, %29, %29, 16\n v_alignbit_b32 %30, %30, %30, 16\n v_alignbit_b32 %31, %31, %31, 16\n"
+            "s_setprio 3\n v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "s_setprio 0\n v_alignbit_b32 %8, %8, %8, 12\n v_alignbit_b32 %9, %9, %9, 12\n v_alignbit_b32 %10, %10, %10, 12\n v_alignbit_b32 %11, %11, %11, 12\n v_alignbit_b32 %12, %12, %12, 12\n v_alignbit_b32 %13, %13, %13, 12\n v_alignbit_b32 %14, %14, %14, 12\n v_alignbit_b32 %15, %15, %15, 12\n"
+            "v_add3_u32 %0, %0, %8, %33\n v_add3_u32 %1, %1, %9, %33\n v_add3_u32 %2, %2, %10, %33\n v_add3_u32 %3, %3, %11, %33\n v_add3_u32 %4, %4, %12, %33\n v_add3_u32 %5, %5, %13, %33\n v_add3_u32 %6, %6, %14, %33\n v_add3_u32 %7, %7, %15, %33\n"
+            "s_setprio 3\n v_xor_b32 %24, %24, %0\n v_xor_b32 %25, %25, %1\n v_xor_b32 %26, %26, %2\n v_xor_b32 %27, %27, %3\n v_xor_b32 %28, %28, %4\n v_xor_b32 %29, %29, %5\n v_xor_b32 %30, %30, %6\n v_xor_b32 %31, %31, %7\n"
+            "s_setprio 0\n v_alignbit_b32 %24, %24, %24, 8\n v_alignbit_b32 %25, %25, %25, 8\n v_alignbit_b32 %26, %26, %26, 8\n v_alignbit_b32 %27, %27, %27, 8\n v_alignbit_b32 %28, %28, %28, 8\n v_alignbit_b32 %29, %29, %29, 8\n v_alignbit_b32 %30, %30, %30, 8\n v_alignbit_b32 %31, %31, %31, 8\n"
+            "s_setprio 3\n v_add_u32 %16, %16, %24\n v_add_u32 %17, %17, %25\n v_add_u32 %18, %18, %26\n v_add_u32 %19, %19, %27\n v_add_u32 %20, %20, %28\n v_add_u32 %21, %21, %29\n v_add_u32 %22, %22, %30\n v_add_u32 %23, %23, %31\n"
+            "v_xor_b32 %8, %8, %16\n v_xor_b32 %9, %9, %17\n v_xor_b32 %10, %10, %18\n v_xor_b32 %11, %11, %19\n v_xor_b32 %12, %12, %20\n v_xor_b32 %13, %13, %21\n v_xor_b32 %14, %14, %22\n v_xor_b32 %15, %15, %23\n"
+            "s_setprio 0\n v_alignbit_b32 %8, %8, %8, 7\n v_alignbit_b32 %9, %9, %9, 7\n v_alignbit_b32 %10, %10, %10, 7\n v_alignbit_b32 %11, %11, %11, 7\n v_alignbit_b32 %12, %12, %12, 7\n v_alignbit_b32 %13, %13, %13, 7\n v_alignbit_b32 %14, %14, %14, 7\n v_alignbit_b32 %15, %15, %15, 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+          : "v"(mx), "v"(my));
+    }
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static const int k_blake2s_G_ilv8_prio2_ipi = 16 * 12;
 
 #define CHECK(x)                                                                  \
   do {                                                                            \
@@ -265,6 +655,59 @@ int main(int argc, char** argv) {
       {"blake2s_G", k_blake2s_G, k_blake2s_G_ipi},
       {"blake2s_G plain", k_blake2s_G_plain, k_blake2s_G_plain_ipi},
   };
+  if (argc > 1 && !strcmp(argv[1], "ilv")) {
+    S more[] = {
+        {"add dep x1", k_add_dep1, k_add_dep1_ipi},
+        {"add dep x2", k_add_dep2, k_add_dep2_ipi},
+        {"add dep x4", k_add_dep4, k_add_dep4_ipi},
+        {"add_u32 (x8)", k_add_u32, k_add_u32_ipi},
+        {"mix add3:xor", k_mix_add3_xor, k_mix_add3_xor_ipi},
+        {"blake2s_G", k_blake2s_G, k_blake2s_G_ipi},
+        {"blake2s_G ilv4", k_blake2s_G_ilv4, k_blake2s_G_ilv4_ipi},
+        {"blake2s_G ilv8", k_blake2s_G_ilv8, k_blake2s_G_ilv8_ipi},
+        {"blake2s_G plain", k_blake2s_G_plain, k_blake2s_G_plain_ipi},
+        {"blake2s_G pl ilv4", k_blake2s_G_plain_ilv4, k_blake2s_G_plain_ilv4_ipi},
+    };
+    for (auto& s : more) {
+      const int iters = (int)(4096ll * 64 / s.ipi);
+      for (int W : {1, 2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, iters, d_out, d_recs, false);
+    }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "why")) {
+    S more[] = {
+        {"or_b32", k_or_b32, k_or_b32_ipi},
+        {"lshlrev const", k_lshl_c, k_lshl_c_ipi},
+        {"lshrrev const", k_lshr_c, k_lshr_c_ipi},
+        {"lshr->tmp, xor", k_lshr_2reg, k_lshr_2reg_ipi},
+        {"rot sequence", k_rot_seq, k_rot_seq_ipi},
+        {"add_u32 4KB body", k_add_u32_big, k_add_u32_big_ipi},
+        {"add dep 4KB body", k_add_dep1_big, k_add_dep1_big_ipi},
+    };
+    for (auto& s : more) {
+      const int iters = (int)(4096ll * 64 / s.ipi);
+      for (int W : {1, 2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, iters, d_out, d_recs, false);
+    }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "prio")) {
+    S more[] = {
+        {"phase 8 prio-", k_phase<0, 8>, 16},      {"phase 8 slow-hi", k_phase<1, 8>, 16},      {"phase 8 fast-hi", k_phase<2, 8>, 16},
+        {"phase 32 prio-", k_phase<0, 32>, 64},    {"phase 32 slow-hi", k_phase<1, 32>, 64},    {"phase 32 fast-hi", k_phase<2, 32>, 64},
+        {"phase 128 prio-", k_phase<0, 128>, 256}, {"phase 128 slow-hi", k_phase<1, 128>, 256}, {"phase 128 fast-hi", k_phase<2, 128>, 256},
+        {"G ilv4", k_blake2s_G_ilv4, k_blake2s_G_ilv4_ipi},
+        {"G ilv4 slow-hi", k_blake2s_G_ilv4_prio1, k_blake2s_G_ilv4_prio1_ipi},
+        {"G ilv4 fast-hi", k_blake2s_G_ilv4_prio2, k_blake2s_G_ilv4_prio2_ipi},
+        {"G ilv8", k_blake2s_G_ilv8, k_blake2s_G_ilv8_ipi},
+        {"G ilv8 slow-hi", k_blake2s_G_ilv8_prio1, k_blake2s_G_ilv8_prio1_ipi},
+        {"G ilv8 fast-hi", k_blake2s_G_ilv8_prio2, k_blake2s_G_ilv8_prio2_ipi},
+    };
+    for (auto& s : more) {
+      const int iters = (int)(4096ll * 64 / s.ipi);
+      for (int W : {2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, iters, d_out, d_recs, false);
+    }
+    return 0;
+  }
   for (auto& s : streams) {
     const int iters = (int)(4096ll * 64 / s.ipi);
     if (pmc) {
