@@ -22,9 +22,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
-# ALU ceilings measured on MI355X with tools/microbench.hip; informational only
-BLAKE2S_PEAK_GCOMP = 39.0                                  # G compressions/s, chip-wide
-BUTTERFLY_PEAK_G = 1.0 / (1.0 / 6326.0 + 2.0 / 12800.0)    # G butterflies/s = 1 M31 mul + 2 add|sub
+# ALU ceilings measured on MI355X with both VALU issue ports in use (tools/microbench_reconcile.hip `prio` / `bfly`,
+# profiles/r3_valu_coissue.txt); informational only
+BLAKE2S_PEAK_GCOMP = 63.8    # G compressions/s chip-wide: 1024 SIMDs x 2.235 GHz x 0.425 instr/clk x 64 lanes / 976 instr
+BUTTERFLY_PEAK_G = 4800.0    # G M31 butterflies/s chip-wide: 0.035 butterflies/clk/SIMD x 2.08 GHz x 1024 SIMDs x 64 lanes
 
 
 def parse_args(argv=None):

@@ -40,50 +40,61 @@ LMN_HD uint32_t b2_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); 
 // it is about to issue - so co-resident waves that execute a quarter round as the compiler schedules it run at 0.25
 // instructions/clk/SIMD.  Grouping the four quarter rounds' instructions by class and raising the wave's priority
 // (s_setprio) while it issues the port-0-only class lets another wave's plain ops take the second port: 0.42/clk/SIMD.
-#define LMN_B2_HALF(a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3, x0, y0, x1, y1, x2, y2, x3, y3)        \
-  asm volatile(                                                                                                           \
-      "v_add3_u32 %0, %0, %4, %16\n v_add3_u32 %1, %1, %5, %18\n v_add3_u32 %2, %2, %6, %20\n v_add3_u32 %3, %3, %7, %22\n"  \
-      "s_setprio 0\n"                                                                                                     \
-      "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"               \
-      "s_setprio 3\n"                                                                                                     \
-      "v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n"          \
-      "v_alignbit_b32 %15, %15, %15, 16\n"                                                                                \
-      "s_setprio 0\n"                                                                                                     \
-      "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"               \
-      "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"                     \
-      "s_setprio 3\n"                                                                                                     \
-      "v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n"                   \
-      "v_alignbit_b32 %7, %7, %7, 12\n"                                                                                   \
-      "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %19\n v_add3_u32 %2, %2, %6, %21\n v_add3_u32 %3, %3, %7, %23\n"  \
-      "s_setprio 0\n"                                                                                                     \
-      "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"               \
-      "s_setprio 3\n"                                                                                                     \
-      "v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n"             \
-      "v_alignbit_b32 %15, %15, %15, 8\n"                                                                                 \
-      "s_setprio 0\n"                                                                                                     \
-      "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"               \
-      "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"                     \
-      "s_setprio 3\n"                                                                                                     \
-      "v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n"                      \
-      "v_alignbit_b32 %7, %7, %7, 7\n"                                                                                    \
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1), "+v"(c2),     \
-        "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                                                                  \
-      : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3));
+template <int LO, int HI>
+__device__ __forceinline__ void b2_half(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t& b0, uint32_t& b1,
+                                        uint32_t& b2, uint32_t& b3, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                        uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t x0, uint32_t y0,
+                                        uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+  asm volatile(
+      "v_add3_u32 %0, %0, %4, %16\n v_add3_u32 %1, %1, %5, %18\n v_add3_u32 %2, %2, %6, %20\n v_add3_u32 %3, %3, %7, %22\n"
+      "s_setprio %24\n"
+      "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+      "s_setprio %25\n"
+      "v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n"
+      "v_alignbit_b32 %15, %15, %15, 16\n"
+      "s_setprio %24\n"
+      "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+      "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+      "s_setprio %25\n"
+      "v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n"
+      "v_alignbit_b32 %7, %7, %7, 12\n"
+      "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %19\n v_add3_u32 %2, %2, %6, %21\n v_add3_u32 %3, %3, %7, %23\n"
+      "s_setprio %24\n"
+      "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+      "s_setprio %25\n"
+      "v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n"
+      "v_alignbit_b32 %15, %15, %15, 8\n"
+      "s_setprio %24\n"
+      "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+      "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+      "s_setprio %25\n"
+      "v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n"
+      "v_alignbit_b32 %7, %7, %7, 7\n"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1), "+v"(c2),
+        "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+      : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "n"(LO), "n"(HI));
+}
+
 
 #undef LMN_B2_ROUND
 #define LMN_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                               \
-  LMN_B2_HALF(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, m[s0], m[s1], m[s2], m[s3], m[s4],   \
-              m[s5], m[s6], m[s7])                                                                                       \
-  LMN_B2_HALF(v0, v1, v2, v3, v5, v6, v7, v4, v10, v11, v8, v9, v15, v12, v13, v14, m[s8], m[s9], m[s10], m[s11],        \
-              m[s12], m[s13], m[s14], m[s15])
-#define LMN_B2_ENTER asm volatile("s_setprio 3");
-#define LMN_B2_LEAVE asm volatile("s_setprio 0");
+  b2_half<LO, HI>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, m[s0], m[s1], m[s2], m[s3],     \
+                  m[s4], m[s5], m[s6], m[s7]);                                                                           \
+  b2_half<LO, HI>(v0, v1, v2, v3, v5, v6, v7, v4, v10, v11, v8, v9, v15, v12, v13, v14, m[s8], m[s9], m[s10], m[s11],    \
+                  m[s12], m[s13], m[s14], m[s15]);
+#define LMN_B2_ENTER asm volatile("s_setprio %0" ::"n"(HI));
+#define LMN_B2_LEAVE asm volatile("s_setprio %0" ::"n"(LO));
 #else
 #define LMN_B2_ENTER
 #define LMN_B2_LEAVE
 #endif
 
-// h <- F(h, m, t, f0).  The sigma schedule is unrolled so message words stay in registers.
+// h <- F(h, m, t, f0).  The sigma schedule is unrolled so message words stay in registers.  LO / HI: wave priority
+// while issuing the any-port / first-port-only instruction runs on the device (LO == HI: constant priority).
+#ifndef LMN_B2_PRIO_HI
+#define LMN_B2_PRIO_HI 3
+#endif
+template <int LO = 0, int HI = LMN_B2_PRIO_HI>
 LMN_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32_t f0) {
   uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
   uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;

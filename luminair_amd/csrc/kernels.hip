@@ -10,6 +10,20 @@ namespace lmn {
 
 constexpr int TPB = 256;
 
+// Wave priority of the short kernels that sit on a proof's serial path (tree tops, FRI tail, scans, small reductions):
+// with several proofs in flight their few waves otherwise wait behind every older wave of the big kernels.
+#ifndef LMN_SERIAL_PRIO
+#define LMN_SERIAL_PRIO 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU)
+#define LMN_SERIAL_KERNEL()                                              \
+  do {                                                                   \
+    if (LMN_SERIAL_PRIO) __builtin_amdgcn_s_setprio(LMN_SERIAL_PRIO);    \
+  } while (0)
+#else
+#define LMN_SERIAL_KERNEL() do { } while (0)
+#endif
+
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 #ifndef LMN_EMU
@@ -437,9 +451,56 @@ struct FftStagePlan {
 
 LMN_HD uint32_t fft_lds_pad(uint32_t e) { return e + (e >> 5); }
 
+// Issue order of one butterfly layer.  gfx950 co-issues two VALU instructions per slot from two different waves, but the
+// multiplier / three-operand / min-max class (v_mad_u64_u32, v_alignbit_b32, v_min_u32) only goes to the first port, which
+// the arbiter gives to the oldest wave whatever it is about to issue (profiles/r3_valu_coissue.txt).  A layer's
+// butterflies are independent, so their instructions are issued class by class - sched_barrier keeps the compiler from
+// re-interleaving them - with the wave's priority raised while it issues the first-port class: another wave's add/sub/and
+// instructions then take the second port (measured on this butterfly: 0.021 -> 0.035 butterflies/clk/SIMD).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU) && !defined(LMN_NO_ISSUE_PHASES)
+#define LMN_PHASE_PORT0()                  \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_setprio(3);         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+#define LMN_PHASE_ANY()                    \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_setprio(0);         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+#else
+#define LMN_PHASE_PORT0() do { } while (0)
+#define LMN_PHASE_ANY() do { } while (0)
+#endif
+
+// out[k] = x[k] * w[k] in M31 for N independent products, issued in phases (field.h m_mul, same arithmetic).  Leaves the
+// wave in the first-port phase.
+template <int N>
+LMN_D void m_mul_phased(const uint32_t (&x)[N], const uint32_t (&w)[N], uint32_t (&out)[N]) {
+  uint64_t pr[N];
+  uint32_t hi[N], s[N], s2[N];
+  LMN_PHASE_PORT0();
+#pragma unroll
+  for (int k = 0; k < N; ++k) pr[k] = (uint64_t)x[k] * (uint64_t)w[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) hi[k] = (uint32_t)(pr[k] >> 31);
+  LMN_PHASE_ANY();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    s[k] = ((uint32_t)pr[k] & P31) + hi[k];
+    s2[k] = s[k] - P31;
+  }
+  LMN_PHASE_PORT0();
+#pragma unroll
+  for (int k = 0; k < N; ++k) out[k] = s[k] < s2[k] ? s[k] : s2[k];
+}
+
 template <int R, bool INV>
 LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_layer, int hi, uint32_t H,
                              uint32_t mhigh) {
+  constexpr int NB = 1 << (R - 1);  // independent butterflies per layer
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) {
     const int r = INV ? rr : R - 1 - rr;
@@ -447,21 +508,56 @@ LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_
     const uint32_t* __restrict__ t = tw.l[L];
     const uint32_t hb = (H << (hi - L - 1)) + (mhigh << (R - 1 - r));
     LMN_ASSUME(hb < (1u << 28));  // lets the compiler use 32-bit offsets from the uniform table pointer
+    uint32_t w[NB], a[NB], b[NB], x[NB], u[NB], u2[NB], d[NB], d2[NB];
 #pragma unroll
-    for (int j = 0; j < (1 << R); ++j) {
-      if (j & (1 << r)) continue;
-      const uint32_t w = t[hb + (uint32_t)(j >> (r + 1))];
-      const uint32_t a = v[j], b = v[j | (1 << r)];
-      if (INV) {
-        v[j] = m_add(a, b);
-        v[j | (1 << r)] = m_mul(m_sub(a, b), w);
-      } else {
-        const uint32_t x = m_mul(b, w);
-        v[j] = m_add(a, x);
-        v[j | (1 << r)] = m_sub(a, x);
+    for (int k = 0; k < NB; ++k) {
+      const int j = ((k >> r) << (r + 1)) | (k & ((1 << r) - 1));  // k-th index with bit r clear
+      w[k] = t[hb + (uint32_t)(j >> (r + 1))];
+      a[k] = v[j];
+      b[k] = v[j | (1 << r)];
+    }
+    if (INV) {
+      LMN_PHASE_ANY();
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        u[k] = a[k] + b[k];
+        u2[k] = u[k] - P31;
+        d[k] = a[k] - b[k];
+        d2[k] = d[k] + P31;
+      }
+      LMN_PHASE_PORT0();
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        a[k] = u[k] < u2[k] ? u[k] : u2[k];   // m_add(a, b)
+        d[k] = d[k] < d2[k] ? d[k] : d2[k];   // m_sub(a, b)
+      }
+      m_mul_phased<NB>(d, w, x);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int j = ((k >> r) << (r + 1)) | (k & ((1 << r) - 1));
+        v[j] = a[k];
+        v[j | (1 << r)] = x[k];
+      }
+    } else {
+      m_mul_phased<NB>(b, w, x);
+      LMN_PHASE_ANY();
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        u[k] = a[k] + x[k];
+        u2[k] = u[k] - P31;
+        d[k] = a[k] - x[k];
+        d2[k] = d[k] + P31;
+      }
+      LMN_PHASE_PORT0();
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int j = ((k >> r) << (r + 1)) | (k & ((1 << r) - 1));
+        v[j] = u[k] < u2[k] ? u[k] : u2[k];              // m_add(a, x)
+        v[j | (1 << r)] = d[k] < d2[k] ? d[k] : d2[k];   // m_sub(a, x)
       }
     }
   }
+  LMN_PHASE_ANY();
 }
 
 // sm_in / sm_out: LDS tile read by a stage that does not load from global / written by one that does not store to
@@ -528,8 +624,13 @@ LMN_D void fft_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* col, con
     radix_butterflies<R, INV>(v, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
     if (to_global) {
       if (INV && scale != 1u) {
+        uint32_t sc[1 << R], pr[1 << R];
 #pragma unroll
-        for (int j = 0; j < (1 << R); ++j) v[j] = m_mul(v[j], scale);
+        for (int j = 0; j < (1 << R); ++j) sc[j] = scale;
+        m_mul_phased<(1 << R)>(v, sc, pr);
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) v[j] = pr[j];
+        LMN_PHASE_ANY();
       }
       if (p == 0 && cb == 0 && R >= 2) {
         uint4* q = reinterpret_cast<uint4*>(tdst + e0);
@@ -1401,6 +1502,7 @@ constexpr int MERKLE_SMALL_BLOCK = 1024;
 template <int MODE>
 LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
                           MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
+  LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   const uint32_t i = threadIdx.x;
   uint32_t cur[8];
@@ -1412,6 +1514,7 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
   }
+  LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
   merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
   // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
   if (ch != nullptr && (size >> nfused) == 1u) chan_mix_root_draw_block(ch, sh, sh + 16, alpha_out, root_copy);
@@ -1455,6 +1558,7 @@ void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
 // =============================================================================================
 LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ root, QM31* out_alpha,
                                 uint32_t* root_copy) {
+  LMN_SERIAL_KERNEL();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   chan_mix_root_draw(ch, root, out_alpha, root_copy);
 }
@@ -1471,6 +1575,7 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 // =============================================================================================
 LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, int n_layers, int first_log,
                       QM31* alphas_out, uint32_t* roots_out) {
+  LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   const uint32_t i = threadIdx.x;
   for (int li = 0; li < n_layers; ++li) {
@@ -1523,6 +1628,7 @@ void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, i
 // =============================================================================================
 LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,
                     uint32_t* __restrict__ out) {
+  LMN_SERIAL_KERNEL();
   uint32_t e = blockIdx.x;
   if (e >= n) return;
   GatherEntry g = entries[e];
@@ -1602,6 +1708,7 @@ void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s) {
 }
 
 LMN_KERNEL k_logup_reduce(const uint32_t* __restrict__ partials, int nblocks, uint32_t n_inv, QM31* out) {
+  LMN_SERIAL_KERNEL();
   LMN_SHARED uint64_t red[TPB * 4];
   uint64_t acc[4] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
@@ -1690,6 +1797,7 @@ LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restric
 // inclusive scan of the block totals in place (single block of up to 1024 lanes; lane t owns a contiguous run)
 constexpr int SCAN_SUMS_THREADS = 1024;
 LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
+  LMN_SERIAL_KERNEL();
   LMN_SHARED QM31 sh[SCAN_SUMS_THREADS];
   const int T = (int)blockDim.x;
   const int per = (nblocks + T - 1) / T;
@@ -1751,6 +1859,7 @@ static_assert(SCAN2_ELEMS == TPB * 16 && (1 << (SCAN2_C + 1)) * 8 == TPB, "one 8
 template <int MODE>
 LMN_KERNEL k_logup_scan2(const QM31* __restrict__ last_tmp, const QM31* __restrict__ claimed_shift, int log_size,
                          uint32_t* __restrict__ out_cols, QM31* __restrict__ blocksums) {
+  LMN_SERIAL_KERNEL();
   LMN_DYN_SMEM(QM31, T);
   constexpr int A = SCAN2_A, C = SCAN2_C;
   const int gbits = log_size - 1 - A - C;                 // bits of the region index G
@@ -2228,6 +2337,7 @@ void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, co
 // with maps[p][EVAL_LB + k].  maps = [y, x, pi(x), pi^2(x), ...] per sample point.
 LMN_KERNEL k_eval_tables(const QM31* __restrict__ maps, int maps_stride, QM31* __restrict__ lo_tab,
                          QM31* __restrict__ hi_tab, uint32_t hi_n, int hi_bits) {
+  LMN_SERIAL_KERNEL();
   const int p = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const QM31* mp = maps + (uint64_t)p * maps_stride;
@@ -2256,6 +2366,7 @@ void launch_eval_tables(const QM31* maps, int maps_stride, int npoints, QM31* lo
 // out[job] = sum over that job's chunks of partial[job][chunk]
 LMN_KERNEL k_eval_reduce(const EvalJob* __restrict__ jobs, const QM31* __restrict__ partial, int max_chunks,
                          QM31* __restrict__ out) {
+  LMN_SERIAL_KERNEL();
   LMN_SHARED QM31 red[TPB];
   const int job = blockIdx.x;
   const int nc = eval_num_chunks_hd(jobs[job].log_n);
@@ -2389,6 +2500,7 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
 LMN_KERNEL k_fold(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t src_len,
                   const uint32_t* __restrict__ itw, const QM31* __restrict__ alpha_ptr, int accumulate,
                   uint64_t dst_stride) {
+  LMN_SERIAL_KERNEL();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (src_len >> 1)) return;
   const uint64_t n = dst_stride;

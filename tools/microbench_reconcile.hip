@@ -542,6 +542,89 @@ __global__ void __launch_bounds__(256) k_blake2s_G_ilv8_prio2(uint32_t* out, Wav
 }
 static const int k_blake2s_G_ilv8_prio2_ipi = 16 * 12;
 
+
+// the M31 butterfly of the FFT kernels (one multiplication by a twiddle, one add, one sub), 8 independent ones per lane and
+// iteration.  MODE 0: as the compiler schedules field.h's formulas; MODE 1: the same arithmetic issued class by class
+// (sched_barrier keeps the groups apart) with the port-0-only groups at raised wave priority.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bfly(uint32_t* out, WaveRec* recs, int iters) {
+  constexpr uint32_t P = 0x7fffffffu;
+  uint32_t a[8], b[8], tw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = (threadIdx.x * 2654435761u + k) & P;
+    b[k] = (threadIdx.x * 40503u + 977u * k + blockIdx.x) & P;
+    tw[k] = (threadIdx.x * 7919u + 31u * k + 5u) & P;
+  }
+  WaveRec rec;
+  __syncthreads();
+  stamp_begin(rec);
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint64_t p = (uint64_t)b[k] * tw[k];
+        uint32_t s = (uint32_t)(p & P) + (uint32_t)(p >> 31);
+        uint32_t m = s < s - P ? s : s - P;
+        uint32_t u = a[k] + m, d = a[k] - m;
+        a[k] = u < u - P ? u : u - P;
+        b[k] = d < d + P ? d : d + P;
+      }
+    } else {
+      uint64_t p[8];
+      uint32_t hi[8], s[8], s2[8], m[8], u[8], u2[8], d[8], d2[8];
+      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = (uint64_t)b[k] * tw[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hi[k] = (uint32_t)(p[k] >> 31);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s[k] = ((uint32_t)p[k] & P) + hi[k];
+        s2[k] = s[k] - P;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = s[k] < s2[k] ? s[k] : s2[k];
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        u[k] = a[k] + m[k];
+        u2[k] = u[k] - P;
+        d[k] = a[k] - m[k];
+        d2[k] = d[k] + P;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a[k] = u[k] < u2[k] ? u[k] : u2[k];
+        b[k] = d[k] < d2[k] ? d[k] : d2[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // next "layer": partners change (keeps every value live and dependent)
+    uint32_t t = b[0];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) b[k] = b[k + 1];
+    b[7] = t;
+  }
+  stamp_end(rec, recs);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc ^= a[k] ^ b[k];
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 #define CHECK(x)                                                                  \
   do {                                                                            \
     hipError_t e_ = (x);                                                          \
@@ -706,6 +789,13 @@ int main(int argc, char** argv) {
       const int iters = (int)(4096ll * 64 / s.ipi);
       for (int W : {2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, iters, d_out, d_recs, false);
     }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "bfly")) {
+    // "instructions" per iteration = 8 butterflies: the printed rates are BUTTERFLIES per clock per SIMD (wave level)
+    S more[] = {{"bfly compiler", k_bfly<0>, 8}, {"bfly phased", k_bfly<1>, 8}};
+    for (auto& s : more)
+      for (int W : {1, 2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, 2048, d_out, d_recs, false);
     return 0;
   }
   for (auto& s : streams) {

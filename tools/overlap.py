@@ -32,3 +32,15 @@ span = hi - lo
 print("timed region: proofs %d..%d, %.2f ms (%.3f ms per proof)  GPU busy %.1f %%  mean kernels in flight %.2f" % (
     skip, skip + count, span / 1e6, span / 1e6 / count, 100.0 * busy / span, conc / span))
 print("time share by number of kernels in flight (8 = 8 or more): " + "  ".join("%d: %.1f%%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
+
+# per-kernel mean duration inside the region (compare with the solo durations of the one-proof-in-flight run: the ratio
+# says which kernels pay for sharing the chip)
+per = {}
+for s_, e_, k in rows:
+    if s_ >= lo and e_ <= hi:
+        a = per.setdefault(k.replace("void ", "").replace("lmn::", ""), [0, 0])
+        a[0] += 1
+        a[1] += e_ - s_
+print("kernel                               launches/proof   mean us   sum us/proof")
+for k, (n, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:18]:
+    print("%-36s %8.1f %12.1f %12.1f" % (k[:36], n / count, tot / n / 1e3, tot / count / 1e3))
