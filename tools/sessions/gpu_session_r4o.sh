@@ -1,0 +1,25 @@
+#!/bin/bash
+# round-3 final measurements after the two-port issue work: full GPU suite, smoke, driver command x6, default bench,
+# round profile (kernel stats / PMC / VALU / timeline / overlap), config latencies, reference bench matrix
+set -u
+OUT=gpurun_out/r4o
+mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for i in 1 2 3 4 5 6; do
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_cmd_$i.json 2> $OUT/driver_cmd_$i.err; echo "driver rc=$?"
+done
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default rc=$?"
+python - <<'PY'
+import json, glob
+runs = []
+for f in sorted(glob.glob("gpurun_out/r4o/driver_cmd_*.json")) + ["gpurun_out/r4o/bench_default.json"]:
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    runs.append(d)
+    sub = {k: round(d[k]["value"], 1) for k in ("host_rows", "config_2b", "mul_only", "config_3") if isinstance(d.get(k), dict) and "value" in d[k]}
+    print(f.split("/")[-1], round(d["value"], 1), d["steps"], d.get("errors"), sub, "solo", d.get("prove_latency_ms"), "cpu", d["cpu_baseline"]["value"] if d.get("cpu_baseline") else None)
+json.dump(runs[:-1], open("gpurun_out/r4o/driver_cmd_runs.json", "w"))
+PY
+bash tools/profile_round.sh r3 > $OUT/profile_round.log 2>&1; tail -30 $OUT/profile_round.log
+timeout 600 python tools/config_latency.py > $OUT/config_latency.jsonl 2> $OUT/config_latency.err; echo "config rc=$?"; cut -c1-300 $OUT/config_latency.jsonl
+timeout 600 python tools/reference_bench_matrix.py > $OUT/reference_bench_matrix.json 2> $OUT/reference_bench_matrix.err; echo "matrix rc=$?"; tail -c 600 $OUT/reference_bench_matrix.json
