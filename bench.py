@@ -569,6 +569,25 @@ def main(argv=None):
             return dict(throughput(provers, hb, 48, 8), note="trace rows as host buffers: PCIe-inclusive",
                         prove_latency_ms=solo_latency(prover.ctx, hb[0]))
         line["host_rows"] = sub_result("host_rows", run_host_rows)
+
+        def run_host_rows_pinned():
+            # the same, with the rows in page-locked host memory (lmn_host_alloc: what a binding's `flatten` would write
+            # into - include/luminair_hip.h): the GPU's DMA engines fetch them directly
+            lib = provers[0].ctx.lib
+            pins = []
+            try:
+                for k, r in tabs:
+                    a = lib.host_rows(r.shape, r.dtype)
+                    a.array[...] = r
+                    pins.append((k, a))
+                hb = [[(k, a.array, len(a.array)) for k, a in pins] for _ in provers]
+                return dict(throughput(provers, hb, 48, 8),
+                            note="trace rows in page-locked host memory (lmn_host_alloc): PCIe-inclusive, direct DMA",
+                            prove_latency_ms=solo_latency(prover.ctx, hb[0]))
+            finally:
+                for _, a in pins:
+                    a.free()
+        line["host_rows_pinned"] = sub_result("host_rows_pinned", run_host_rows_pinned)
         lr = args.log_rows
         line["config_2b"] = sub_result("config_2b", lambda: variant_throughput(
             syn.config2_graph_faithful(1 << lr, 42), _bk.VARIANT_PINNED, 32,

@@ -94,6 +94,7 @@ class LmnTimings(C.Structure):
 
 EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
+           "lmn_host_alloc", "lmn_host_free", "lmn_host_register", "lmn_host_unregister",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
@@ -138,6 +139,10 @@ class Library:
         lib.lmn_get_timings.argtypes = [C.c_void_p, C.POINTER(LmnTimings)]
         lib.lmn_set_profiling.argtypes = [C.c_void_p, C.c_int]
         lib.lmn_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.lmn_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.lmn_host_free.argtypes = [C.c_void_p]
+        lib.lmn_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        lib.lmn_host_unregister.argtypes = [C.c_void_p]
         lib.lmn_device_free.argtypes = [C.c_void_p, C.c_void_p]
         lib.lmn_verify.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.c_uint32]
         lib.lmn_verify_with_config.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.POINTER(LmnConfig)]
@@ -224,6 +229,22 @@ class Library:
         lib.lmn_trace_elementwise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                               C.POINTER(LmnNodeInfo), C.c_void_p, C.c_uint64, C.c_void_p]
 
+    def host_rows(self, shape, dtype=np.uint32) -> "PinnedArray":
+        """A page-locked numpy array (`lmn_host_alloc`): trace rows written here reach the GPU by direct DMA."""
+        return PinnedArray(self, shape, dtype)
+
+    def host_register(self, arr: np.ndarray):
+        """Page-lock an existing C-contiguous array in place (`lmn_host_register`); pair with host_unregister."""
+        assert arr.flags["C_CONTIGUOUS"]
+        rc = self.lib.lmn_host_register(arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, self.lib.lmn_strerror(rc).decode())
+
+    def host_unregister(self, arr: np.ndarray):
+        rc = self.lib.lmn_host_unregister(arr.ctypes.data_as(C.c_void_p))
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, self.lib.lmn_strerror(rc).decode())
+
     def default_config(self) -> LmnConfig:
         cfg = LmnConfig()
         self.lib.lmn_default_config(C.byref(cfg))
@@ -284,6 +305,34 @@ def default_library() -> Library:
     if _default_library is None:
         _default_library = Library()
     return _default_library
+
+
+class PinnedArray:
+    """numpy view of an `lmn_host_alloc` buffer; `.array` is valid until `free()` (or garbage collection of this object)."""
+
+    def __init__(self, library: "Library", shape, dtype=np.uint32):
+        self.library = library
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        rc = library.lib.lmn_host_alloc(nbytes, C.byref(p))
+        if rc != LMN_OK:
+            raise LuminairBackendError(rc, library.lib.lmn_strerror(rc).decode())
+        self.ptr = p.value
+        buf = (C.c_uint8 * nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.library.lib.lmn_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

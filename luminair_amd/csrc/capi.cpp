@@ -10,6 +10,21 @@
 using lmn::Context;
 
 namespace {
+// for the entry points that need no context
+template <class F>
+static int host_guard(F&& f) {
+  try {
+    f();
+    return LMN_OK;
+  } catch (const LmnError& e) {
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    return LMN_ERR_OUT_OF_MEMORY;
+  } catch (...) {
+    return LMN_ERR_INTERNAL;
+  }
+}
+
 template <typename F>
 int guard(lmn_ctx* ctx, F&& f) {
   return lmn::capi_guard(ctx, std::forward<F>(f));
@@ -210,6 +225,24 @@ int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_setting
   lmn_default_config(&c);  // PcsConfig::default(), as the reference verifier hard-codes it
   c.protocol_variant = protocol_variant;
   return lmn_verify_with_config(proof_bincode, proof_len, settings, &c);
+}
+
+// page-locked host memory for host-resident trace rows (no context: usable by every context of the process)
+int lmn_host_alloc(size_t bytes, void** host_out) {
+  if (!host_out || bytes == 0) return LMN_ERR_INVALID_ARGUMENT;
+  *host_out = nullptr;
+  return host_guard([&] { *host_out = lmn_host_alloc_pinned(bytes); });
+}
+void lmn_host_free(void* host) {
+  if (host) lmn_host_free_pinned(host);
+}
+int lmn_host_register(void* host, size_t bytes) {
+  if (!host || bytes == 0) return LMN_ERR_INVALID_ARGUMENT;
+  return host_guard([&] { lmn_host_register_range(host, bytes); });
+}
+int lmn_host_unregister(void* host) {
+  if (!host) return LMN_ERR_INVALID_ARGUMENT;
+  return host_guard([&] { lmn_host_unregister_range(host); });
 }
 
 int lmn_upload(lmn_ctx* ctx, const void* host, size_t bytes, void** device_out) {

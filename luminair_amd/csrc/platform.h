@@ -87,6 +87,8 @@ inline void* lmn_host_alloc_pinned(size_t bytes) {
   return p;
 }
 inline void lmn_host_free_pinned(void* p) { (void)hipHostFree(p); }
+inline void lmn_host_register_range(void* p, size_t bytes) { LMN_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault)); }
+inline void lmn_host_unregister_range(void* p) { LMN_HIP_CHECK(hipHostUnregister(p)); }
 typedef hipEvent_t lmn_event_t;
 inline lmn_event_t lmn_event_create() {
   hipEvent_t e;
@@ -184,6 +186,8 @@ inline void lmn_memset(void* d, int v, size_t n, lmn_stream_t) { memset(d, v, n)
 inline void lmn_sync(lmn_stream_t) {}
 inline void* lmn_host_alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
 inline void lmn_host_free_pinned(void* p) { free(p); }
+inline void lmn_host_register_range(void*, size_t) {}
+inline void lmn_host_unregister_range(void*) {}
 #include <chrono>
 typedef double* lmn_event_t;
 inline lmn_event_t lmn_event_create() { return new double(0.0); }

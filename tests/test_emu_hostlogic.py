@@ -373,3 +373,33 @@ def test_emu_prover_pool_prove_many(root):
         pool.prove_many([pies[0], bad, pies[1]])
     assert [p.to_bincode() for p in pool.prove_many(pies[:2])] == want[:2]
     pool.close()
+
+
+def test_emu_rows_in_lmn_host_alloc_memory(emu_ctx):
+    """`lmn_host_alloc` / `lmn_host_register` (page-locked host memory for host-resident trace rows; plain memory in the
+    emulation build): same proof as from an ordinary numpy buffer, argument checks."""
+    import ctypes as C
+    from luminair_amd import backend as bk
+    ctx, emu_lib = emu_ctx, emu_ctx.lib
+    tabs = syn.config2_add_only(1 << 6, 3)
+    want = ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    pinned = []
+    for k, r in tabs:
+        a = emu_lib.host_rows(r.shape, r.dtype)
+        a.array[...] = r
+        pinned.append((k, a))
+    assert ctx.prove_tables([(k, a.array, len(a.array)) for k, a in pinned]) == want
+    own = [np.array(r, copy=True) for _, r in tabs]
+    for x in own:
+        emu_lib.host_register(x)
+    assert ctx.prove_tables([(k, x, len(x)) for (k, _), x in zip(tabs, own)]) == want
+    for x in own:
+        emu_lib.host_unregister(x)
+    for _, a in pinned:
+        a.free()
+        a.free()                                   # idempotent
+    p = C.c_void_p()
+    assert emu_lib.lib.lmn_host_alloc(0, C.byref(p)) == bk.ERR_INVALID_ARGUMENT
+    assert emu_lib.lib.lmn_host_alloc(64, None) == bk.ERR_INVALID_ARGUMENT
+    assert emu_lib.lib.lmn_host_register(None, 64) == bk.ERR_INVALID_ARGUMENT
+    assert emu_lib.lib.lmn_host_unregister(None) == bk.ERR_INVALID_ARGUMENT

@@ -242,6 +242,53 @@ def test_gpu_four_contexts_host_rows_shared_and_private_buffers(hip_lib_path):
         b.free()
 
 
+def test_gpu_host_rows_in_page_locked_memory(hip_lib_path):
+    """`lmn_host_alloc` / `lmn_host_register`: trace rows in page-locked host memory (direct DMA, the upload call returns
+    at once) give the same proof as device-resident rows - four contexts, one thread each, 12 proofs each, two of them
+    reading ONE shared allocated buffer and two reading private arrays that were page-locked in place."""
+    import hashlib
+    import threading
+    tabs = syn.config2_add_only(1 << 20, 42)
+    provers = [luminair_amd.Prover(0) for _ in range(4)]
+    lib = provers[0].ctx.lib
+    dev = [(k, provers[0].ctx.upload(r), len(r)) for k, r in tabs]
+    ref = hashlib.sha256(provers[0].ctx.prove_tables(dev)).hexdigest()
+    pinned = []
+    for k, r in tabs:
+        a = lib.host_rows(r.shape, r.dtype)
+        a.array[...] = r
+        pinned.append(a)
+    shared = [(k, a.array, len(a.array)) for (k, _), a in zip(tabs, pinned)]
+    private = []
+    for _ in range(2):
+        arrs = [np.array(r, copy=True) for _, r in tabs]
+        for x in arrs:
+            lib.host_register(x)
+        private.append(arrs)
+    bufs = [shared, shared] + [[(k, x, len(x)) for (k, _), x in zip(tabs, arrs)] for arrs in private]
+    bad = []
+
+    def work(i):
+        for it in range(12):
+            try:
+                if hashlib.sha256(provers[i].ctx.prove_tables(bufs[i])).hexdigest() != ref:
+                    bad.append((i, it, "bytes differ"))
+            except Exception as e:  # noqa: BLE001
+                bad.append((i, it, str(e)))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for arrs in private:
+        for x in arrs:
+            lib.host_unregister(x)
+    for a in pinned:
+        a.free()
+    for _, b, _ in dev:
+        b.free()
+    assert not bad, bad[:4]
+
+
 def test_gpu_one_context_driven_by_several_threads_is_serialised(hip_lib_path):
     """Misuse made safe: calls on ONE context from several threads are serialised by the context's lock
     (include/luminair_hip.h) - round 2's bench put two pool workers into one context and got corrupted proofs and
