@@ -497,22 +497,39 @@ LMN_D void m_mul_phased(const uint32_t (&x)[N], const uint32_t (&w)[N], uint32_t
   for (int k = 0; k < N; ++k) out[k] = s[k] < s2[k] ? s[k] : s2[k];
 }
 
+// The 2^R - 1 twiddles of a register stage (layer r needs 2^(R-1-r) of them: butterfly k of the layer uses entry k >> r).
+// Loaded in one go BEFORE the stage's data so that a single memory latency covers all R layers - loading them layer by
+// layer put one exposed L2 round trip in front of every layer (the kernels run at 2.6 - 4 waves per SIMD).
+template <int R>
+struct StageTwiddles {
+  uint32_t t[(1 << R) - 1];  // layers 0 .. R-1 one after the other
+  static constexpr int at(int r) { return (1 << R) - (1 << (R - r)); }  // first entry of layer r
+};
+
 template <int R, bool INV>
-LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const TwPtrs& tw, int first_layer, int hi, uint32_t H,
-                             uint32_t mhigh) {
-  constexpr int NB = 1 << (R - 1);  // independent butterflies per layer
+LMN_D void load_stage_twiddles(StageTwiddles<R>& T, const TwPtrs& tw, int first_layer, int hi, uint32_t H, uint32_t mhigh) {
 #pragma unroll
-  for (int rr = 0; rr < R; ++rr) {
-    const int r = INV ? rr : R - 1 - rr;
+  for (int r = 0; r < R; ++r) {
     const int L = first_layer + r;
     const uint32_t* __restrict__ t = tw.l[L];
     const uint32_t hb = (H << (hi - L - 1)) + (mhigh << (R - 1 - r));
     LMN_ASSUME(hb < (1u << 28));  // lets the compiler use 32-bit offsets from the uniform table pointer
+#pragma unroll
+    for (int q = 0; q < (1 << (R - 1 - r)); ++q) T.t[StageTwiddles<R>::at(r) + q] = t[hb + (uint32_t)q];
+  }
+}
+
+template <int R, bool INV>
+LMN_D void radix_butterflies(uint32_t (&v)[1 << R], const StageTwiddles<R>& T) {
+  constexpr int NB = 1 << (R - 1);  // independent butterflies per layer
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int r = INV ? rr : R - 1 - rr;
     uint32_t w[NB], a[NB], b[NB], x[NB], u[NB], u2[NB], d[NB], d2[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      const int j = ((k >> r) << (r + 1)) | (k & ((1 << r) - 1));  // k-th index with bit r clear
-      w[k] = t[hb + (uint32_t)(j >> (r + 1))];
+      const int j = ((k >> r) << (r + 1)) | (k & ((1 << r) - 1));  // k-th index with bit r clear; j >> (r+1) == k >> r
+      w[k] = T.t[StageTwiddles<R>::at(r) + (k >> r)];
       a[k] = v[j];
       b[k] = v[j | (1 << r)];
     }
@@ -588,6 +605,9 @@ LMN_D void fft_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* col, con
     const uint32_t e0 = ((g >> p) << (p + R)) | (g & ((1u << p) - 1u));
     const uint32_t off0 = ((e0 >> cb) << lo) + (e0 & cmask);
     LMN_ASSUME(off0 < 0x10000000u);
+    const uint32_t m0 = e0 >> cb;
+    StageTwiddles<R> T;
+    load_stage_twiddles<R, INV>(T, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
     uint32_t v[1 << R];
     if (from_global) {
       if (p == 0 && cb == 0 && R >= 2) {
@@ -620,8 +640,7 @@ LMN_D void fft_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* col, con
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) v[j] = sm_in[pb + fft_lds_pad((uint32_t)j << p)];
     }
-    const uint32_t m0 = e0 >> cb;
-    radix_butterflies<R, INV>(v, tw, first_layer, hi, H, m0 >> (first_layer - lo + R));
+    radix_butterflies<R, INV>(v, T);
     if (to_global) {
       if (INV && scale != 1u) {
         uint32_t sc[1 << R], pr[1 << R];
