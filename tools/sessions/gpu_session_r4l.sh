@@ -3,7 +3,7 @@
 set -u
 OUT=gpurun_out/r4l
 mkdir -p $OUT
-for V in ${VARIANTS:-base serial3 b2hi2 serial3_b2hi2 nofftphase}; do
+for V in ${VARIANTS:-base nofftphase nob2phase nophases}; do
   cp tools/bin/variants/$V.so luminair_amd/csrc/libluminair_hip.so
   for i in 1 2; do
     timeout 300 python bench.py --no-cpu-baseline --no-extras --no-anchor --steps 192 --warmup 24 2>/dev/null | tail -1 > $OUT/${V}_$i.json
