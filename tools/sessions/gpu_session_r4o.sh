@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out/r4o
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_suite.log 2>&1; grep -E "passed|failed|rror" $OUT/gpu_suite.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 for i in 1 2 3 4 5 6; do
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_cmd_$i.json 2> $OUT/driver_cmd_$i.err; echo "driver rc=$?"
