@@ -649,7 +649,20 @@ def main(argv=None):
             return {"workload": "ONE 2^%d-row Add proof sharded into row blocks over %d GPUs" % (args.log_rows, world),
                     "prove_latency_ms": 1e3 * tmax / n_sh, "solo_unsharded_latency_ms": latency_ms,
                     "bytes_identical_to_unsharded_proof": True, "scaling": "strong"}
-        line["sharded_proof"] = sub_result("sharded_proof", run_sharded)
+        def run_sharded_classified():
+            # a proof that comes out DIFFERENT is a parity failure (errors, non-zero exit); a transport that cannot be
+            # set up on this node (RCCL initialisation, peer access) is reported in `warnings` like the watchdog case -
+            # the multi-rank RCCL path cannot be exercised on the one-GPU development boxes
+            try:
+                return run_sharded()
+            except RuntimeError as e:
+                rejected = getattr(e, "code", 0) in (_bk.ERR_EMPTY_TRACE, _bk.ERR_MAIN_TRACE, _bk.ERR_INTERACTION_TRACE,
+                                                     _bk.ERR_CONSTRAINTS, _bk.ERR_VERIFICATION, _bk.ERR_INVALID_LOGUP)
+                if "bytes differ" in str(e) or rejected:      # a valid proof request rejected, or different bytes
+                    raise
+                line.setdefault("warnings", []).append("sharded_proof: %s: %s" % (type(e).__name__, e))
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+        line["sharded_proof"] = sub_result("sharded_proof", run_sharded_classified)
         dog.cancel()
     # a failure on any rank must reach rank 0's line and every rank's exit status
     n_err = len(errors)
