@@ -798,6 +798,16 @@ int main(int argc, char** argv) {
       for (int W : {1, 2, 4, 8}) run(s.label, s.k, s.ipi, W, n_cu, 2048, d_out, d_recs, false);
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "pmc2")) {  // the co-issue streams under rocprofv3 --pmc, 8 waves per SIMD
+    S more[] = {
+        {"G ilv4", k_blake2s_G_ilv4, k_blake2s_G_ilv4_ipi},
+        {"G ilv4 slow-hi", k_blake2s_G_ilv4_prio1, k_blake2s_G_ilv4_prio1_ipi},
+        {"phase 128 prio-", k_phase<0, 128>, 256},
+        {"phase 128 slow-hi", k_phase<1, 128>, 256},
+    };
+    for (auto& s : more) run(s.label, s.k, s.ipi, 8, n_cu, (int)(4096ll * 64 / s.ipi), d_out, d_recs, false);
+    return 0;
+  }
   for (auto& s : streams) {
     const int iters = (int)(4096ll * 64 / s.ipi);
     if (pmc) {
