@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Parity soak: random component mixes (all 17 kinds, ragged sizes, LUTs) proved on the GPU and by the C oracle, byte for
+byte, over many seeds and three size scales.  Usage: soak_random.py [n_seeds] (default 48).  Test infrastructure (uses
+oracle/ as the checker)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import luminair_amd
+from level2_checks import random_pie
+from oracle.channel import ProtocolVariant
+from oracle.proof import to_bincode
+from oracle.prover import prove
+from oracle.cbackend import CKernels
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+p = luminair_amd.Prover(0, protocol_variant=luminair_amd.backend.VARIANT_PINNED)
+ck = CKernels()
+bad, t0, rows = [], time.time(), 0
+for seed in range(100, 100 + n):
+    scale = (1, 40, 150, 400)[seed % 4]
+    tabs, luts = random_pie(seed, scale)
+    rows += sum(len(r) for _, r in tabs)
+    got = p.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts)).to_bincode()
+    want = to_bincode(prove(tabs, variant=ProtocolVariant.PINNED, kernels=ck, luts=luts))
+    if got != want:
+        bad.append(seed)
+print("random pies: %d seeds, %d trace rows in total, %.0f s, mismatching seeds: %s" % (n, rows, time.time() - t0, bad))
+sys.exit(1 if bad else 0)
