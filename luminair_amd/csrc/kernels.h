@@ -8,9 +8,12 @@ namespace lmn {
 
 constexpr int MAX_LOG = 30;
 
-// Per-layer twiddle pointers of one canonic circle domain (layer 0 = circle/y layer).
+// Per-layer twiddle pointers of one canonic circle domain (layer 0 = circle/y layer).  d[i] = the same table with
+// every entry doubled (2w < 2^32): the fixed-shape FFT kernels multiply by 2w so that the 64-bit product splits into
+// floor(x w / 2^31) (high word) and 2 (x w mod 2^31) (low word) without a funnel shift (fft_fixed.hip).
 struct TwPtrs {
   const uint32_t* l[MAX_LOG];
+  const uint32_t* d[MAX_LOG];
 };
 
 // ---- a3: AoS rows -> padded SoA columns (write_trace / pack_values)

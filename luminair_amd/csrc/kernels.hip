@@ -3,6 +3,9 @@
 // trace data).  See DESIGN.md for the per-kernel roofline notes.
 #include <cmath>
 #include "kernels.h"
+#include "issue_phases.h"
+#include "fft_fixed.h"
+#include "launch_util.h"
 
 #include <algorithm>
 
@@ -26,25 +29,6 @@ constexpr int TPB = 256;
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
-#ifndef LMN_EMU
-}  // namespace lmn
-#include <mutex>
-#include <set>
-#include <utility>
-namespace lmn {
-// Kernels that use more than 64 KiB of dynamic LDS need the attribute once per (device, function): contexts of one
-// process may live on several GPUs and are created from several threads.
-static void allow_big_lds(const void* fn, int bytes) {
-  static std::mutex mu;
-  static std::set<std::pair<int, const void*>> done;
-  int dev = 0;
-  LMN_HIP_CHECK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
-  if (done.count({dev, fn})) return;
-  LMN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  done.insert({dev, fn});
-}
-#endif
 LMN_D QM31 load_secure_col(const uint32_t* __restrict__ base, uint64_t stride, uint64_t i) {
   return QM31{base[i], base[stride + i], base[2 * stride + i], base[3 * stride + i]};
 }
@@ -451,30 +435,6 @@ struct FftStagePlan {
 
 LMN_HD uint32_t fft_lds_pad(uint32_t e) { return e + (e >> 5); }
 
-// Issue order of one butterfly layer.  gfx950 co-issues two VALU instructions per slot from two different waves, but the
-// multiplier / three-operand / min-max class (v_mad_u64_u32, v_alignbit_b32, v_min_u32) only goes to the first port, which
-// the arbiter gives to the oldest wave whatever it is about to issue (profiles/r3_valu_coissue.txt).  A layer's
-// butterflies are independent, so their instructions are issued class by class - sched_barrier keeps the compiler from
-// re-interleaving them - with the wave's priority raised while it issues the first-port class: another wave's add/sub/and
-// instructions then take the second port (measured on this butterfly: 0.021 -> 0.035 butterflies/clk/SIMD).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU) && !defined(LMN_NO_ISSUE_PHASES)
-#define LMN_PHASE_PORT0()                  \
-  do {                                     \
-    __builtin_amdgcn_sched_barrier(0);     \
-    __builtin_amdgcn_s_setprio(3);         \
-    __builtin_amdgcn_sched_barrier(0);     \
-  } while (0)
-#define LMN_PHASE_ANY()                    \
-  do {                                     \
-    __builtin_amdgcn_sched_barrier(0);     \
-    __builtin_amdgcn_s_setprio(0);         \
-    __builtin_amdgcn_sched_barrier(0);     \
-  } while (0)
-#else
-#define LMN_PHASE_PORT0() do { } while (0)
-#define LMN_PHASE_ANY() do { } while (0)
-#endif
-
 // out[k] = x[k] * w[k] in M31 for N independent products, issued in phases (field.h m_mul, same arithmetic).  Leaves the
 // wave in the first-port phase.
 template <int N>
@@ -830,6 +790,13 @@ static void launch_staged_pass(uint32_t* data, uint64_t col_stride, const uint32
   static const int env_thr = getenv("LMN_FFT_THREADS") ? atoi(getenv("LMN_FFT_THREADS")) : 0;
   if (env_cpb > 0) cpb = env_cpb;
   if (cpb > ncols) cpb = ncols;
+  // the shapes of the prover's committed columns have compile-time-specialised kernels (fft_fixed.hip)
+  if (plen >= (1ull << log_n)) {
+    const uint32_t scale_log = scale == 1u ? 0u : (uint32_t)__builtin_ctz(scale);
+    if (launch_fft_fixed_pass(INV, data, col_stride, psrc, pstride, p.lo, rbits, p.cb, log_n, tw, scale_log, ncols, cpb,
+                              block_index << (log_n - p.hi), pl.xcd_swizzle, s))
+      return;
+  }
   unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
   int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
   if (env_thr > 0) threads = env_thr;
@@ -890,8 +857,9 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
 #ifndef LMN_EMU
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_interp_extend, 160 * 1024);
 #endif
-  LMN_LAUNCH(k_fft_interp_extend, dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(threads), smem, s, coeffs, coeff_stride,
-             coeffs, coeff_stride, lde, lde_stride, pl, itw, tw_ext, inv_pow2(log_n), ncols, cpb);
+  if (!launch_interp_extend_fixed(coeffs, coeff_stride, lde, lde_stride, log_n, itw, tw_ext, ncols, s))
+    LMN_LAUNCH(k_fft_interp_extend, dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(threads), smem, s, coeffs,
+               coeff_stride, coeffs, coeff_stride, lde, lde_stride, pl, itw, tw_ext, inv_pow2(log_n), ncols, cpb);
   launch_staged_pass<false>(lde, lde_stride, lde, lde_stride, 2ull << log_n, low, log_n + 1, tw_ext, 1u, ncols, s);
   return 3;
 }

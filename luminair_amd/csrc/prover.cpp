@@ -455,6 +455,10 @@ void Context::ensure_twiddles(int M) {
   twX_.assign(M + 1, nullptr);
   itwY_.assign(M + 1, nullptr);
   itwX_.assign(M + 1, nullptr);
+  twY2_.assign(M + 1, nullptr);
+  twX2_.assign(M + 1, nullptr);
+  itwY2_.assign(M + 1, nullptr);
+  itwX2_.assign(M + 1, nullptr);
   auto batch_inverse = [](const std::vector<uint32_t>& v) {
     std::vector<uint32_t> pre(v.size()), out(v.size());
     uint32_t acc = 1;
@@ -476,6 +480,10 @@ void Context::ensure_twiddles(int M) {
     lmn_sync(stream_);
     return d;
   };
+  auto up2 = [&](std::vector<uint32_t> v) {   // doubled entries (TwPtrs::d)
+    for (auto& x : v) x *= 2u;
+    return up(v);
+  };
   for (int m = 1; m <= M; ++m) {
     // half coset of CanonicCoset(m): initial index 2^(30-m), step 2^(32-m), 2^(m-1) points
     uint32_t half = 1u << (m - 1);
@@ -490,12 +498,16 @@ void Context::ensure_twiddles(int M) {
     for (uint32_t h = 0; h < half; ++h) Y[h] = pts[bit_reverse(h, m - 1)].y;
     twY_[m] = up(Y);
     itwY_[m] = up(batch_inverse(Y));
+    twY2_[m] = up2(Y);
+    itwY2_[m] = up2(batch_inverse(Y));
     if (m >= 2) {
       uint32_t quarter = 1u << (m - 2);
       std::vector<uint32_t> X(quarter);
       for (uint32_t h = 0; h < quarter; ++h) X[h] = pts[bit_reverse(h, m - 2)].x;
       twX_[m] = up(X);
       itwX_[m] = up(batch_inverse(X));
+      twX2_[m] = up2(X);
+      itwX2_[m] = up2(batch_inverse(X));
     }
   }
   tw_max_log_ = M;
@@ -504,13 +516,21 @@ void Context::ensure_twiddles(int M) {
 TwPtrs Context::tw(int m) const {
   TwPtrs t{};
   t.l[0] = twY_[m];
-  for (int i = 1; i < m; ++i) t.l[i] = twX_[m - i + 1];
+  t.d[0] = twY2_[m];
+  for (int i = 1; i < m; ++i) {
+    t.l[i] = twX_[m - i + 1];
+    t.d[i] = twX2_[m - i + 1];
+  }
   return t;
 }
 TwPtrs Context::itw(int m) const {
   TwPtrs t{};
   t.l[0] = itwY_[m];
-  for (int i = 1; i < m; ++i) t.l[i] = itwX_[m - i + 1];
+  t.d[0] = itwY2_[m];
+  for (int i = 1; i < m; ++i) {
+    t.l[i] = itwX_[m - i + 1];
+    t.d[i] = itwX2_[m - i + 1];
+  }
   return t;
 }
 
@@ -2327,9 +2347,9 @@ void Context::op_fold(int circle, uint32_t* dst, const uint32_t* src, uint32_t l
 // tiled FFT vs one-layer-per-launch kernels on pseudo-random data (device-side differential check)
 void Context::op_fft_selftest(uint32_t log_size, uint32_t ncols) {
   check_op_log(log_size, "fft_selftest");
-  ensure_twiddles((int)log_size);
+  ensure_twiddles((int)log_size + 1);
   size_t w = (size_t)ncols << log_size;
-  arena_.reserve(w * 8 + (1u << 20));
+  arena_.reserve(w * 32 + (1u << 20));
   begin_op();
   std::vector<uint32_t> h(w);
   uint64_t st = 0x9E3779B97F4A7C15ull;
@@ -2358,6 +2378,30 @@ void Context::op_fft_selftest(uint32_t log_size, uint32_t ncols) {
       if (ra[i] != rb[i])
         throw LmnError(LMN_ERR_INTERNAL, std::string("fft selftest mismatch (inverse=") + std::to_string(inverse) +
                                              ") at word " + std::to_string(i));
+  }
+  // the fused interpolate + extend path of the commitments against the separate transforms
+  if (fft_interp_extend_supported((int)log_size) && (int)log_size + 1 <= tw_max_log_) {
+    begin_op();
+    uint32_t* ev = arena_.alloc_words(w);
+    uint32_t* co = arena_.alloc_words(w);
+    uint32_t* lde = arena_.alloc_words(2 * w);
+    uint32_t* co2 = arena_.alloc_words(w);
+    uint32_t* lde2 = arena_.alloc_words(2 * w);
+    lmn_h2d(ev, h.data(), w * 4, stream_);
+    launch_interp_extend(co, n, ev, n, lde, 2 * n, (int)ncols, (int)log_size, itw((int)log_size), tw((int)log_size + 1), stream_);
+    lmn_d2d(co2, ev, w * 4, stream_);
+    launch_fft_simple(co2, n, (int)ncols, (int)log_size, itw((int)log_size), true, stream_);
+    launch_extend(co2, n, (int)log_size, lde2, 2 * n, (int)log_size + 1, (int)ncols, stream_);
+    launch_fft_simple(lde2, 2 * n, (int)ncols, (int)log_size + 1, tw((int)log_size + 1), false, stream_);
+    std::vector<uint32_t> ra(3 * w), rb(3 * w);
+    lmn_d2h(ra.data(), co, w * 4, stream_);
+    lmn_d2h(ra.data() + w, lde, 2 * w * 4, stream_);
+    lmn_d2h(rb.data(), co2, w * 4, stream_);
+    lmn_d2h(rb.data() + w, lde2, 2 * w * 4, stream_);
+    lmn_sync(stream_);
+    for (size_t i = 0; i < 3 * w; ++i)
+      if (ra[i] != rb[i])
+        throw LmnError(LMN_ERR_INTERNAL, std::string("fft selftest mismatch (interpolate + extend) at word ") + std::to_string(i));
   }
 }
 

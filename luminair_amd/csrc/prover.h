@@ -262,6 +262,7 @@ class Context {
   int tw_max_log_ = 0;
   // twiddle tables: Y[m] (m>=1), X[k] (k>=2), forward + inverse, device pointers
   std::vector<uint32_t*> twY_, twX_, itwY_, itwX_;
+  std::vector<uint32_t*> twY2_, twX2_, itwY2_, itwX2_;  // the same tables, entries doubled (TwPtrs::d)
   std::vector<void*> tw_allocs_;
   friend struct StageTimer;
 };

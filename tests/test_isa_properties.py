@@ -14,16 +14,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def device_asm(tmp_path_factory):
+def _emit_asm(tmp_path_factory, name):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "kernels.s"
-    src = os.path.join(ROOT, "luminair_amd", "csrc", "kernels.hip")
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    src = os.path.join(ROOT, "luminair_amd", "csrc", name + ".hip")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S", src,
                         "-o", str(out)], capture_output=True, text=True, cwd=os.path.dirname(src), timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    return _emit_asm(tmp_path_factory, "kernels")
+
+
+@pytest.fixture(scope="module")
+def fft_asm(tmp_path_factory):
+    return _emit_asm(tmp_path_factory, "fft_fixed")
 
 
 def _kernels(asm):
@@ -103,3 +112,28 @@ def test_butterfly_layers_are_issued_in_priority_phases(device_asm):
         assert seq.count("3") >= 12 and seq.count("0") >= 12, (part, seq.count("3"), seq.count("0"))
         assert re.search(r"3S{16}0f{12,}3S{8}0", seq), part     # one R = 4 layer: 16 first-port, plain run, 8 min
         assert "scratch_" not in body, part
+
+
+def _valu_per_butterfly(body):
+    valu = len(re.findall(r"^\s*v_[a-z0-9_]+", body, re.M))
+    mads = len(re.findall(r"^\s*v_mad_u64_u32", body, re.M))      # one multiplication per butterfly
+    return valu / mads, mads
+
+
+def test_fixed_shape_fft_kernels_stay_close_to_11_vector_instructions_per_butterfly(fft_asm):
+    """fft_fixed.hip: 11 instructions of arithmetic per butterfly (doubled twiddles) plus at most 1.5 of everything else -
+    addressing, LDS indices, twiddle handling, the 2^-n rotation - in the emitted gfx950 code; no spills, and the register
+    budgets the measured occupancy rests on (the generic k_fft_staged sits at ~19 per butterfly)."""
+    ks = _kernels(fft_asm)
+    assert len(_find(ks, "k_fft_fx")) == 12 and len(_find(ks, "k_fft_interp_extend_fx")) == 4
+    for name, (body, md) in ks.items():
+        assert md["vgpr_spill"] == 0 and md["sgpr_spill"] == 0 and "scratch_" not in body, (name, md)
+        per, mads = _valu_per_butterfly(body)
+        hot = any(h in name for h in ("k_fft_fxILb0ELi12E", "interp_extend_fxILi8E", "interp_extend_fxILi9E"))
+        assert per <= (12.5 if hot else 13.6), (name, per, mads)   # inverse passes include the 2^-n rotation
+        assert md["vgpr"] <= (64 if "interp_extend" in name else 80), (name, md)
+        seq = _classes(body)
+        assert seq.count("3") >= 6 and seq.count("0") >= 6, name        # the issue phases are in the emitted code
+    # no 64-bit per-lane address arithmetic in the strided stages: buffer addressing with scalar offsets
+    body = ks[_find(ks, "k_fft_interp_extend_fxILi8E")[0]][0]
+    assert "buffer_store_dword" in body and "v_addc_co_u32" not in body
