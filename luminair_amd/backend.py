@@ -92,7 +92,9 @@ class LmnTimings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
+API_VERSION = 4   # LMN_API_VERSION of include/luminair_hip.h
+
+EXPORTS = ["lmn_abi_version", "lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_host_alloc", "lmn_host_free", "lmn_host_register", "lmn_host_unregister",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
@@ -122,6 +124,16 @@ class Library:
         self.path = path
         lib = C.CDLL(path)
         self.lib = lib
+        # the ctypes structures below mirror include/luminair_hip.h at this ABI version; a library built from another
+        # header (e.g. a 56-byte lmn_view without `offset`) must be refused, not fed garbage
+        try:
+            lib.lmn_abi_version.restype = C.c_uint32
+            got = int(lib.lmn_abi_version())
+        except AttributeError:
+            got = None
+        if got != API_VERSION:
+            raise LuminairBackendError(ERR_INVALID_ARGUMENT, "%s implements ABI version %s, this package binds version %d"
+                                       % (path, got, API_VERSION))
         lib.lmn_strerror.restype = C.c_char_p
         lib.lmn_strerror.argtypes = [C.c_int]
         lib.lmn_last_error.restype = C.c_char_p

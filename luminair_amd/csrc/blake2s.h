@@ -70,8 +70,9 @@ __device__ __forceinline__ void b2_half(uint32_t& a0, uint32_t& a1, uint32_t& a2
       "s_setprio %25\n"
       "v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n"
       "v_alignbit_b32 %7, %7, %7, 7\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1), "+v"(c2),
-        "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+      // early clobber: the message words are still read after the first state registers have been written
+      : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3), "+&v"(b0), "+&v"(b1), "+&v"(b2), "+&v"(b3), "+&v"(c0), "+&v"(c1),
+        "+&v"(c2), "+&v"(c3), "+&v"(d0), "+&v"(d1), "+&v"(d2), "+&v"(d3)
       : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "n"(LO), "n"(HI));
 }
 

@@ -51,6 +51,8 @@ const char* lmn_strerror(int code) {
   }
 }
 
+uint32_t lmn_abi_version(void) { return LMN_API_VERSION; }
+
 const char* lmn_last_error(const lmn_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 
 void lmn_default_config(lmn_config* cfg) {
@@ -85,6 +87,13 @@ int lmn_ctx_create(int device, const lmn_config* cfg, lmn_ctx** out) {
   return LMN_OK;
 }
 
+// error text written by the CALLING thread: under the context's own lock, like the worker's guard()
+static int set_error(lmn_ctx* ctx, int code, const char* msg) {
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  ctx->last_error = msg;
+  return code;
+}
+
 static void async_stop(lmn_ctx* ctx) {
   lmn_async* a = ctx->async;
   if (!a) return;
@@ -110,6 +119,7 @@ void lmn_ctx_destroy(lmn_ctx* ctx) {
 // submit / wait one thread keeps a proof in flight on each of several contexts
 int lmn_prove_submit(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
   if (!ctx) return LMN_ERR_INVALID_ARGUMENT;
+  std::unique_lock<std::mutex> create_lock(ctx->async_mu);
   if (!ctx->async) {
     lmn_async* a = new lmn_async();
     ctx->async = a;
@@ -134,17 +144,21 @@ int lmn_prove_submit(lmn_ctx* ctx, const lmn_table* tables, size_t n_tables, con
     });
   }
   lmn_async* a = ctx->async;
+  create_lock.unlock();
+  bool busy = false;
   {
     std::lock_guard<std::mutex> lk(a->m);
     if (a->state != lmn_async::IDLE) {
-      ctx->last_error = "lmn_prove_submit: a submitted proof has not been collected with lmn_prove_wait";
-      return LMN_ERR_INVALID_ARGUMENT;
+      busy = true;
+    } else {
+      a->tables = tables;
+      a->n_tables = n_tables;
+      a->settings = settings;
+      a->state = lmn_async::SUBMITTED;
     }
-    a->tables = tables;
-    a->n_tables = n_tables;
-    a->settings = settings;
-    a->state = lmn_async::SUBMITTED;
   }
+  if (busy) return set_error(ctx, LMN_ERR_INVALID_ARGUMENT,
+                             "lmn_prove_submit: a submitted proof has not been collected with lmn_prove_wait");
   a->cv.notify_all();
   return LMN_OK;
 }
@@ -153,21 +167,23 @@ int lmn_prove_wait(lmn_ctx* ctx, uint8_t** proof_bincode, size_t* proof_len) {
   if (!ctx || !proof_bincode || !proof_len) return LMN_ERR_INVALID_ARGUMENT;
   *proof_bincode = nullptr;
   *proof_len = 0;
-  lmn_async* a = ctx->async;
-  if (!a) {
-    ctx->last_error = "lmn_prove_wait: nothing was submitted";
-    return LMN_ERR_INVALID_ARGUMENT;
+  lmn_async* a;
+  {
+    std::lock_guard<std::mutex> create_lock(ctx->async_mu);
+    a = ctx->async;
   }
+  if (!a) return set_error(ctx, LMN_ERR_INVALID_ARGUMENT, "lmn_prove_wait: nothing was submitted");
   std::unique_lock<std::mutex> lk(a->m);
   if (a->state == lmn_async::IDLE) {
-    ctx->last_error = "lmn_prove_wait: nothing was submitted";
-    return LMN_ERR_INVALID_ARGUMENT;
+    lk.unlock();
+    return set_error(ctx, LMN_ERR_INVALID_ARGUMENT, "lmn_prove_wait: nothing was submitted");
   }
   a->cv.wait(lk, [&] { return a->state == lmn_async::DONE; });
   const int rc = a->rc;
   if (rc == LMN_OK) {
     uint8_t* p = (uint8_t*)malloc(a->proof.size() ? a->proof.size() : 1);
     if (!p) {
+      a->proof.clear();
       a->state = lmn_async::IDLE;
       return LMN_ERR_OUT_OF_MEMORY;
     }

@@ -29,6 +29,7 @@ struct lmn_ctx {
   // different contexts run concurrently.  Recursive: a shard collective callback may call back into its context.
   std::recursive_mutex mu;
   lmn_async* async = nullptr;
+  std::mutex async_mu;   // guards the lazy creation of `async` (two first submits from different threads)
 };
 
 namespace lmn {

@@ -1132,6 +1132,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   EventLog* log = g_log(this);
   log->reset();
   memset(&timings, 0, sizeof timings);
+#ifndef LMN_EMU
+  // LMN_FRI_OVERLAP: a previous proof that failed between the fork and the join may have left a kernel of the second
+  // stream writing the arena this proof is about to reset
+  if (have_stream2_) lmn_sync(stream2_);
+#endif
   wait_before_level_ = -1;
 
   // ---- validate + size

@@ -294,7 +294,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     // pre-expanded `lookups` form does not) - it only must not be announced when the claim lacks it.
     const uint32_t lut_bits = LMN_LOOKUP_SIN | LMN_LOOKUP_EXP2 | LMN_LOOKUP_LOG2;
     if (settings->has_lookups & ~present) fail("settings announce a lookup the proof's claim lacks");
-    if ((settings->has_lookups & lut_bits) && (settings->has_lookups & lut_bits) != (present & lut_bits))
+    if (settings->has_lookups && (settings->has_lookups & lut_bits) != (present & lut_bits))
       fail("settings.lookups do not match the proof's claim");
     if (settings->n_luts && !settings->luts) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "null luts pointer");
     for (uint32_t i = 0; i < settings->n_luts; ++i) {

@@ -175,6 +175,10 @@ class DeviceGraph:
     def slice(t, ranges) -> TensorView:
         """`GraphTensor::slice`: ranges = one (start, stop) per dimension (None = the whole dimension)."""
         v = _as_view(t)
+        ranges = list(ranges)
+        if len(ranges) > len(v.shape):
+            raise ValueError("slice: %d ranges for a %d-dimensional tensor" % (len(ranges), len(v.shape)))
+        ranges += [None] * (len(v.shape) - len(ranges))      # missing trailing dimensions are taken whole
         shape, off = [], v.offset
         for d, stride, r in zip(v.shape, v.strides, ranges):
             lo, hi = (0, d) if r is None else r
