@@ -94,7 +94,7 @@ class LmnTimings(C.Structure):
 
 API_VERSION = 4   # LMN_API_VERSION of include/luminair_hip.h
 
-EXPORTS = ["lmn_abi_version", "lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
+EXPORTS = ["lmn_abi_version", "lmn_kind_padding_row", "lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
            "lmn_host_alloc", "lmn_host_free", "lmn_host_register", "lmn_host_unregister",
            "lmn_op_interpolate", "lmn_op_evaluate", "lmn_op_merkle_root", "lmn_op_eval_at_point",
@@ -141,6 +141,9 @@ class Library:
         lib.lmn_default_config.argtypes = [C.POINTER(LmnConfig)]
         lib.lmn_kind_columns.restype = C.c_uint32
         lib.lmn_kind_columns.argtypes = [C.c_uint32]
+        lib.lmn_kind_relations.restype = C.c_uint32
+        lib.lmn_kind_relations.argtypes = [C.c_uint32]
+        lib.lmn_kind_padding_row.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         lib.lmn_ctx_create.argtypes = [C.c_int, C.POINTER(LmnConfig), C.POINTER(C.c_void_p)]
         lib.lmn_ctx_destroy.argtypes = [C.c_void_p]
         lib.lmn_prove.argtypes = [C.c_void_p, C.POINTER(LmnTable), C.c_size_t, C.POINTER(LmnSettings),

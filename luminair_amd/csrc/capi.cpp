@@ -70,6 +70,15 @@ uint32_t lmn_kind_columns(uint32_t kind) {
   return s ? (uint32_t)s->n_cols : 0u;
 }
 
+int lmn_kind_padding_row(uint32_t kind, uint32_t* out) {
+  const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
+  if (!s || !out) return LMN_ERR_INVALID_ARGUMENT;
+  for (int c = 0; c < s->n_cols; ++c) out[c] = 0u;
+  if (s->is_last_col >= 0) out[s->is_last_col] = 1u;
+  for (int k = 0; k < s->n_pad; ++k) out[s->pad_col[k]] = s->pad_val[k];
+  return LMN_OK;
+}
+
 int lmn_ctx_create(int device, const lmn_config* cfg, lmn_ctx** out) {
   if (!out) return LMN_ERR_INVALID_ARGUMENT;
   *out = nullptr;
