@@ -84,7 +84,10 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1
     assert line["config"]["ranks_in_process_group"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["errors"] == []
-    assert line["sharded_proof"]["bytes_identical_to_unsharded_proof"] is True
+    sp = line["sharded_proof"]["config_2a"]
+    assert sp["bytes_identical_to_unsharded_proof"] is True
+    assert sp["solo_unsharded_latency_ms"] > 0 and isinstance(sp["sharding_wins"], bool)   # says when sharding loses
+    assert line["short_region"]["steps"] == 20 and line["config"]["proofs_per_step_per_gpu"] == 1
     assert "EMULATION" in line["data"]              # never mistaken for a measurement
     assert line["value"] > 0 and abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4 / 1e3)) < 1e-6 * line["value"]
 
