@@ -1,0 +1,92 @@
+"""Lock-step batches of SMALL proofs (`lmn_batch_*`, libluminair_hip_batch.so; luminair_amd/csrc/batch.h).
+
+The reference proves one pie per `prove(pie, settings)` call (crates/prover/src/prover.rs:28-31); its own benchmark
+shape (crates/graph/benches/ops.rs:92-166: 32x32 tensors) and BASELINE config 4 (examples/black-schole-nn) are bound
+by kernel launches and host round trips on a GPU.  `BatchProver.prove_batch` proves up to `slots` pies of identical
+shape with one launch per pipeline step; every proof is byte-identical to `Prover.prove`'s."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+from . import backend
+from .backend import LmnConfig, LmnSettings, LmnTable, LuminairBackendError
+
+BATCH_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libluminair_hip_batch.so")
+
+
+class BatchProver:
+    def __init__(self, device: int = 0, slots: int = 32, protocol_variant: int = backend.VARIANT_KAT,
+                 library_path: Optional[str] = None, **pcs):
+        self.lib = backend.Library(library_path or BATCH_LIB)
+        lib = self.lib.lib
+        lib.lmn_batch_create.argtypes = [C.c_int, C.POINTER(LmnConfig), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.lmn_batch_prove.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(LmnTable)), C.c_size_t,
+                                        C.POINTER(LmnSettings), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_int)]
+        lib.lmn_batch_last_error.restype = C.c_char_p
+        lib.lmn_batch_last_error.argtypes = [C.c_void_p]
+        lib.lmn_batch_counter.restype = C.c_uint64
+        lib.lmn_batch_counter.argtypes = [C.c_void_p, C.c_int]
+        lib.lmn_batch_destroy.argtypes = [C.c_void_p]
+        cfg = LmnConfig()
+        lib.lmn_default_config(C.byref(cfg))
+        cfg.protocol_variant = protocol_variant
+        for k, v in pcs.items():
+            setattr(cfg, k, v)
+        self.slots = slots
+        self.handle = C.c_void_p()
+        rc = lib.lmn_batch_create(device, C.byref(cfg), slots, C.byref(self.handle))
+        if rc != 0:
+            raise LuminairBackendError(rc, "lmn_batch_create failed: %s" % lib.lmn_strerror(rc).decode())
+
+    def prove_batch(self, pies: Sequence[Sequence[Tuple[int, object, int]]], luts=None) -> List[bytes]:
+        """pies[i] = [(kind, rows, n_rows)] like `Context.prove_tables`; all pies must have the same kinds and row counts."""
+        n = len(pies)
+        if n == 0 or n > self.slots:
+            raise ValueError("a batch holds 1..%d pies" % self.slots)
+        keep, settings = [], None
+        arrs = (C.POINTER(LmnTable) * n)()
+        n_tables = len(pies[0])
+        for i, tables in enumerate(pies):
+            arr, nt, st, k = backend.Context._marshal_tables(None, tables, luts)
+            if nt != n_tables:
+                raise ValueError("the pies of a batch must have the same tables")
+            keep.append(k)
+            arrs[i] = C.cast(arr, C.POINTER(LmnTable))
+            settings = settings or st
+        proofs = (C.POINTER(C.c_uint8) * n)()
+        lens = (C.c_size_t * n)()
+        rcs = (C.c_int * n)()
+        lib = self.lib.lib
+        rc = lib.lmn_batch_prove(self.handle, n, arrs, n_tables, C.byref(settings), proofs, lens, rcs)
+        out = []
+        for i in range(n):
+            if proofs[i]:
+                out.append(C.string_at(proofs[i], lens[i]))
+                lib.lmn_free(proofs[i])
+            else:
+                out.append(None)
+        if rc != 0:
+            raise LuminairBackendError(rc, "lmn_batch_prove: %s (per pie: %s)"
+                                       % ((lib.lmn_batch_last_error(self.handle) or b"").decode(), list(rcs)))
+        return out
+
+    def counters(self):
+        c = self.lib.lib.lmn_batch_counter
+        return {"launches": int(c(self.handle, 0)), "host_waits": int(c(self.handle, 1)),
+                "copy_launches": int(c(self.handle, 2)), "direct_copies": int(c(self.handle, 3)),
+                "arrival_skew_ms": int(c(self.handle, 4)) / 1e6, "leader_ms": int(c(self.handle, 5)) / 1e6,
+                "member_busy_ms": int(c(self.handle, 6)) / 1e6}
+
+    def close(self):
+        if self.handle:
+            self.lib.lib.lmn_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

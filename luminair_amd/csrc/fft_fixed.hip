@@ -27,7 +27,7 @@ namespace lmn {
 
 LMN_HD constexpr uint32_t fx_pad(uint32_t e) { return e + (e >> 5); }
 
-#if !defined(LMN_EMU)
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
 #define LMN_BOUNDS(n) __launch_bounds__(n)
 #else
 #define LMN_BOUNDS(n)
@@ -366,7 +366,7 @@ static void launch_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, 
   using S = FxShape<RBITS, CB, LO0>;
   const unsigned tiles = 1u << (log_n - S::TB);
   const size_t smem = (size_t)4 * S::LDS_WORDS;
-#ifndef LMN_EMU
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_fx<INV, RBITS, CB, LO0>, 160 * 1024);
 #endif
   LMN_LAUNCH((k_fft_fx<INV, RBITS, CB, LO0>), dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(S::NT), smem, s, data,
@@ -414,7 +414,7 @@ static void launch_ie(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, ui
                       const TwPtrs& tw_ext, uint32_t scale_log, int ncols, lmn_stream_t s) {
   using S = FxShape<RBITS, 4, false>;
   const size_t smem = (size_t)8 * S::LDS_WORDS;
-#ifndef LMN_EMU
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_interp_extend_fx<RBITS>, 160 * 1024);
 #endif
   LMN_LAUNCH((k_fft_interp_extend_fx<RBITS>), dim3(1u << (12 - 4), (unsigned)ncols), dim3(S::NT), smem, s, coeffs, coeff_stride,

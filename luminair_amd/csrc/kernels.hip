@@ -854,7 +854,7 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
   const unsigned tiles = 1u << (FFT_LOW_BITS - FFT_HIGH_CB);
   int cpb = 1;
   const int threads = (int)std::min<uint32_t>(TPB, std::max<uint32_t>(64u, tile_elems >> 4));
-#ifndef LMN_EMU
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_interp_extend, 160 * 1024);
 #endif
   if (!launch_interp_extend_fixed(coeffs, coeff_stride, lde, lde_stride, log_n, itw, tw_ext, ncols, s))
@@ -1929,7 +1929,7 @@ void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_
   if (log_size >= SCAN2_MIN_LOG && !scattered) {
     const dim3 grid(1u << (log_size - 2 - SCAN2_A - SCAN2_C));
     const size_t smem = (size_t)SCAN2_ELEMS * sizeof(QM31);
-#ifndef LMN_EMU
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
     allow_big_lds((const void*)k_logup_scan2<0>, (int)smem);
     allow_big_lds((const void*)k_logup_scan2<1>, (int)smem);
 #endif

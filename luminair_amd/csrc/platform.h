@@ -16,7 +16,11 @@
 #include <hip/hip_runtime.h>
 #define LMN_HD __host__ __device__ __forceinline__
 #define LMN_D __device__ __forceinline__
+#ifdef LMN_BATCH
+#define LMN_KERNEL __device__ void   /* kernel bodies; the one __global__ is lmn_batch_tramp (batch.h) */
+#else
 #define LMN_KERNEL __global__ void
+#endif
 #define LMN_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; T* name = reinterpret_cast<T*>(name##_raw)
 #define LMN_SHARED __shared__
 typedef hipStream_t lmn_stream_t;
@@ -38,11 +42,16 @@ struct LmnError : std::runtime_error {
                                std::to_string(__LINE__));                                          \
   } while (0)
 
+#ifdef LMN_BATCH
+#include "batch.h"
+#define LMN_LAUNCH(kernel, grid, block, smem, stream, ...) ::lmn::batch_launch<&kernel>(grid, block, smem, stream, __VA_ARGS__)
+#else
 #define LMN_LAUNCH(kernel, grid, block, smem, stream, ...)                          \
   do {                                                                              \
     hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);             \
     LMN_HIP_CHECK(hipGetLastError());                                               \
   } while (0)
+#endif
 
 inline void* lmn_dev_malloc(size_t bytes) {
   void* p = nullptr;
@@ -50,19 +59,34 @@ inline void* lmn_dev_malloc(size_t bytes) {
   return p;
 }
 inline void lmn_dev_free(void* p) { (void)hipFree(p); }
+#ifdef LMN_BATCH
+#define LMN_BATCH_COPY(dst, src, n, dir) if (::lmn::batch_copy((dst), (src), (n), (dir))) return
+#else
+#define LMN_BATCH_COPY(dst, src, n, dir) do { } while (0)
+#endif
 inline void lmn_h2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_BATCH_COPY(dst, src, n, 0);
   LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
 }
 inline void lmn_d2h(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_BATCH_COPY(dst, src, n, 1);
   LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
 }
 inline void lmn_d2d(void* dst, const void* src, size_t n, lmn_stream_t s) {
+  LMN_BATCH_COPY(dst, src, n, 2);
   LMN_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
 }
-inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) { LMN_HIP_CHECK(hipMemsetAsync(dst, v, n, s)); }
+inline void lmn_memset(void* dst, int v, size_t n, lmn_stream_t s) {
+  LMN_BATCH_COPY(dst, (const void*)(uintptr_t)(unsigned char)v, n, 3);
+  LMN_HIP_CHECK(hipMemsetAsync(dst, v, n, s));
+}
 // Spin on hipStreamQuery instead of blocking in hipStreamSynchronize: the prover synchronises 6
 // times per proof and the blocking wake-up latency (tens of microseconds) would sit on the critical path.
 inline void lmn_sync(lmn_stream_t s) {
+#ifdef LMN_BATCH
+  ::lmn::batch_sync(s);   // a rendezvous of the lock-step group: one stream wait for all members
+  return;
+#endif
   static const int mode = getenv("LMN_SYNC_MODE") ? atoi(getenv("LMN_SYNC_MODE")) : 0;  // 0 spin, 1 block, 2 hybrid
   if (mode == 1) {
     LMN_HIP_CHECK(hipStreamSynchronize(s));
@@ -84,11 +108,29 @@ inline void lmn_sync(lmn_stream_t s) {
 inline void* lmn_host_alloc_pinned(size_t bytes) {
   void* p = nullptr;
   LMN_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+#ifdef LMN_BATCH
+  ::lmn::batch_register_pinned(p, bytes);
+#endif
   return p;
 }
-inline void lmn_host_free_pinned(void* p) { (void)hipHostFree(p); }
-inline void lmn_host_register_range(void* p, size_t bytes) { LMN_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault)); }
-inline void lmn_host_unregister_range(void* p) { LMN_HIP_CHECK(hipHostUnregister(p)); }
+inline void lmn_host_free_pinned(void* p) {
+#ifdef LMN_BATCH
+  ::lmn::batch_unregister_pinned(p);
+#endif
+  (void)hipHostFree(p);
+}
+inline void lmn_host_register_range(void* p, size_t bytes) {
+  LMN_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+#ifdef LMN_BATCH
+  ::lmn::batch_register_pinned(p, bytes);
+#endif
+}
+inline void lmn_host_unregister_range(void* p) {
+#ifdef LMN_BATCH
+  ::lmn::batch_unregister_pinned(p);
+#endif
+  LMN_HIP_CHECK(hipHostUnregister(p));
+}
 typedef hipEvent_t lmn_event_t;
 inline lmn_event_t lmn_event_create() {
   hipEvent_t e;

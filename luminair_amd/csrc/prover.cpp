@@ -244,9 +244,19 @@ Context::~Context() {
     lmn_event_destroy(ev_fork_);
     lmn_event_destroy(ev_join_);
   }
-  (void)hipStreamDestroy(stream_);
+  if (owns_stream_) (void)hipStreamDestroy(stream_);
 #endif
 }
+
+#ifdef LMN_BATCH
+void Context::adopt_stream(lmn_stream_t s) {
+  LMN_HIP_CHECK(hipSetDevice(device_));
+  LMN_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (owns_stream_) LMN_HIP_CHECK(hipStreamDestroy(stream_));
+  stream_ = s;
+  owns_stream_ = false;
+}
+#endif
 
 void* Context::pin_alloc(size_t bytes) {
   size_t a = (pin_off_ + 63) & ~(size_t)63;

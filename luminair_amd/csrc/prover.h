@@ -120,6 +120,10 @@ class Context {
   Context(int device, const lmn_config& cfg);
   ~Context();
   std::vector<uint8_t> prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings);
+#ifdef LMN_BATCH
+  // lock-step batches (batch.h): every member context issues its work on the group's one stream
+  void adopt_stream(lmn_stream_t s);
+#endif
 
   // level-2 ops
   void op_interpolate(uint32_t* cols, uint32_t ncols, uint32_t log_size);
@@ -251,6 +255,7 @@ class Context {
 
   int device_;
   lmn_stream_t stream_{};
+  bool owns_stream_ = true;
   // second stream + ordering events: the quotient kernel of the smaller LDE size runs next to the leaf hashing of
   // the larger one in the first FRI layer (LMN_FRI_OVERLAP=1, experiment)
   lmn_stream_t stream2_{};
