@@ -71,9 +71,15 @@ class LmnRange(C.Structure):
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p,
+                            C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p)
+
+
 class LmnCollective(C.Structure):
-    """`lmn_collective`: the one exchange primitive of a sharded proof, an in-place all-gather on device memory."""
-    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("group_begin", C.c_void_p), ("group_end", C.c_void_p)]
+    """`lmn_collective`: the exchange primitives of a sharded proof - an in-place all-gather on device memory and
+    (optional) the all-to-all that re-partitions column-parallel LDEs into row blocks."""
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("group_begin", C.c_void_p), ("group_end", C.c_void_p),
+                ("all_to_all", ALL_TO_ALL_FN)]
 
 
 RCCL_ID_BYTES = 128
@@ -86,13 +92,14 @@ class LmnTimings(C.Structure):
         ("fft_bytes", C.c_uint64), ("merkle_bytes", C.c_uint64), ("fft_launches", C.c_uint32),
         ("merkle_launches", C.c_uint32), ("fft_butterflies", C.c_uint64), ("merkle_compressions", C.c_uint64),
         ("merkle_fused_ms", C.c_float), ("merkle_fused_launches", C.c_uint32), ("merkle_fused_bytes", C.c_uint64),
-        ("merkle_fused_compressions", C.c_uint64)]
+        ("merkle_fused_compressions", C.c_uint64), ("shard_a2a_bytes", C.c_uint64), ("shard_gather_bytes", C.c_uint64),
+        ("shard_a2a_calls", C.c_uint32), ("shard_gather_calls", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-API_VERSION = 4   # LMN_API_VERSION of include/luminair_hip.h
+API_VERSION = 5   # LMN_API_VERSION of include/luminair_hip.h
 
 EXPORTS = ["lmn_abi_version", "lmn_kind_padding_row", "lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
@@ -585,9 +592,11 @@ class Context:
         return acc
 
     # ---- single-proof sharding (lmn_ctx_set_shard*)
-    def set_shard(self, rank: int, world: int, all_gather, fri_min_log: int = 0):
+    def set_shard(self, rank: int, world: int, all_gather, fri_min_log: int = 0, all_to_all=None):
         """Shard every later `prove` over `world` contexts (one per GPU, one per process).  `all_gather(buf_ptr,
-        bytes_per_rank, stream)` is the in-place all-gather of `lmn_collective` (device pointer as an int)."""
+        bytes_per_rank, stream)` is the in-place all-gather of `lmn_collective` (device pointer as an int);
+        `all_to_all(send_ptr, send_off, send_bytes, recv_ptr, recv_off, recv_bytes, stream)` (lists of `world` ints) the
+        optional second primitive."""
         def _cb(_user, buf, nbytes, stream):
             try:
                 all_gather(buf, nbytes, stream)
@@ -596,11 +605,21 @@ class Context:
                 import traceback
                 traceback.print_exc()
                 return 1
+        def _a2a(_user, send, so, sb, recv, ro, rb, stream):
+            try:
+                all_to_all(send, [so[p] for p in range(world)], [sb[p] for p in range(world)], recv,
+                           [ro[p] for p in range(world)], [rb[p] for p in range(world)], stream)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
         cb = ALL_GATHER_FN(_cb)
-        coll = LmnCollective(None, cb, None, None)
+        cb2 = ALL_TO_ALL_FN(_a2a) if all_to_all is not None else ALL_TO_ALL_FN()
+        coll = LmnCollective(None, cb, None, None, cb2)
         self._check(self.lib.lib.lmn_ctx_set_shard(self.handle, rank, world, fri_min_log, C.byref(coll)))
-        # keep the trampoline alive as long as the context uses it (a rejected call keeps the previous one)
-        self._shard_cb, self._shard_coll = cb, coll
+        # keep the trampolines alive as long as the context uses them (a rejected call keeps the previous ones)
+        self._shard_cb, self._shard_coll = (cb, cb2), coll
 
     def rccl_unique_id(self) -> bytes:
         buf = (C.c_uint8 * RCCL_ID_BYTES)()

@@ -39,6 +39,14 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
 // twiddles of the whole domain); dst receives 2^(log_n - log_blocks) words per column
 int launch_fft_block(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
                      int log_n, int log_blocks, uint32_t block, const TwPtrs& tw, lmn_stream_t s);
+// Row blocks of `ncols` columns (column stride src_stride, blocks of block_rows rows) packed per destination rank for
+// the all-to-all of a sharded commitment: dst[((s * ncols + c) * nsel + h) * block_rows + i] =
+// src[c * src_stride + sel.blk[s][h] * block_rows + i] for s < world, h < nsel.
+struct PackSel {
+  uint32_t blk[8][2];
+};
+void launch_pack_blocks(const uint32_t* src, uint64_t src_stride, uint32_t* dst, uint32_t block_rows, int ncols, int nsel,
+                        int world, const PackSel& sel, lmn_stream_t s);
 // single-layer reference kernels (debug / self-test only)
 void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
                        lmn_stream_t s);
@@ -207,6 +215,8 @@ struct EvalJob {
   const uint32_t* coeffs;
   int log_n;
   int point;                   // which point table (0 = oods, 1.. = shifted points)
+  int owner = -1;              // sharded proofs: -1 = the coefficient chunks are split over the ranks; r = only rank r
+                               // holds the coefficients (column-parallel interpolation) and evaluates all chunks
 };
 constexpr int EVAL_LB = 10;
 // tables: for point p: lo table at lo_tab + p*2^EVAL_LB, hi table at hi_tab + p*hi_stride

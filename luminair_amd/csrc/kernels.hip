@@ -950,6 +950,21 @@ LMN_KERNEL k_fft_layer_simple(uint32_t* __restrict__ data, uint64_t col_stride, 
   }
 }
 
+LMN_KERNEL k_pack_blocks(const uint32_t* __restrict__ src, uint64_t src_stride, uint32_t* __restrict__ dst, uint32_t block_rows,
+                         int ncols, int nsel, PackSel sel) {
+  const uint32_t h = blockIdx.y % (uint32_t)nsel, c = (blockIdx.y / (uint32_t)nsel) % (uint32_t)ncols;
+  const uint32_t s = blockIdx.y / (uint32_t)(nsel * ncols);
+  const uint32_t* sp = src + (uint64_t)c * src_stride + (uint64_t)sel.blk[s][h] * block_rows;
+  uint32_t* dp = dst + (((uint64_t)s * ncols + c) * nsel + h) * block_rows;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < block_rows; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+}
+void launch_pack_blocks(const uint32_t* src, uint64_t src_stride, uint32_t* dst, uint32_t block_rows, int ncols, int nsel,
+                        int world, const PackSel& sel, lmn_stream_t s) {
+  if (ncols <= 0) return;
+  LMN_LAUNCH(k_pack_blocks, dim3(std::min<unsigned>(cdiv(block_rows, TPB), 64u), (unsigned)(world * ncols * nsel)), dim3(TPB),
+             0, s, src, src_stride, dst, block_rows, ncols, nsel, sel);
+}
+
 void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
                        lmn_stream_t s) {
   uint64_t half = 1ull << (log_n - 1);
@@ -2253,7 +2268,9 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
   const int nchunks = eval_num_chunks_hd(job.log_n);
   if (chunk >= nchunks) return;
   if (shard_world > 1) {
-    const uint32_t owner = (uint32_t)nchunks >= shard_world ? (uint32_t)chunk / ((uint32_t)nchunks / shard_world) : (uint32_t)chunk;
+    // job.owner >= 0: the coefficients exist on that rank only, which evaluates every chunk
+    const uint32_t owner = job.owner >= 0 ? (uint32_t)job.owner
+                           : (uint32_t)nchunks >= shard_world ? (uint32_t)chunk / ((uint32_t)nchunks / shard_world) : (uint32_t)chunk;
     if (owner != shard_rank) {
       if (threadIdx.x == 0) partial_out[(uint64_t)blockIdx.y * max_chunks + chunk] = q_zero();
       return;

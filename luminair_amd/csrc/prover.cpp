@@ -703,6 +703,8 @@ void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uin
   const bool group = ncols > 1 && shard_.coll.group_begin && shard_.coll.group_end;
   if (group && shard_.coll.group_begin(shard_.coll.user) != 0) throw LmnError(LMN_ERR_INTERNAL, "shard group_begin failed");
   int rc = 0;
+  timings.shard_gather_bytes += (uint64_t)ncols * words_per_rank * 4 * (shard_.world - 1);
+  timings.shard_gather_calls += (uint32_t)ncols;
   for (int c = 0; c < ncols && rc == 0; ++c)
     rc = shard_.coll.all_gather(shard_.coll.user, base + (uint64_t)c * col_stride, (size_t)words_per_rank * 4,
                                 (void*)(uintptr_t)stream_);
@@ -711,21 +713,110 @@ void Context::gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uin
   if (rc != 0) throw LmnError(LMN_ERR_INTERNAL, "shard all_gather failed (code " + std::to_string(rc) + ")");
 }
 
-uint32_t* Context::interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size) {
+bool Context::shard_all_to_all() const {
+  static const bool off = getenv("LMN_SHARD_A2A") && atoi(getenv("LMN_SHARD_A2A")) == 0;   // ablation: replicated interpolation
+  return shard_.active && shard_.world > 1 && shard_.coll.all_to_all != nullptr && !off;
+}
+
+Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size,
+                                                   int halo_first) {
   const uint64_t n = 1ull << log_size;
+  CommitOut out;
   StageTimer t(this, g_log(this), stream_, C_FFT);
-  timings.fft_bytes += (uint64_t)ncols * 8ull * n;
-  timings.fft_butterflies += (uint64_t)ncols * (n / 2) * (uint64_t)log_size;
   if (!shard_.active && cfg.log_blowup == 1 && fft_interp_extend_supported(log_size)) {
+    timings.fft_bytes += (uint64_t)ncols * 8ull * n;
+    timings.fft_butterflies += (uint64_t)ncols * (n / 2) * (uint64_t)log_size;
     uint32_t* lde = arena_.alloc_words((size_t)ncols * 2 * n);
     timings.fft_launches += launch_interp_extend(coeffs, n, evals, n, lde, 2 * n, ncols, log_size, itw(log_size),
                                                  tw(log_size + 1), stream_);
     timings.fft_bytes += (uint64_t)ncols * 12ull * n;                       // the extension: 4n read + 8n written
     timings.fft_butterflies += (uint64_t)ncols * n * (uint64_t)log_size;  // 2^(k+1)/2 * k (the top layer is the identity)
-    return lde;
+    out.lde = lde;
+    out.stride = 2 * n;
+    return out;
   }
+  const int g = shard_.g;
+  const uint64_t L = 2 * n, Lb = L >> g;
+  // column-parallel interpolation pays where the transforms are throughput-bound; small columns stay replicated (two more
+  // collectives would cost more than the few microseconds of butterflies).  LMN_SHARD_A2A_MIN_LOG lowers the bar (tests).
+  static const int a2a_min_log = getenv("LMN_SHARD_A2A_MIN_LOG") ? atoi(getenv("LMN_SHARD_A2A_MIN_LOG")) : 13;
+  if (shard_all_to_all() && cfg.log_blowup == 1 && log_size >= a2a_min_log && log_size >= 4) {
+    // ---- stage A: this rank's share of the columns, interpolated and extended over ALL rows
+    const uint32_t G = shard_.world, me = shard_.rank;
+    for (uint32_t r = 0; r <= G; ++r) out.first[r] = (int)((uint64_t)r * ncols / G);
+    const int c0 = out.first[me], nm = out.first[me + 1] - c0;
+    uint32_t* full = arena_.alloc_words((size_t)std::max(nm, 1) * L);
+    if (nm > 0) {
+      timings.fft_bytes += (uint64_t)nm * 20ull * n;
+      timings.fft_butterflies += (uint64_t)nm * (n / 2 + n) * (uint64_t)log_size;
+      if (fft_interp_extend_supported(log_size)) {
+        timings.fft_launches += launch_interp_extend(coeffs + (uint64_t)c0 * n, n, evals + (uint64_t)c0 * n, n, full, L, nm,
+                                                     log_size, itw(log_size), tw(log_size + 1), stream_);
+      } else {
+        timings.fft_launches += launch_ifft(coeffs + (uint64_t)c0 * n, n, evals + (uint64_t)c0 * n, n, nm, log_size, itw(log_size), stream_);
+        timings.fft_launches += launch_fft(full, L, coeffs + (uint64_t)c0 * n, n, log_size, nm, log_size + 1, tw(log_size + 1), stream_);
+      }
+    }
+    // ---- stage B: row block s of every own column goes to rank s
+    uint32_t* sendbuf = arena_.alloc_words((size_t)std::max(nm, 1) * L);
+    uint32_t* lde = arena_.alloc_words((size_t)ncols * Lb);
+    PackSel sel{};
+    for (uint32_t s = 0; s < G; ++s) sel.blk[s][0] = s;
+    launch_pack_blocks(full, L, sendbuf, (uint32_t)Lb, nm, 1, (int)G, sel, stream_);
+    size_t so[8], sb[8], ro[8], rb[8];
+    for (uint32_t p = 0; p < G; ++p) {
+      so[p] = (size_t)p * nm * Lb * 4;
+      sb[p] = (size_t)nm * Lb * 4;
+      ro[p] = (size_t)out.first[p] * Lb * 4;
+      rb[p] = (size_t)(out.first[p + 1] - out.first[p]) * Lb * 4;
+    }
+    if (shard_.coll.all_to_all(shard_.coll.user, sendbuf, so, sb, lde, ro, rb, (void*)(uintptr_t)stream_) != 0)
+      throw LmnError(LMN_ERR_INTERNAL, "shard all_to_all failed");
+    timings.shard_a2a_bytes += (uint64_t)(ncols - nm) * Lb * 4;
+    timings.shard_a2a_calls++;
+    if (halo_first >= 0) {
+      // the mask offset -1 of the last logup column group reads the previous trace row, which under bit reversal lies
+      // in block rev(rev(b)+1) (odd storage indices) or rev(rev(b)-1) (even ones) of the same 4 columns
+      auto nb = [&](uint32_t b, int h) {
+        const uint32_t rbv = bit_reverse(b, g);
+        return bit_reverse((h == 0 ? rbv + 1 : rbv + G - 1) & (G - 1), g);
+      };
+      const int h0 = std::max(halo_first, c0), h1 = std::min(halo_first + 4, c0 + nm), nh = std::max(0, h1 - h0);
+      uint32_t* hsend = arena_.alloc_words((size_t)std::max(nh, 1) * 2 * Lb * G);
+      uint32_t* hrecv = arena_.alloc_words((size_t)4 * 2 * Lb);
+      PackSel hs{};
+      for (uint32_t s = 0; s < G; ++s) {
+        hs.blk[s][0] = nb(s, 0);
+        hs.blk[s][1] = nb(s, 1);
+      }
+      if (nh > 0) launch_pack_blocks(full + (uint64_t)(h0 - c0) * L, L, hsend, (uint32_t)Lb, nh, 2, (int)G, hs, stream_);
+      for (uint32_t p = 0; p < G; ++p) {
+        const int q0 = std::max(halo_first, out.first[p]), q1 = std::min(halo_first + 4, out.first[p + 1]);
+        const int nq = std::max(0, q1 - q0);
+        so[p] = (size_t)p * nh * 2 * Lb * 4;
+        sb[p] = (size_t)nh * 2 * Lb * 4;
+        ro[p] = (size_t)std::max(0, q0 - halo_first) * 2 * Lb * 4;
+        rb[p] = (size_t)nq * 2 * Lb * 4;
+      }
+      if (shard_.coll.all_to_all(shard_.coll.user, hsend, so, sb, hrecv, ro, rb, (void*)(uintptr_t)stream_) != 0)
+        throw LmnError(LMN_ERR_INTERNAL, "shard all_to_all failed");
+      timings.shard_a2a_bytes += (uint64_t)(4 - nh) * 2 * Lb * 4;
+      timings.shard_a2a_calls++;
+      out.halo = arena_.alloc_words(4 * L);
+      for (int j = 0; j < 4; ++j)
+        for (int h = 0; h < 2; ++h)
+          lmn_d2d(out.halo + (uint64_t)j * L + (uint64_t)nb(me, h) * Lb, hrecv + ((uint64_t)j * 2 + h) * Lb, Lb * 4, stream_);
+    }
+    out.lde = lde;
+    out.stride = Lb;
+    out.sharded = true;
+    out.owned = true;
+    return out;
+  }
+  timings.fft_bytes += (uint64_t)ncols * 8ull * n;
+  timings.fft_butterflies += (uint64_t)ncols * (n / 2) * (uint64_t)log_size;
   timings.fft_launches += launch_ifft(coeffs, n, evals, n, ncols, log_size, itw(log_size), stream_);
-  return nullptr;
+  return out;
 }
 
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
@@ -1190,10 +1281,15 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
     if (shard_.active) words += (4ull << (ls + 1)) + 4096;     // halo rows of the last logup column group
+    if (shard_all_to_all()) {                                  // own columns over all rows, packed copy, halo exchange
+      const uint64_t G = shard_.world;
+      words += 2 * (((uint64_t)sp->n_cols / G + 1) + ((uint64_t)(4 * sp->n_rel) / G + 1)) * (2ull << ls) + 6 * (2ull << ls);
+    }
   }
   const int comp_log = max_log + 1;
   const int max_lde = comp_log + lb;
   words += (4ull << comp_log) * 2 + row_split(4ull << max_lde);  // composition values/coeffs + lde
+  if (shard_all_to_all()) words += 2ull << max_lde;              // one composition column over all rows + its packed copy
   words += row_split((4ull << max_lde) * 3);                   // quotient columns (all sizes) + fri layers
   words += row_split(7 * (16ull << max_lde));                  // merkle trees (4 trace + fri first + inner)
   if (shard_.active) words += 64ull << std::min(max_lde, std::max(shard_.fri_min_log, 12) + 2);  // replicated small FRI layers + their trees
@@ -1319,11 +1415,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       uint64_t n = 1ull << ci.log_size;
       int nc = ci.spec->n_cols;
       uint32_t* coeffs = arena_.alloc_words((size_t)nc * n);
-      uint32_t* lde = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size);
+      const CommitOut co = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size);
       ci.main_start = off;
       off += nc;
       for (int c = 0; c < nc; ++c)
-        tree1.cols.push_back({ci.log_size, coeffs + (uint64_t)c * n, lde ? lde + (uint64_t)c * 2 * n : nullptr});
+        tree1.cols.push_back({ci.log_size, coeffs + (uint64_t)c * n, co.lde ? co.lde + (uint64_t)c * co.stride : nullptr,
+                              co.sharded, co.owner_of(c)});
     }
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
@@ -1383,9 +1480,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       ci.inter_start = off;
       off += nic;
       // interaction evals -> coefficients in place, registered as tree-2 columns
-      uint32_t* ilde = interpolate_for_commit(ievals, ievals, nic, ci.log_size);
+      const CommitOut co = interpolate_for_commit(ievals, ievals, nic, ci.log_size, nic - 4);
+      ci.halo = co.halo;
       for (int c = 0; c < nic; ++c)
-        tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, ilde ? ilde + (uint64_t)c * 2 * n : nullptr});
+        tree2.cols.push_back({ci.log_size, ievals + (uint64_t)c * n, co.lde ? co.lde + (uint64_t)c * co.stride : nullptr,
+                              co.sharded, co.owner_of(c)});
     }
   }
   {
@@ -1442,6 +1541,9 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         // The mask offset -1 of the last logup column group reads other row blocks: under bit reversal the previous
         // row of block b lies in block rev(rev(b)+1) (odd storage indices) or rev(rev(b)-1) (even ones).  Evaluate
         // those two blocks of the group's 4 columns here as well, straight from the coefficients.
+        if (ci.halo) {   // arrived with the interaction commit's all-to-all
+          a.prev_last = ci.halo;
+        } else {
         uint32_t* halo = arena_.alloc_words(4 * E);
         const uint32_t G = 1u << sg, rb = bit_reverse(shard_.rank, sg);
         const uint32_t nb[2] = {bit_reverse((rb + 1) & (G - 1), sg), bit_reverse((rb + G - 1) & (G - 1), sg)};
@@ -1452,6 +1554,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
                                                    ci.log_size, 4, e, sg, nb[h], tw(e), stream_);
         }
         a.prev_last = halo;
+        }
       }
       a.out = sub[e];
       a.accumulate = first ? 0 : 1;
@@ -1482,7 +1585,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       for (auto& kv : sub) gather_columns(kv.second, 1ull << kv.first, 4, (1ull << kv.first) >> sg);
     // DomainEvaluationAccumulator::finalize: fold smaller sizes into larger ones
     uint32_t* cur = nullptr;  // coefficients, 4 x 2^cur_log
-    uint32_t* comp_lde = nullptr;
+    CommitOut comp_out;
     int cur_log = 0;
     for (auto& kv : sub) {
       int e = kv.first;
@@ -1497,7 +1600,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         launch_secure_add(vals, ext, 4 * E, stream_);
       }
       if (e == comp_log) {
-        comp_lde = interpolate_for_commit(vals, vals, 4, e);   // the last (largest) size: the committed polynomial
+        comp_out = interpolate_for_commit(vals, vals, 4, e);   // the last (largest) size: the committed polynomial
       } else {
         StageTimer t(this, log, stream_, C_FFT);
         timings.fft_launches += launch_ifft(vals, E, vals, E, 4, e, itw(e), stream_);
@@ -1509,7 +1612,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     }
     if (cur_log != comp_log) throw LmnError(LMN_ERR_INTERNAL, "composition size mismatch");
     for (int k = 0; k < 4; ++k)
-      tree3.cols.push_back({comp_log, cur + ((uint64_t)k << comp_log), comp_lde ? comp_lde + ((uint64_t)k << (comp_log + 1)) : nullptr});
+      tree3.cols.push_back({comp_log, cur + ((uint64_t)k << comp_log), comp_out.lde ? comp_out.lde + (uint64_t)k * comp_out.stride : nullptr,
+                            comp_out.sharded, comp_out.owner_of(k)});
   }
   {
     StageTimer st(this, log, stream_, C_COMP_COMMIT);
@@ -1551,7 +1655,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     std::vector<EvalJob> jobs;
     for (int t = 0; t < 4; ++t)
       for (size_t c = 0; c < trees[t]->cols.size(); ++c)
-        for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p});
+        for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p, trees[t]->cols[c].owner});
     std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true);
     size_t k = 0;
     for (int t = 0; t < 4; ++t) {
@@ -2058,85 +2162,113 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
 }
 
 // ------------------------------------------------------------------------------------ single-proof sharding
-#ifndef LMN_EMU
 }  // namespace lmn
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 namespace lmn {
 // Built-in transport: RCCL over xGMI, bound at run time (the library has no link-time dependency on librccl, so a
 // single-GPU deployment never loads it).  One communicator per context, collectives enqueued on the prover's stream.
+// The handful of RCCL entry points used are declared here (NCCL's stable C ABI) instead of including rccl.h, so that the
+// test-only emulation build carries the same transport code: tests/emu/stub_rccl.cpp stands in for librccl there
+// (LMN_RCCL_LIB names the library to load) and runs unique-id exchange, per-rank communicator initialisation, group
+// batching and the collectives themselves with world 2 / 4 / 8 on a machine without GPUs.
+typedef struct lmnNcclComm* lmnNcclComm_t;
+struct lmnNcclUniqueId {
+  char internal[128];
+};
+constexpr int LMN_NCCL_UINT8 = 1;   // ncclUint8 / ncclChar
 struct RcclApi {
   void* handle = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  int (*GetUniqueId)(lmnNcclUniqueId*) = nullptr;
+  int (*CommInitRank)(lmnNcclComm_t*, int, lmnNcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(lmnNcclComm_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, lmnNcclComm_t, void*) = nullptr;
+  int (*Send)(const void*, size_t, int, int, lmnNcclComm_t, void*) = nullptr;
+  int (*Recv)(void*, size_t, int, int, lmnNcclComm_t, void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   static RcclApi& get() {
     static RcclApi api = [] {
       RcclApi a;
-      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (a.handle) break;
+      const char* env = getenv("LMN_RCCL_LIB");
+      if (env && *env) {
+        a.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+      } else {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+          a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+          if (a.handle) break;
+        }
       }
       if (a.handle) {
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
         a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
-        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+        a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
         a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
       }
       return a;
     }();
     if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather)
-      throw LmnError(LMN_ERR_NO_DEVICE, "librccl could not be loaded (needed for lmn_ctx_set_shard_rccl)");
+      throw LmnError(LMN_ERR_NO_DEVICE, "librccl could not be loaded (needed for lmn_ctx_set_shard_rccl; LMN_RCCL_LIB overrides "
+                                        "the library name)");
     return api;
   }
 };
 struct RcclTransport {
-  ncclComm_t comm = nullptr;
-  uint32_t rank = 0;
+  lmnNcclComm_t comm = nullptr;
+  uint32_t rank = 0, world = 1;
   static int all_gather(void* user, void* buf, size_t bytes, void* stream) {
     RcclTransport* t = (RcclTransport*)user;
-    ncclResult_t r = RcclApi::get().AllGather((const char*)buf + (size_t)t->rank * bytes, buf, bytes, ncclUint8, t->comm,
-                                              (hipStream_t)stream);
-    return r == ncclSuccess ? 0 : (int)r;
+    return RcclApi::get().AllGather((const char*)buf + (size_t)t->rank * bytes, buf, bytes, LMN_NCCL_UINT8, t->comm, stream);
   }
-  static int group_begin(void*) { return RcclApi::get().GroupStart() == ncclSuccess ? 0 : 1; }
-  static int group_end(void*) { return RcclApi::get().GroupEnd() == ncclSuccess ? 0 : 1; }
+  static int group_begin(void*) { return RcclApi::get().GroupStart(); }
+  static int group_end(void*) { return RcclApi::get().GroupEnd(); }
+  // grouped point-to-point: xGMI links are point-to-point, every peer pair moves its part over its own link
+  static int all_to_all(void* user, const void* send, const size_t* so, const size_t* sb, void* recv, const size_t* ro,
+                        const size_t* rb, void* stream) {
+    RcclTransport* t = (RcclTransport*)user;
+    RcclApi& api = RcclApi::get();
+    int rc = api.GroupStart();
+    for (uint32_t p = 0; p < t->world && rc == 0; ++p) {
+      if (sb[p]) rc = api.Send((const char*)send + so[p], sb[p], LMN_NCCL_UINT8, (int)p, t->comm, stream);
+      if (rc == 0 && rb[p]) rc = api.Recv((char*)recv + ro[p], rb[p], LMN_NCCL_UINT8, (int)p, t->comm, stream);
+    }
+    const int rc_end = api.GroupEnd();
+    return rc ? rc : rc_end;
+  }
 };
 void rccl_unique_id(uint8_t* out) {
-  static_assert(sizeof(ncclUniqueId) <= LMN_RCCL_ID_BYTES, "ncclUniqueId larger than the ABI slot");
-  ncclUniqueId id;
-  ncclResult_t r = RcclApi::get().GetUniqueId(&id);
-  if (r != ncclSuccess) throw LmnError(LMN_ERR_INTERNAL, "ncclGetUniqueId failed");
+  static_assert(sizeof(lmnNcclUniqueId) <= LMN_RCCL_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+  lmnNcclUniqueId id;
+  if (RcclApi::get().GetUniqueId(&id) != 0) throw LmnError(LMN_ERR_INTERNAL, "ncclGetUniqueId failed");
   memset(out, 0, LMN_RCCL_ID_BYTES);
   memcpy(out, &id, sizeof id);
 }
 void Context::set_shard_rccl(uint32_t rank, uint32_t world, uint32_t fri_min_log, const uint8_t* id_bytes) {
+#ifndef LMN_EMU
   LMN_HIP_CHECK(hipSetDevice(device_));
+#endif
   {
-    lmn_collective probe{nullptr, &RcclTransport::all_gather, nullptr, nullptr};
+    lmn_collective probe{nullptr, &RcclTransport::all_gather, nullptr, nullptr, nullptr};
     check_shard_args(rank, world, fri_min_log, &probe);  // a rejected call leaves the current sharding untouched
   }
   clear_shard();
-  ncclUniqueId id;
+  lmnNcclUniqueId id;
   memcpy(&id, id_bytes, sizeof id);
   RcclTransport* t = new RcclTransport();
   t->rank = rank;
-  ncclResult_t r = RcclApi::get().CommInitRank(&t->comm, (int)world, id, (int)rank);
-  if (r != ncclSuccess) {
+  t->world = world;
+  if (RcclApi::get().CommInitRank(&t->comm, (int)world, id, (int)rank) != 0) {
     delete t;
     throw LmnError(LMN_ERR_INTERNAL, "ncclCommInitRank failed");
   }
   RcclApi& api = RcclApi::get();
   const bool can_group = api.GroupStart && api.GroupEnd;
   lmn_collective c{t, &RcclTransport::all_gather, can_group ? &RcclTransport::group_begin : nullptr,
-                   can_group ? &RcclTransport::group_end : nullptr};
+                   can_group ? &RcclTransport::group_end : nullptr,
+                   can_group && api.Send && api.Recv ? &RcclTransport::all_to_all : nullptr};
   try {
     set_shard(rank, world, fri_min_log, &c);
   } catch (...) {
@@ -2151,13 +2283,6 @@ static void rccl_release(void* p) {
   if (t->comm) RcclApi::get().CommDestroy(t->comm);
   delete t;
 }
-#else
-void rccl_unique_id(uint8_t*) { throw LmnError(LMN_ERR_NO_DEVICE, "no RCCL in the emulation build"); }
-void Context::set_shard_rccl(uint32_t, uint32_t, uint32_t, const uint8_t*) {
-  throw LmnError(LMN_ERR_NO_DEVICE, "no RCCL in the emulation build");
-}
-static void rccl_release(void*) {}
-#endif
 
 void Context::check_shard_args(uint32_t rank, uint32_t world, uint32_t fri_min_log, const lmn_collective* coll) {
   if (world == 0 || (world & (world - 1)) || world > 8 || rank >= world)

@@ -46,6 +46,7 @@ struct Instance {
   int log_size;
   int main_start, inter_start;  // column offsets inside trees 1 / 2
   QM31 claimed;
+  uint32_t* halo = nullptr;               // sharded proofs with all_to_all: neighbour blocks of the last logup group
   const QM31* d_claimed_shift = nullptr;  // device [claimed, shift] (prover only)
   uint32_t* trace_evals = nullptr;        // device, n_cols x 2^log_size (prover only)
   int pre_idx[2] = {-1, -1};    // tree-0 column indices of the component's preprocessed columns
@@ -84,6 +85,7 @@ struct DevColumn {
   uint32_t* coeffs;  // 2^log_size
   uint32_t* lde;     // 2^(log_size + log_blowup), bit-reversed canonic-domain evaluations
   bool sharded = false;  // lde holds only this rank's block of 2^(log_size + log_blowup - g) rows
+  int owner = -1;        // >= 0: the coefficients exist on that rank only (column-parallel interpolation)
 };
 
 // A column as the Merkle / decommitment code sees it.  sharded: ptr is this rank's aligned block of
@@ -203,7 +205,27 @@ class Context {
   // evaluations -> coefficients (`coeffs` may equal `evals`).  Unsharded proofs of a supported size get the blown-up
   // evaluation in the same three launches (launch_interp_extend): returns the LDE (ncols x 2^(log + log_blowup),
   // arena) or nullptr when lde_and_merkle has to produce it.
-  uint32_t* interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size);
+  //   Sharded proofs whose collective offers all_to_all (SURVEY.md section 8e stages A / B): this rank interpolates and
+  //   extends only its contiguous share of the columns and receives its row block of every column's LDE through one
+  //   all-to-all; coefficients then exist on the owning rank only (CommitOut::first), and with halo_first >= 0 the two
+  //   neighbouring row blocks of the 4 columns halo_first .. halo_first + 3 (mask offset -1 of the last logup column
+  //   group) arrive through a second, small all-to-all.
+  struct CommitOut {
+    uint32_t* lde = nullptr;      // nullptr: lde_and_merkle produces it
+    uint64_t stride = 0;          // words between the columns of `lde`
+    bool sharded = false;         // `lde` holds this rank's row block only
+    bool owned = false;           // column c's coefficients live on rank `owner_of(c)` only
+    int first[9] = {0};           // columns [first[r], first[r + 1]) belong to rank r
+    uint32_t* halo = nullptr;     // 4 columns x 2^(log + 1) words, the two neighbour blocks filled in
+    int owner_of(int c) const {
+      if (!owned) return -1;
+      int r = 0;
+      while (first[r + 1] <= c) ++r;
+      return r;
+    }
+  };
+  CommitOut interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size, int halo_first = -1);
+  bool shard_all_to_all() const;
   // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
   void lde_and_merkle(DevTree& tree);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its

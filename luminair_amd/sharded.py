@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 
-def shard_context(ctx, group=None, fri_min_log: int = 0):
+def shard_context(ctx, group=None, fri_min_log: int = 0, all_to_all: bool = True):
     """Make `ctx.prove_tables` a single proof sharded over the ranks of `group` (torch.distributed must be
     initialised; one context per rank; every rank passes the same tables and receives the same proof bytes).
     `nccl` backend: the library's own RCCL communicator on the prover's stream (`lmn_ctx_set_shard_rccl`), the
@@ -53,7 +53,46 @@ def shard_context(ctx, group=None, fri_min_log: int = 0):
         for r, part in enumerate(parts):
             if r != rank:
                 t[r * nbytes:(r + 1) * nbytes] = part
-    ctx.set_shard(rank, world, all_gather, fri_min_log)
+    def a2a(send, send_off, send_bytes, recv, recv_off, recv_bytes, _stream):
+        # the all-to-all of SURVEY.md section 8e stage B over the same host-staged transport (tests only)
+        def read(ptr, nbytes):
+            if nbytes == 0:
+                return np.empty(0, np.uint8)
+            if device_memory:
+                from .backend import DeviceBuffer
+                return ctx.download(DeviceBuffer(ctx, ptr, nbytes, owned=False), np.uint8)
+            return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).copy()
+
+        def write(ptr, data):
+            if len(data) == 0:
+                return
+            if device_memory:
+                from .backend import DeviceBuffer
+                ctx.upload_to(DeviceBuffer(ctx, ptr, len(data), owned=False), data)
+            else:
+                np.ctypeslib.as_array((C.c_uint8 * len(data)).from_address(ptr))[:] = data
+        outs = [torch.from_numpy(read(send + send_off[p], send_bytes[p])) for p in range(world)]
+        ins = [torch.empty(recv_bytes[p], dtype=torch.uint8) for p in range(world)]
+        dist.all_to_all(ins, outs, group=group) if dist.get_backend(group) != "gloo" else _gloo_all_to_all(ins, outs, rank, world, group)
+        for p in range(world):
+            write(recv + recv_off[p], ins[p].numpy())
+    ctx.set_shard(rank, world, all_gather, fri_min_log, a2a if all_to_all else None)
+
+
+def _gloo_all_to_all(ins, outs, rank, world, group):
+    """gloo has no all_to_all: pairwise exchange (isend / irecv), the own part is a copy"""
+    import torch.distributed as dist
+    reqs = []
+    for p in range(world):
+        if p == rank:
+            ins[p].copy_(outs[p])
+            continue
+        if outs[p].numel():
+            reqs.append(dist.isend(outs[p], p, group=group))
+        if ins[p].numel():
+            reqs.append(dist.irecv(ins[p], p, group=group))
+    for r in reqs:
+        r.wait()
 
 
 def _parent(left: bytes, right: bytes) -> bytes:

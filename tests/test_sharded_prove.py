@@ -44,7 +44,7 @@ def _cases():
     ]
 
 
-def _prove_all(make_ctx):
+def _prove_all(make_ctx, stats=None):
     out = []
     ctxs = {}
     for case in _cases():
@@ -54,6 +54,9 @@ def _prove_all(make_ctx):
             ctxs[key] = make_ctx(*key)
         proof = ctxs[key].prove_tables([(k, r, len(r)) for k, r in tabs], luts)
         out.append((name, hashlib.sha256(proof).hexdigest(), len(proof)))
+        if stats is not None:
+            t = ctxs[key].timings()
+            stats.append((t["shard_a2a_calls"], t["shard_a2a_bytes"], t["shard_gather_calls"]))
     for c in ctxs.values():
         c.close()
     return out
@@ -70,7 +73,9 @@ def _make_ctx(pinned, pcs=None):
     return backend.Context(0, cfg, lib)
 
 
-def _worker(rank, world, port, fri_min_log, q):
+def _worker(rank, world, port, fri_min_log, a2a, q):
+    # a2a: SURVEY 8e stages A / B (column-parallel interpolation + all-to-all into row blocks) for every column size
+    os.environ["LMN_SHARD_A2A_MIN_LOG"] = "4"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from luminair_amd.sharded import shard_context
@@ -79,7 +84,7 @@ def _worker(rank, world, port, fri_min_log, q):
     try:
         def make(pinned, pcs=None):
             ctx = _make_ctx(pinned, pcs)
-            shard_context(ctx, fri_min_log=fri_min_log)
+            shard_context(ctx, fri_min_log=fri_min_log, all_to_all=a2a)
             return ctx
         # errors surface identically on every rank (same transcript, same checks) and leave the contexts usable
         from luminair_amd import backend, synthetic as syn
@@ -98,7 +103,12 @@ def _worker(rank, world, port, fri_min_log, q):
         except backend.LuminairBackendError as e:
             assert e.code == backend.ERR_INVALID_ARGUMENT
         ctx.close()
-        q.put((rank, _prove_all(make)))
+        stats = []
+        proofs = _prove_all(make, stats)
+        # the exchange mode under test really ran: every proof used the all-to-all (two per interaction run: rows + halo), or none did
+        assert all((c > 0) == bool(a2a) for c, _, _ in stats), stats
+        assert all(g > 0 for _, _, g in stats)
+        q.put((rank, proofs))
     finally:
         dist.destroy_process_group()
 
@@ -115,12 +125,12 @@ def single_rank_proofs():
     return _single()
 
 
-@pytest.mark.parametrize("world,fri_min_log", [(2, 4), (4, 5), (8, 0)])
-def test_sharded_prove_is_byte_identical(world, fri_min_log, single_rank_proofs):
+@pytest.mark.parametrize("world,fri_min_log,a2a", [(2, 4, True), (4, 5, True), (8, 0, True), (2, 5, False), (8, 4, False)])
+def test_sharded_prove_is_byte_identical(world, fri_min_log, a2a, single_rank_proofs):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fri_min_log, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fri_min_log, a2a, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -190,7 +200,7 @@ def _gpu_prove_all(lib, shard=None):
     return out
 
 
-def _gpu_worker(rank, world, port, fri_min_log, lib_path, q):
+def _gpu_worker(rank, world, port, fri_min_log, lib_path, q, a2a=True):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from luminair_amd import backend, synthetic as syn
@@ -199,16 +209,18 @@ def _gpu_worker(rank, world, port, fri_min_log, lib_path, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # every rank on GPU 0: the sharded code paths, not the speed-up
-        q.put((rank, _gpu_prove_all(backend.Library(lib_path), lambda c: shard_context(c, fri_min_log=fri_min_log))))
+        q.put((rank, _gpu_prove_all(backend.Library(lib_path),
+                                    lambda c: shard_context(c, fri_min_log=fri_min_log, all_to_all=a2a))))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,fri_min_log", [(2, 6), (4, 0), (8, 7)])
-def test_gpu_sharded_prove_multi_rank_on_one_gpu(world, fri_min_log, hip_lib_path):
+@pytest.mark.parametrize("world,fri_min_log,a2a", [(2, 6, True), (4, 0, True), (8, 7, True), (4, 6, False)])
+def test_gpu_sharded_prove_multi_rank_on_one_gpu(world, fri_min_log, a2a, hip_lib_path):
     """The world > 1 code paths of the REAL library (row-block LDEs from `k_fft_top_block`, halo blocks of the last
-    logup group, row-offset constraint / quotient / fold kernels, owner-aware decommitment) on hardware: `world`
+    logup group, row-offset constraint / quotient / fold kernels, owner-aware decommitment; with a2a the
+    column-parallel interpolate + extend, the block packing and the all-to-all for columns of 2^13 rows and more) on hardware: `world`
     processes share GPU 0, the collective is the gloo-staged callback, and every rank must return the unsharded
     proof's bytes."""
     from luminair_amd import backend
@@ -216,7 +228,7 @@ def test_gpu_sharded_prove_multi_rank_on_one_gpu(world, fri_min_log, hip_lib_pat
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, fri_min_log, hip_lib_path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, fri_min_log, hip_lib_path, q, a2a)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
