@@ -62,12 +62,31 @@ def record_worker(rank, world, port, name, path, q):
         ctx.upload_to(DeviceBuffer(ctx, buf, nbytes * world, owned=False), whole)
         if rank == 0:
             rec.append(whole)
-    ctx.set_shard(rank, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')))
+    def all_to_all(send, so, sb, recv, ro, rb, _stream):
+        outs = [torch.from_numpy(ctx.download(DeviceBuffer(ctx, send + so[p], sb[p], owned=False), np.uint8)) if sb[p]
+                else torch.empty(0, dtype=torch.uint8) for p in range(world)]
+        ins = [torch.empty(rb[p], dtype=torch.uint8) for p in range(world)]
+        from luminair_amd.sharded import _gloo_all_to_all
+        _gloo_all_to_all(ins, outs, rank, world, None)
+        for p in range(world):
+            if rb[p]:
+                ctx.upload_to(DeviceBuffer(ctx, recv + ro[p], rb[p], owned=False), ins[p].numpy())
+        if rank == 0:
+            rec.append([ins[p].numpy().copy() for p in range(world)])
+    use_a2a = os.environ.get("LMN_REPLAY_A2A", "1") != "0"
+    ctx.set_shard(rank, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')), all_to_all if use_a2a else None)
     tabs = workload(name)
     bufs = [(k, ctx.upload(r), len(r)) for k, r in tabs]
     proof = ctx.prove_tables(bufs)
     if rank == 0:
-        np.savez(path, *rec)
+        flat = {}
+        for i, r in enumerate(rec):
+            if isinstance(r, list):
+                for p_, part in enumerate(r):
+                    flat["a2a_%d_%d" % (i, p_)] = part
+            else:
+                flat["ag_%d" % i] = r
+        np.savez(path, n=np.array([len(rec)]), **flat)
     q.put((rank, hashlib.sha256(proof).hexdigest()))
     ctx.close()
     dist.destroy_process_group()
@@ -81,23 +100,49 @@ def replay(world, name, path, want_sha, reps):
     from luminair_amd import backend
     from luminair_amd.backend import DeviceBuffer
     data = np.load(path)
-    rec = [data["arr_%d" % i] for i in range(len(data.files))]
+    rec = []
+    for i in range(int(data["n"][0])):
+        if "ag_%d" % i in data.files:
+            rec.append(data["ag_%d" % i])
+        else:
+            rec.append([data["a2a_%d_%d" % (i, p_)] for p_ in range(world)])
     ctx = backend.Context(0)
-    staged = [ctx.upload(r) for r in rec]
+    staged = [ctx.upload(r) if not isinstance(r, list) else [ctx.upload(x) if len(x) else None for x in r] for r in rec]
     state = {"i": 0, "mode": "pcie"}
+
+    def all_to_all(send, so, sb, recv, ro, rb, _stream):
+        k = state["i"] % len(rec)
+        state["i"] += 1
+        parts = rec[k]
+        assert isinstance(parts, list) and [len(x) for x in parts] == list(rb)
+        for p_ in range(world):
+            if not rb[p_]:
+                continue
+            if p_ == 0:        # the own part is a real device copy out of the send buffer
+                ctx.device_copy(recv + ro[0], send + so[0], rb[0])
+            elif state["mode"] == "pcie":
+                ctx.upload_to(DeviceBuffer(ctx, recv + ro[p_], rb[p_], owned=False), parts[p_])
+            else:
+                ctx.device_copy(recv + ro[p_], staged[k][p_].ptr, rb[p_])
 
     def all_gather(buf, nbytes, _stream):
         k = state["i"] % len(rec)
         state["i"] += 1
-        assert len(rec[k]) == nbytes * world
+        assert not isinstance(rec[k], list) and len(rec[k]) == nbytes * world
         if state["mode"] == "pcie":
             ctx.upload_to(DeviceBuffer(ctx, buf, nbytes * world, owned=False), rec[k])
         else:
             ctx.device_copy(buf, staged[k].ptr, nbytes * world)
-    ctx.set_shard(0, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')))
+    use_a2a = os.environ.get("LMN_REPLAY_A2A", "1") != "0"
+    ctx.set_shard(0, world, all_gather, int(os.environ.get('LMN_FRI_MIN_LOG', '0')), all_to_all if use_a2a else None)
     tabs = workload(name)
     bufs = [(k, ctx.upload(r), len(r)) for k, r in tabs]
-    res = {"world": world, "all_gathers_per_proof": len(rec), "gathered_bytes_per_proof": int(sum(len(r) for r in rec))}
+    ags = [r for r in rec if not isinstance(r, list)]
+    a2as = [r for r in rec if isinstance(r, list)]
+    res = {"world": world, "exchange": "all_to_all + all_gather" if use_a2a else "all_gather only (replicated interpolation)",
+           "all_gathers_per_proof": len(ags), "gathered_bytes_per_proof": int(sum(len(r) for r in ags)),
+           "all_to_alls_per_proof": len(a2as),
+           "all_to_all_received_bytes_per_proof": int(sum(len(x) for r in a2as for x in r[1:]))}
     for mode in ("pcie", "ideal"):
         state["mode"] = mode
         assert hashlib.sha256(ctx.prove_tables(bufs)).hexdigest() == want_sha, "replayed rank-0 proof differs"
@@ -117,11 +162,17 @@ def replay(world, name, path, want_sha, reps):
     #  direct: 15 us per GROUP of calls (the library batches the coordinate columns of one exchange in one RCCL
     #          group: consecutive calls of equal size are counted once), (world-1) peers feeding the rank over their
     #          own links at ~153 GB/s each (xGMI is point-to-point: 7 links per GPU on an 8-GPU node)
+    #  an all-to-all is point-to-point by construction: ring = everything a rank receives passes one link; direct = every
+    #  peer's part over its own link (the largest part bounds the call)
     recv = res["gathered_bytes_per_proof"] * (world - 1) / world
-    groups = sum(1 for i, r in enumerate(rec) if i == 0 or len(r) != len(rec[i - 1]))
+    groups = sum(1 for i, r in enumerate(ags) if i == 0 or len(r) != len(ags[i - 1]))
     res["all_gather_groups_per_proof"] = groups
-    res["modelled_exchange_ms"] = 1e3 * (len(rec) * 15e-6 + recv / 150e9)
-    res["modelled_exchange_direct_links_ms"] = 1e3 * (groups * 15e-6 + recv / (153e9 * max(1, world - 1)))
+    a2a_recv = res["all_to_all_received_bytes_per_proof"]
+    a2a_direct = sum(max((len(x) for x in r[1:]), default=0) for r in a2as)
+    res["exchanged_bytes_received_per_rank"] = int(recv + a2a_recv)
+    res["modelled_exchange_ms"] = 1e3 * ((len(ags) + len(a2as)) * 15e-6 + (recv + a2a_recv) / 150e9)
+    res["modelled_exchange_direct_links_ms"] = 1e3 * ((groups + len(a2as)) * 15e-6 + recv / (153e9 * max(1, world - 1))
+                                                      + a2a_direct / 153e9)
     res["estimated_latency_ms"] = res["rank0_ms_ideal"] + res["modelled_exchange_ms"]
     res["estimated_latency_direct_links_ms"] = res["rank0_ms_ideal"] + res["modelled_exchange_direct_links_ms"]
     ctx.close()
