@@ -628,6 +628,40 @@ def main(argv=None):
             syn.config3_mixed(lr + 1, lr, lr), _bk.VARIANT_KAT, 16,
             "BASELINE config 3: Add 2^%d + Mul 2^%d + Recip 2^%d rows in one pie (three components, mixed-size trees; "
             "Recip's constraint form unpinned)" % (lr + 1, lr, lr), n_ctx=min(inflight, 4)))
+    if rank == 0 and world == 1 and not args.no_extras and not args.host_rows and not emu:
+        # small proofs (the reference's own benchmark shape, BASELINE config 4): lock-step batches (lmn_batch_prove,
+        # libluminair_hip_batch.so) next to concurrent contexts of the main library
+        def run_small():
+            from luminair_amd.batch import BatchProver
+            res = {}
+            tabs4, luts4 = syn.config4_black_scholes_shape()
+            for name, mk, luts, B in (("reference_shape_32x32_add", lambda i: syn.config2_graph_faithful(1024, 100 + i), None, 64),
+                                      ("config_4", lambda i: tabs4, luts4, 16)):
+                pies = [[(k, r, len(r)) for k, r in mk(i)] for i in range(B)]
+                sp = mk_prover(protocol_variant=_bk.VARIANT_PINNED)
+                want = sp.ctx.prove_tables(pies[0], luts)
+                solo_ms = solo_latency(sp.ctx, pies[0], 9, luts)
+                sp.ctx.close()
+                bp = BatchProver(dev, B, protocol_variant=_bk.VARIANT_PINNED)
+                try:
+                    got = bp.prove_batch(pies, luts)
+                    if got[0] != want:
+                        raise RuntimeError("batched proof bytes differ from lmn_prove")
+                    for _ in range(2):
+                        bp.prove_batch(pies, luts)
+                    reps = max(4, 512 // B)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        bp.prove_batch(pies, luts)
+                    dt = time.perf_counter() - t0
+                finally:
+                    bp.close()
+                res[name] = {"value": B * reps / dt, "unit": "proofs/s", "proofs_per_batch": B, "ms_per_batch": 1e3 * dt / reps,
+                             "solo_lmn_prove_latency_ms": solo_ms, "bytes_identical_to_lmn_prove": True}
+            res["note"] = ("lmn_batch_prove: B pies of identical shape in lock-step, one launch per pipeline step for the whole "
+                           "batch (host rows, PINNED variant); config 4 = 2->64->64->1 tanh MLP shape with its 2^17-row exp2 LUT")
+            return res
+        line["small_proofs"] = sub_result("small_proofs", run_small)
     if anchor:
         line["reference_shape_anchor"] = anchor
     if trace_gen:

@@ -1,7 +1,7 @@
 // Runtime of the lock-step batch build (batch.h) and its C entry points lmn_batch_* (include/luminair_hip.h).
 // Only compiled into libluminair_hip_batch.so (-DLMN_BATCH).
 #ifdef LMN_BATCH
-#include "../../include/luminair_hip.h"
+#include "../../include/luminair_hip_batch.h"
 
 #include <ucontext.h>
 

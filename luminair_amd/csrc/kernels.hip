@@ -29,6 +29,32 @@ constexpr int TPB = 256;
 
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Experiment switch (tools/build_variants.sh qphase "-DLMN_QM31_PHASES"): the 16 multiply-accumulates of a QM31 product and
+// the multiply-accumulate runs of the lazy dot products issued as first-port phases (issue_phases.h), as the Blake2s and
+// butterfly code does.
+#if defined(LMN_QM31_PHASES) && defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU)
+LMN_D QM31 q_mul_phased(QM31 x, QM31 y) {
+  const uint32_t nb = P31 - x.b, nd = P31 - x.d;
+  const uint32_t c2 = m_dbl(x.c), d2 = m_dbl(x.d);
+  const uint32_t e1 = m_sub(c2, x.d);
+  const uint32_t e2 = P31 - m_add(d2, x.c);
+  const uint32_t f1 = m_add(x.c, d2);
+  LMN_PHASE_PORT0();
+  const uint64_t lre = (uint64_t)x.a * y.a + (uint64_t)nb * y.b + (uint64_t)e1 * y.c + (uint64_t)e2 * y.d;
+  const uint64_t lim = (uint64_t)x.a * y.b + (uint64_t)x.b * y.a + (uint64_t)f1 * y.c + (uint64_t)e1 * y.d;
+  const uint64_t hre = (uint64_t)x.a * y.c + (uint64_t)nb * y.d + (uint64_t)x.c * y.a + (uint64_t)nd * y.b;
+  const uint64_t him = (uint64_t)x.a * y.d + (uint64_t)x.b * y.c + (uint64_t)x.c * y.b + (uint64_t)x.d * y.a;
+  LMN_PHASE_ANY();
+  return {m_red64(lre), m_red64(lim), m_red64(hre), m_red64(him)};
+}
+#define q_mul q_mul_phased
+#define LMN_QPHASE_PORT0() LMN_PHASE_PORT0()
+#define LMN_QPHASE_ANY() LMN_PHASE_ANY()
+#else
+#define LMN_QPHASE_PORT0() do { } while (0)
+#define LMN_QPHASE_ANY() do { } while (0)
+#endif
+
 LMN_D QM31 load_secure_col(const uint32_t* __restrict__ base, uint64_t stride, uint64_t i) {
   return QM31{base[i], base[stride + i], base[2 * stride + i], base[3 * stride + i]};
 }
@@ -2304,10 +2330,12 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
       uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
       cv[k] = lo < lo_n ? cp[lo] : 0u;
     }
+    LMN_QPHASE_PORT0();
     qacc_mad(in0, Hv, cv[0]);
     qacc_mad(in1, Hv, cv[1]);
     qacc_mad(in2, Hv, cv[2]);
     qacc_mad(in3, Hv, cv[3]);
+    LMN_QPHASE_ANY();
     if (++pending == 3) {
       pending = 0;
       qacc_fold(in0);
@@ -2457,13 +2485,17 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
       for (; kk + 6 <= k1; kk += 6) {
         uint32_t f0 = tab[kk].col[s], f1 = tab[kk + 1].col[s], f2 = tab[kk + 2].col[s];
         uint32_t f3 = tab[kk + 3].col[s], f4 = tab[kk + 4].col[s], f5 = tab[kk + 5].col[s];
+        LMN_QPHASE_PORT0();
         qacc_mad(acc, tab[kk].c, f0);
         qacc_mad(acc, tab[kk + 1].c, f1);
         qacc_mad(acc, tab[kk + 2].c, f2);
+        LMN_QPHASE_ANY();
         qacc_fold(acc);
+        LMN_QPHASE_PORT0();
         qacc_mad(acc, tab[kk + 3].c, f3);
         qacc_mad(acc, tab[kk + 4].c, f4);
         qacc_mad(acc, tab[kk + 5].c, f5);
+        LMN_QPHASE_ANY();
         qacc_fold(acc);
       }
       for (; kk < k1; ++kk) {

@@ -18,9 +18,12 @@ def test_batch_library_exports_the_batch_abi_and_the_whole_c_abi():
     if not os.path.exists(BATCH_LIB):
         import __graft_entry__
         __graft_entry__.build()
+    import re
     lib = backend.Library(BATCH_LIB)                    # binds every symbol of include/luminair_hip.h + checks the ABI version
-    for name in backend.EXPORTS + ["lmn_batch_create", "lmn_batch_prove", "lmn_batch_last_error", "lmn_batch_counter",
-                                   "lmn_batch_destroy"]:
+    hdr = open(os.path.join(ROOT, "include", "luminair_hip_batch.h")).read()
+    declared = sorted(set(re.findall(r"\b(lmn_batch_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == ["lmn_batch_counter", "lmn_batch_create", "lmn_batch_destroy", "lmn_batch_last_error", "lmn_batch_prove"]
+    for name in backend.EXPORTS + declared:
         getattr(lib.lib, name)
     # no GPU here: creating a batch fails loudly, it never falls back to anything
     if not __import__("torch").cuda.is_available():

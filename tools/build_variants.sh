@@ -8,7 +8,7 @@ make -s > /dev/null
 mkdir -p ../../tools/bin/variants
 while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -x hip $2 -c kernels.hip -o /tmp/kernels_$1.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/kernels_$1.o prover.o verifier.o capi.o level2.o -o ../../tools/bin/variants/$1.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/kernels_$1.o fft_fixed.o prover.o verifier.o capi.o level2.o -o ../../tools/bin/variants/$1.so
   echo "built tools/bin/variants/$1.so  ($2)"
   shift 2
 done
