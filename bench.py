@@ -459,7 +459,7 @@ def main(argv=None):
         launches = max(launches, 1)
         achieved = nbytes / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
         traffic = None
-        got = [pmc[k] for k in pmc_names if k in pmc]
+        got = [v for k, v in pmc.items() if any(k == n or k.startswith(n + "<") for n in pmc_names)]
         if got:
             tot_l = sum(g["launches"] for g in got)
             traffic = sum(g["hbm_bytes_per_launch_corrected"] * g["launches"] for g in got) / max(tot_l, 1)

@@ -29,7 +29,7 @@ PY
 )
 python tools/valu_summary.py $S $NP > $OUT/${TAG}_valu_summary.txt
 # multi-stream run: GPU busy fraction and kernels in flight
-rocprofv3 --output-format csv --kernel-trace -d $OUT/${TAG}_conc -o conc -- python bench.py --no-cpu-baseline --no-extras --no-anchor --steps 64 --warmup 8 > $OUT/${TAG}_bench_under_rocprof_inflight4.json 2> $OUT/${TAG}_conc.log
+rocprofv3 --output-format csv --kernel-trace -d $OUT/${TAG}_conc -o conc -- python bench.py --no-cpu-baseline --no-extras --no-anchor --steps 8 --warmup 1 > $OUT/${TAG}_bench_under_rocprof_inflight4.json 2> $OUT/${TAG}_conc.log
 python tools/overlap.py $(find $OUT/${TAG}_conc -name '*kernel_trace.csv' | head -1) 16 64 > $OUT/${TAG}_overlap.txt   # skip = 8 contexts + 8 warm-up proofs
 rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_sq $OUT/${TAG}_conc
 tail -25 $OUT/${TAG}_valu_summary.txt; cat $OUT/${TAG}_overlap.txt; tail -12 $OUT/${TAG}_kernel_timeline_one_proof.txt
