@@ -122,6 +122,88 @@ LMN_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32
   h[7] ^= v7 ^ v15;
 }
 
+// out <- F(h0, m, t0, final) for a FRESH hash (h0 = the unkeyed 32-byte-digest initial state) whose single block is also
+// its last: every Merkle node and every <= 16-column leaf.  On the device the first column half round takes the initial
+// state as LITERAL operands - a = (h_a + h_b) + x, d = K_d ^ a, c = K_c + d, b = K_b ^ c - so the 16 state registers are
+// first written by arithmetic instead of 16 constant moves in front of every compression (the asm operands of b2_half
+// are read-write); instruction classes and phases as in b2_half.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU) && !defined(LMN_B2_NO_PRIO) && !defined(LMN_B2_NO_FRESH)
+template <int LO, int HI>
+__device__ __forceinline__ void b2_half_first(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t& b0, uint32_t& b1,
+                                              uint32_t& b2, uint32_t& b3, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                              uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t x0, uint32_t y0,
+                                              uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3,
+                                              uint32_t kd0 /* IV4 ^ t0, wave-uniform */) {
+  constexpr uint32_t H0 = 0x6A09E667u ^ 0x01010020u, H1 = 0xBB67AE85u, H2 = 0x3C6EF372u, H3 = 0xA54FF53Au;
+  constexpr uint32_t H4 = 0x510E527Fu, H5 = 0x9B05688Cu, H6 = 0x1F83D9ABu, H7 = 0x5BE0CD19u;
+  asm volatile(
+      "s_setprio %33\n"
+      "v_add_u32 %0, %25, %16\n v_add_u32 %1, %26, %18\n v_add_u32 %2, %27, %20\n v_add_u32 %3, %28, %22\n"
+      "v_xor_b32 %12, %24, %0\n v_xor_b32 %13, %29, %1\n v_xor_b32 %14, %30, %2\n v_xor_b32 %15, %31, %3\n"
+      "s_setprio %34\n"
+      "v_alignbit_b32 %12, %12, %12, 16\n v_alignbit_b32 %13, %13, %13, 16\n v_alignbit_b32 %14, %14, %14, 16\n"
+      "v_alignbit_b32 %15, %15, %15, 16\n"
+      "s_setprio %33\n"
+      "v_add_u32 %8, 0x6A09E667, %12\n v_add_u32 %9, 0xBB67AE85, %13\n v_add_u32 %10, 0x3C6EF372, %14\n"
+      "v_add_u32 %11, 0xA54FF53A, %15\n"
+      "v_xor_b32 %4, 0x510E527F, %8\n v_xor_b32 %5, 0x9B05688C, %9\n v_xor_b32 %6, 0x1F83D9AB, %10\n"
+      "v_xor_b32 %7, 0x5BE0CD19, %11\n"
+      "s_setprio %34\n"
+      "v_alignbit_b32 %4, %4, %4, 12\n v_alignbit_b32 %5, %5, %5, 12\n v_alignbit_b32 %6, %6, %6, 12\n"
+      "v_alignbit_b32 %7, %7, %7, 12\n"
+      "v_add3_u32 %0, %0, %4, %17\n v_add3_u32 %1, %1, %5, %19\n v_add3_u32 %2, %2, %6, %21\n v_add3_u32 %3, %3, %7, %23\n"
+      "s_setprio %33\n"
+      "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"
+      "s_setprio %34\n"
+      "v_alignbit_b32 %12, %12, %12, 8\n v_alignbit_b32 %13, %13, %13, 8\n v_alignbit_b32 %14, %14, %14, 8\n"
+      "v_alignbit_b32 %15, %15, %15, 8\n"
+      "s_setprio %33\n"
+      "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"
+      "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"
+      "s_setprio %34\n"
+      "v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n"
+      "v_alignbit_b32 %7, %7, %7, 7\n"
+      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(c0), "=&v"(c1),
+        "=&v"(c2), "=&v"(c3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+      : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "s"(kd0), "n"(H0 + H4), "n"(H1 + H5),
+        "n"(H2 + H6), "n"(H3 + H7), "n"(H5), "n"(H6 ^ 0xffffffffu), "n"(H7), "n"(0), "n"(LO), "n"(HI));
+}
+#define LMN_B2_HAVE_FRESH 1
+#endif
+
+LMN_HD void b2_init(uint32_t h[8]);
+template <int LO = 0, int HI = LMN_B2_PRIO_HI>
+LMN_HD void b2_compress_fresh(uint32_t out[8], const uint32_t m[16], uint32_t t0) {
+#ifdef LMN_B2_HAVE_FRESH
+  uint32_t v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;
+  b2_half_first<LO, HI>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, m[0], m[1], m[2], m[3], m[4],
+                        m[5], m[6], m[7], 0x510E527Fu ^ t0);
+  b2_half<LO, HI>(v0, v1, v2, v3, v5, v6, v7, v4, v10, v11, v8, v9, v15, v12, v13, v14, m[8], m[9], m[10], m[11], m[12], m[13],
+                  m[14], m[15]);
+  LMN_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+  LMN_B2_LEAVE
+  out[0] = (0x6A09E667u ^ 0x01010020u) ^ v0 ^ v8;
+  out[1] = 0xBB67AE85u ^ v1 ^ v9;
+  out[2] = 0x3C6EF372u ^ v2 ^ v10;
+  out[3] = 0xA54FF53Au ^ v3 ^ v11;
+  out[4] = 0x510E527Fu ^ v4 ^ v12;
+  out[5] = 0x9B05688Cu ^ v5 ^ v13;
+  out[6] = 0x1F83D9ABu ^ v6 ^ v14;
+  out[7] = 0x5BE0CD19u ^ v7 ^ v15;
+#else
+  b2_init(out);
+  b2_compress<LO, HI>(out, m, t0, 0xffffffffu);
+#endif
+}
+
 // Two independent compressions interleaved statement by statement: 8 independent dependency chains per
 // half-round instead of 4, which keeps the VALU issuing when only ~2 waves share a SIMD.
 #define LMN_B2_G2(a, b, c, d, x, y, A, B, C, D, X, Y) \

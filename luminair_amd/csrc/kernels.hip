@@ -1209,8 +1209,7 @@ LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint3
   // every lane hashes the block alone and keeps its two words.  The DPP path is checked on the GPU.
   uint32_t h[8], m[16];
   for (int k = 0; k < 16; ++k) m[k] = msg[k];
-  b2_init(h);
-  b2_compress(h, m, t0, 0xffffffffu);
+  b2_compress_fresh(h, m, t0);
   o_lo = h[q];
   o_hi = h[4 + q];
   return;
@@ -1278,8 +1277,7 @@ LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t n
       uint32_t m[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) m[k] = sh[threadIdx.x * 16 + k];
-      b2_init(cur);
-      b2_compress(cur, m, 64u, 0xffffffffu);
+      b2_compress_fresh(cur, m, 64u);
       store_hash(out + (uint64_t)(node0 + threadIdx.x) * 8, cur);
     }
     __syncthreads();
@@ -1306,7 +1304,9 @@ LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, i
 // MODE 1: leaf level of a single-size tree (no child layer, one contiguous run of <= 16 columns: one
 // compression per leaf); MODE 2: pure inner level (children only); MODE 0: anything else.  The special modes
 // drop the run selection and the multi-block loop from the hot loop.
-template <int MODE>
+// ZT: the caller keeps the message words this mode never loads at zero (set once, outside its leaf loop), so they are not
+// rewritten for every leaf
+template <int MODE, bool ZT = false>
 LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
                             uint32_t i, uint32_t m[16], const MerkleFold& fold = MerkleFold{}) {
   if (MODE == 3) {
@@ -1325,12 +1325,19 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
     m[1] = r.b;
     m[2] = r.c;
     m[3] = r.d;
+    if (!ZT) {
 #pragma unroll
-    for (int k = 4; k < 16; ++k) m[k] = 0u;
+      for (int k = 4; k < 16; ++k) m[k] = 0u;
+    }
   } else if (MODE == 1) {
     const uint32_t* __restrict__ base = sg.base[0] + i;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m[k] = k < ncols ? base[(uint64_t)k * size] : 0u;
+    for (int k = 0; k < 16; ++k) {
+      if (k < ncols)
+        m[k] = base[(uint64_t)k * size];
+      else if (!ZT)
+        m[k] = 0u;
+    }
   } else if (MODE == 2) {
     const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
     uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
@@ -1346,14 +1353,11 @@ template <int MODE>
 LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
                             uint32_t i, uint32_t m[16], uint32_t h[8]) {
   if (MODE == 3) {
-    b2_init(h);
-    b2_compress(h, m, 16u, 0xffffffffu);
+    b2_compress_fresh(h, m, 16u);
   } else if (MODE == 1) {
-    b2_init(h);
-    b2_compress(h, m, 4u * (uint32_t)ncols, 0xffffffffu);
+    b2_compress_fresh(h, m, 4u * (uint32_t)ncols);
   } else if (MODE == 2) {
-    b2_init(h);
-    b2_compress(h, m, 64u, 0xffffffffu);
+    b2_compress_fresh(h, m, 64u);
   } else {
     merkle_hash_from(prev, sg, ncols, size, i, m, h);
   }
@@ -1375,20 +1379,30 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   const uint32_t W0 = (t >> 6) * (64u << sub);
   uint32_t cur[8];
   uint32_t cur_idx = 0;
-  uint32_t mnext[16];
-  merkle_load_mode<MODE>(prev, sg, ncols, size, W0 + lane, mnext, fold);
-  for (uint32_t j = 0; j < per; ++j) {
+  // software pipeline: the next batch's loads are in flight while this batch is compressed (only ~2 waves share a SIMD
+  // here, too few to hide HBM latency by occupancy alone).  Two message buffers alternate (the loop body handles an even and
+  // an odd batch), so the prefetched words are hashed where they were loaded - no 16-register copy per leaf.
+  uint32_t mA[16], mB[16];
+  constexpr bool ZT = MODE == 1 || MODE == 3;   // the words beyond a leaf's columns stay zero for the whole kernel
+  if (ZT) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mA[k] = mB[k] = 0u;
+  }
+  merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, W0 + lane, mA, fold);
+  auto leaf = [&](uint32_t j, uint32_t (&mc)[16], uint32_t (&mn)[16]) {
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
-    // software pipeline: the next batch's loads are in flight while this batch is compressed (only ~2
-    // waves share a SIMD here, too few to hide HBM latency by occupancy alone)
-    uint32_t mcur[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) mcur[k] = mnext[k];
-    if (j + 1 < per) merkle_load_mode<MODE>(prev, sg, ncols, size, node + 64u, mnext, fold);
-    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mcur, cur);
+    if (j + 1 < per) merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, node + 64u, mn, fold);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur);
     store_hash(outs.p[0] + (uint64_t)node * 8, cur);
-    uint32_t jj = j;
+  };
+  for (uint32_t j = 0; j < per; j += 2) {
+    leaf(j, mA, mB);
+    if (per == 1) break;                       // sub = 0: one leaf per lane, nothing to merge in registers
+#pragma unroll
+    for (int k = 0; k < 8; ++k) stack[k * TPB + threadIdx.x] = cur[k];   // level-0 slot: the even batch waits for its sibling
+    leaf(j + 1, mB, mA);
+    uint32_t jj = j + 1;
     int lvl = 0;
     while (jj & 1u) {
       const bool b = ((lane >> lvl) & 1u) != 0u;
@@ -1402,8 +1416,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
       }
       // the pending (older) node of this lane sits exactly 64 nodes before the newer one at every level
       cur_idx = (b ? cur_idx : cur_idx - 64u) >> 1;
-      b2_init(cur);
-      b2_compress(cur, m, 64u, 0xffffffffu);
+      b2_compress_fresh(cur, m, 64u);
       jj >>= 1;
       ++lvl;
       store_hash(outs.p[lvl] + (uint64_t)cur_idx * 8, cur);
@@ -1444,8 +1457,7 @@ LMN_D void chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_al
     m[8 + k] = root[k];
     root_copy[k] = root[k];
   }
-  b2_init(h);
-  b2_compress(h, m, 64u, 0xffffffffu);
+  b2_compress_fresh(h, m, 64u);
   for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
   ch->n_sent = 0u;
   for (;;) {
@@ -1619,8 +1631,7 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
       m[1] = ly.vals[size + i];
       m[2] = ly.vals[2 * size + i];
       m[3] = ly.vals[3 * size + i];
-      b2_init(cur);
-      b2_compress(cur, m, 16u, 0xffffffffu);
+      b2_compress_fresh(cur, m, 16u);
       store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
 #pragma unroll
       for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
