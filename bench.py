@@ -444,13 +444,13 @@ def main(argv=None):
     except Exception:
         pass
     fams = {
-        "k_fft_staged": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"],
+        "k_fft_fx": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"],
                          ["k_fft_staged<false>", "k_fft_staged<true>", "k_fft_interp_extend", "k_fft_fx", "k_fft_interp_extend_fx"]),
         "k_merkle_fused": (tm["merkle_fused_ms"], tm["merkle_fused_bytes"], tm["merkle_fused_launches"],
                            ["k_merkle_fused", "k_merkle_fused<0>", "k_merkle_fused<1>", "k_merkle_fused<2>", "k_merkle_fused<3>"]),
     }
     alu = {
-        "k_fft_staged": (tm["fft_butterflies"], BUTTERFLY_PEAK_G, "G butterflies/s"),
+        "k_fft_fx": (tm["fft_butterflies"], BUTTERFLY_PEAK_G, "G butterflies/s"),
         "k_merkle_fused": (tm["merkle_fused_compressions"], BLAKE2S_PEAK_GCOMP, "G Blake2s compressions/s"),
     }
 
