@@ -87,9 +87,22 @@ inline void lmn_sync(lmn_stream_t s) {
   ::lmn::batch_sync(s);   // a rendezvous of the lock-step group: one stream wait for all members
   return;
 #endif
-  static const int mode = getenv("LMN_SYNC_MODE") ? atoi(getenv("LMN_SYNC_MODE")) : 0;  // 0 spin, 1 block, 2 hybrid
+  static const int mode = getenv("LMN_SYNC_MODE") ? atoi(getenv("LMN_SYNC_MODE")) : 0;  // 0 spin, 1 hipStreamSynchronize, 2 hybrid, 3 blocking event
   if (mode == 1) {
     LMN_HIP_CHECK(hipStreamSynchronize(s));
+    return;
+  }
+  if (mode == 3) {   // sleep on an interrupt: a blocking-sync event recorded behind the stream's work (no polling at all)
+    static thread_local hipEvent_t ev = nullptr;
+    static thread_local int ev_dev = -1;
+    int dev = 0;
+    LMN_HIP_CHECK(hipGetDevice(&dev));
+    if (!ev || ev_dev != dev) {
+      LMN_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+      ev_dev = dev;
+    }
+    LMN_HIP_CHECK(hipEventRecord(ev, s));
+    LMN_HIP_CHECK(hipEventSynchronize(ev));
     return;
   }
   for (int it = 0;; ++it) {

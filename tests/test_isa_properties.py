@@ -137,3 +137,16 @@ def test_fixed_shape_fft_kernels_stay_close_to_11_vector_instructions_per_butter
     # no 64-bit per-lane address arithmetic in the strided stages: buffer addressing with scalar offsets
     body = ks[_find(ks, "k_fft_interp_extend_fxILi8E")[0]][0]
     assert "buffer_store_dword" in body and "v_addc_co_u32" not in body
+
+
+def test_merkle_kernel_has_no_constant_moves_in_front_of_its_compressions(device_asm):
+    """k_merkle_fused<1>: the initial hash state enters the first half round as literal operands (blake2s.h b2_half_first)
+    and the zero message words are set once per kernel - at most ~25 v_mov per compression site remain (round 3: 46,
+    16 of them state constants and 16 zeroed message words in front of every leaf)."""
+    ks = _kernels(device_asm)
+    name, = _find(ks, "k_merkle_fusedILi1E")
+    body = ks[name][0]
+    movs = len(re.findall(r"^\s*v_mov_b32", body, re.M))
+    sites = len(re.findall(r"^\s*v_alignbit_b32", body, re.M)) / 320.0      # 320 rotations per compression
+    assert sites >= 4 and movs / sites <= 26, (movs, sites)
+    assert re.search(r"v_add_u32 v\d+, 0x[0-9a-f]+, v\d+\n\s*v_add_u32 v\d+, 0x[0-9a-f]+, v\d+", body) or "0x510e527f" in body.lower()
