@@ -115,11 +115,14 @@ template <int R>
 constexpr int fx_tw_at(int r) { return (1 << R) - (1 << (R - r)); }  // first entry of layer r in a stage's twiddle array
 
 // R butterfly layers on the 2^R points a lane holds; t2 = the stage's 2^R - 1 doubled twiddles (layer r: 2^(R-1-r) of them)
-template <int R, bool INV>
+// SKIP_TOP (forward only): the stage's top layer is the identity (its inputs' upper half was zero and has been filled with
+// a copy of the lower half)
+template <int R, bool INV, bool SKIP_TOP = false>
 LMN_D void fx_butterflies(uint32_t (&v)[1 << R], const uint32_t (&t2)[(1 << R) - 1]) {
   constexpr int NB = 1 << (R - 1);
+  static_assert(!(SKIP_TOP && INV), "only the forward transform is zero-extended");
 #pragma unroll
-  for (int rr = 0; rr < R; ++rr) {
+  for (int rr = SKIP_TOP ? 1 : 0; rr < R; ++rr) {
     const int r = INV ? rr : R - 1 - rr;
     uint32_t w[NB], a[NB], b[NB], x[NB], u[NB], u2[NB], d[NB], d2[NB];
 #pragma unroll
@@ -223,7 +226,10 @@ struct FxShape {
 // otherwise from sm_in; TG: results go to global memory (tdst) - scaled by 2^scale_log when INV - and, with KEEP, also
 // into the LDS tile `keep`; otherwise to sm_out.  tsrc / tdst point at the tile's first word; H = tile row of the
 // twiddle index (block offset included).
-template <int R, bool INV, int P, class S, bool FG, bool TG, bool KEEP>
+// ZX (forward, the tile's top stage, from global memory): the source holds only the lower half of the rows - the
+// coefficients of a polynomial of half the domain's size (PolyOps::evaluate onto the blown-up domain): the upper half
+// reads as zero, the top layer's butterflies are copies.
+template <int R, bool INV, int P, class S, bool FG, bool TG, bool KEEP, bool ZX = false>
 LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, const uint32_t* tsrc,
                     int lo, uint32_t H, const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep) {
   constexpr int TB = S::TB, CB = S::CB, RBITS = S::RBITS;
@@ -248,6 +254,14 @@ LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, con
     if constexpr (FG) {
       if constexpr (LO0 && P == 0 && R >= 2) {
         fx_load_run<(1 << R)>(tsrc + e0, v);
+      } else if constexpr (ZX) {
+        static_assert(!INV && P + R == TB, "zero extension: forward transform, top stage");
+        const GTile gt = gtile(tsrc);
+#pragma unroll
+        for (int j = 0; j < (1 << (R - 1)); ++j) {
+          v[j] = gtile_load(gt, off0, (uint32_t)j << gshift);
+          v[j + (1 << (R - 1))] = v[j];
+        }
       } else {
         const GTile gt = gtile(tsrc);
 #pragma unroll
@@ -258,7 +272,7 @@ LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, con
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) v[j] = sm_in[pb + fx_pad((uint32_t)j << P)];
     }
-    fx_butterflies<R, INV>(v, t2);
+    fx_butterflies<R, INV, ZX>(v, t2);
     if constexpr (TG) {
       if constexpr (INV) {
         if (scale_log != 0u) {
@@ -294,16 +308,17 @@ LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, con
 
 // The stages of one tile in execution order (inverse: ascending layers; forward: descending), a barrier after each.
 // FG0: the first stage reads global memory (else sm_first); TGL: the last stage writes global memory.
-template <class S, bool INV, int STEP, bool FG0, bool TGL, bool KEEPL>
+template <class S, bool INV, int STEP, bool FG0, bool TGL, bool KEEPL, bool ZX0 = false>
 LMN_D void fx_steps(const uint32_t* sm_first, uint32_t* sm, uint32_t* tdst, const uint32_t* tsrc, int lo, uint32_t H,
                     const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep) {
   constexpr int k = INV ? STEP : S::NST - 1 - STEP;
   constexpr bool fg = FG0 && STEP == 0;
   constexpr bool tg = TGL && STEP == S::NST - 1;
-  fx_stage<S::R(k), INV, S::CB + S::F(k), S, fg, tg, (tg && KEEPL)>(STEP == 0 ? sm_first : sm, sm, tdst, tsrc, lo, H, twd,
-                                                                      scale_log, keep);
+  fx_stage<S::R(k), INV, S::CB + S::F(k), S, fg, tg, (tg && KEEPL), (ZX0 && STEP == 0)>(STEP == 0 ? sm_first : sm, sm, tdst, tsrc,
+                                                                                         lo, H, twd, scale_log, keep);
   __syncthreads();
-  if constexpr (STEP + 1 < S::NST) fx_steps<S, INV, STEP + 1, FG0, TGL, KEEPL>(sm_first, sm, tdst, tsrc, lo, H, twd, scale_log, keep);
+  if constexpr (STEP + 1 < S::NST)
+    fx_steps<S, INV, STEP + 1, FG0, TGL, KEEPL, ZX0>(sm_first, sm, tdst, tsrc, lo, H, twd, scale_log, keep);
 }
 
 struct TwD {   // kernel argument: the doubled tables only
@@ -315,7 +330,7 @@ static TwD doubled(const TwPtrs& tw) {
   return t;
 }
 
-template <bool INV, int RBITS, int CB, bool LO0>
+template <bool INV, int RBITS, int CB, bool LO0, bool ZX = false>
 LMN_KERNEL LMN_BOUNDS((FxShape<RBITS, CB, LO0>::NT))
 k_fft_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int lo_arg, TwD tw, uint32_t scale_log,
          int ncols, int cpb, uint32_t h_off, int xcd_swizzle) {
@@ -334,7 +349,7 @@ k_fft_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_
     if (c >= ncols) break;
     uint32_t* col = data + (uint64_t)c * col_stride + base;
     const uint32_t* scol = src + (uint64_t)c * src_stride + base;
-    fx_steps<S, INV, 0, true, true, false>(sm, sm, col, scol, lo, H, tw.l, scale_log, nullptr);
+    fx_steps<S, INV, 0, true, true, false, ZX>(sm, sm, col, scol, lo, H, tw.l, scale_log, nullptr);
   }
 }
 
@@ -360,29 +375,45 @@ k_fft_interp_extend_fx(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, u
     fx_steps<S, false, 0, false, true, false>(A, B, lcol + h * n_words, nullptr, LO, h, tw.l, 0u, nullptr);
 }
 
-template <bool INV, int RBITS, int CB, bool LO0>
+template <bool INV, int RBITS, int CB, bool LO0, bool ZX = false>
 static void launch_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int lo, int log_n,
                       const TwPtrs& tw, uint32_t scale_log, int ncols, int cpb, uint32_t h_off, int xcd, lmn_stream_t s) {
   using S = FxShape<RBITS, CB, LO0>;
   const unsigned tiles = 1u << (log_n - S::TB);
   const size_t smem = (size_t)4 * S::LDS_WORDS;
 #if !defined(LMN_EMU) && !defined(LMN_BATCH)
-  if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_fx<INV, RBITS, CB, LO0>, 160 * 1024);
+  if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_fx<INV, RBITS, CB, LO0, ZX>, 160 * 1024);
 #endif
-  LMN_LAUNCH((k_fft_fx<INV, RBITS, CB, LO0>), dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(S::NT), smem, s, data,
+  LMN_LAUNCH((k_fft_fx<INV, RBITS, CB, LO0, ZX>), dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(S::NT), smem, s, data,
              col_stride, src, src_stride, lo, doubled(tw), scale_log, ncols, cpb, h_off, xcd);
 }
 
 template <bool INV>
 static bool dispatch_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int lo, int rbits, int cb,
                         int log_n, const TwPtrs& tw, uint32_t scale_log, int ncols, int cpb, uint32_t h_off, int xcd,
-                        lmn_stream_t s) {
-#define LMN_FX_CASE(RB, CBV, L0V)                                                                                     \
-  launch_fx<INV, RB, CBV, L0V>(data, col_stride, src, src_stride, lo, log_n, tw, scale_log, ncols, cpb, h_off, xcd, s); \
+                        bool zext, lmn_stream_t s) {
+#define LMN_FX_CASE(RB, CBV, L0V)                                                                                            \
+  if constexpr (!INV && !L0V) {                                                                                              \
+    if (zext) {                                                                                                              \
+      launch_fx<INV, RB, CBV, L0V, true>(data, col_stride, src, src_stride, lo, log_n, tw, scale_log, ncols, cpb, h_off, xcd, \
+                                         s);                                                                                 \
+      return true;                                                                                                           \
+    }                                                                                                                        \
+  }                                                                                                                          \
+  if (zext) return false;                                                                                                    \
+  launch_fx<INV, RB, CBV, L0V>(data, col_stride, src, src_stride, lo, log_n, tw, scale_log, ncols, cpb, h_off, xcd, s);      \
   return true
   if (lo == 0 && cb == 0) {
     if (rbits == 12) { LMN_FX_CASE(12, 0, true); }
     return false;
+  }
+  if (cb == 5 && lo >= 5) {
+    switch (rbits) {
+      case 5: LMN_FX_CASE(5, 5, false);
+      case 6: LMN_FX_CASE(6, 5, false);
+      case 7: LMN_FX_CASE(7, 5, false);
+      default: return false;
+    }
   }
   if (cb == 4 && lo >= 4) {
     switch (rbits) {
@@ -400,13 +431,14 @@ static bool dispatch_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src
 
 bool launch_fft_fixed_pass(bool inverse, uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int lo,
                            int rbits, int cb, int log_n, const TwPtrs& tw, uint32_t scale_log, int ncols, int cpb,
-                           uint32_t h_off, int xcd_swizzle, lmn_stream_t s) {
+                           uint32_t h_off, int xcd_swizzle, bool zero_extended_top, lmn_stream_t s) {
   static const bool off = getenv("LMN_NO_FFT_FIXED") != nullptr;
   if (off || !tw.d[0]) return false;
+  if (zero_extended_top && (inverse || lo + rbits != log_n)) return false;
   return inverse ? dispatch_fx<true>(data, col_stride, src, src_stride, lo, rbits, cb, log_n, tw, scale_log, ncols, cpb, h_off,
-                                     xcd_swizzle, s)
+                                     xcd_swizzle, false, s)
                  : dispatch_fx<false>(data, col_stride, src, src_stride, lo, rbits, cb, log_n, tw, scale_log, ncols, cpb, h_off,
-                                      xcd_swizzle, s);
+                                      xcd_swizzle, zero_extended_top, s);
 }
 
 template <int RBITS>

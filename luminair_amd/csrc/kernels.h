@@ -22,6 +22,10 @@ struct PadRow {
 };
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
                           const PadRow& pad, uint32_t* bad_flag /* device word, set when a value >= P */, lmn_stream_t s);
+// only rows [blk_row0, blk_row0 + blk_rows) of the padded table (blk_row0 a multiple of 64); columns out_stride apart
+void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
+                               uint64_t out_stride, uint64_t blk_row0, uint64_t blk_rows, const PadRow& pad, uint32_t* bad_flag,
+                               lmn_stream_t s);
 
 // ---- a4: circle FFT passes.  data = ncols columns of 2^log_n words at stride col_stride.
 // dst may equal src (in place).  launch_fft zero-extends src (2^log_src words) to 2^log_n (LDE).
@@ -47,6 +51,9 @@ struct PackSel {
 };
 void launch_pack_blocks(const uint32_t* src, uint64_t src_stride, uint32_t* dst, uint32_t block_rows, int ncols, int nsel,
                         int world, const PackSel& sel, lmn_stream_t s);
+// the inverse with one block per rank: cols[c * col_stride + r * block_rows + i] = packed[(r * ncols + c) * block_rows + i]
+void launch_unpack_blocks(const uint32_t* packed, uint32_t* cols, uint64_t col_stride, uint32_t block_rows, int ncols, int world,
+                          lmn_stream_t s);
 // single-layer reference kernels (debug / self-test only)
 void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,
                        lmn_stream_t s);

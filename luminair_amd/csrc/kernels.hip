@@ -63,11 +63,14 @@ LMN_D QM31 load_secure_col(const uint32_t* __restrict__ base, uint64_t stride, u
 // a3  AoS -> SoA transpose with padding rows (is_last_idx = 1, everything else 0)
 // =============================================================================================
 constexpr int TR_ROWS = 64;
+// Rows [blk_row0, blk_row0 + blk_rows) of the padded table are produced (the whole table, or one rank's row block of a
+// sharded proof); row r of column c lands at cols[c * out_stride + (r - blk_row0)].
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
-                           uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic) {
+                           uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic,
+                           uint64_t out_stride, uint64_t blk_row0) {
   LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
   const int stride = ncols + 1;
-  const uint64_t row0 = (uint64_t)blockIdx.x * TR_ROWS;
+  const uint64_t row0 = blk_row0 + (uint64_t)blockIdx.x * TR_ROWS;
   const int total = TR_ROWS * ncols;
   for (int k = threadIdx.x; k < total; k += blockDim.x) {
     // k / ncols by the precomputed reciprocal (exact for k < 2^16): a runtime integer division is ~30 VALU ops
@@ -84,18 +87,26 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
   __syncthreads();
   for (int k = threadIdx.x; k < total; k += blockDim.x) {
     int c = k / TR_ROWS, r = k - c * TR_ROWS;
-    if (row0 + r < size) cols[(uint64_t)c * size + row0 + r] = tile[r * stride + c];
+    if (row0 + r < size) cols[(uint64_t)c * out_stride + (row0 - blk_row0) + r] = tile[r * stride + c];
   }
 }
 
-void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
-                          const PadRow& pad, uint32_t* bad_flag, lmn_stream_t s) {
+void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
+                               uint64_t out_stride, uint64_t blk_row0, uint64_t blk_rows, const PadRow& pad, uint32_t* bad_flag,
+                               lmn_stream_t s) {
   uint64_t size = 1ull << log_size;
-  unsigned grid = cdiv(size, TR_ROWS);
+  if (blk_row0 % TR_ROWS || blk_row0 + blk_rows > size) throw LmnError(-100, "transpose: bad row block");
+  unsigned grid = cdiv(blk_rows, TR_ROWS);
   size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
   if (ncols > 32 || ncols < 1) throw LmnError(-100, "transpose: bad column count");
   const uint32_t magic = ncols == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)ncols - 1) / (uint64_t)ncols);  // ceil(2^32 / ncols)
-  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, size, cols, pad, bad_flag, magic);
+  // rows beyond the block are cut off by treating its end as the table's size
+  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, blk_row0 + blk_rows, cols, pad, bad_flag, magic,
+             out_stride, blk_row0);
+}
+void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
+                          const PadRow& pad, uint32_t* bad_flag, lmn_stream_t s) {
+  launch_transpose_pad_rows(rows, n_rows, ncols, log_size, cols, 1ull << log_size, 0, 1ull << log_size, pad, bad_flag, s);
 }
 
 // =============================================================================================
@@ -769,7 +780,10 @@ static int plan_passes(int log_n, FftPass* out) {
     int take = (rem + npass - 1) / npass;
     if (split == 1 && npass > 1) take = FFT_HIGH_BITS;
     if (split == 2 && npass > 1) take = rem - (npass - 1) * FFT_HIGH_BITS;
-    out[n++] = {lo, lo + take, FFT_HIGH_CB};
+    // three-pass sizes (2^23 points and more) have strided passes of 5 - 7 layers: 32-word runs (whole 128-byte lines)
+    // keep their tiles at 4 - 16 KiB; the single strided pass of the smaller sizes keeps 16-word runs (up to 2^10 rows)
+    static const int cb3 = getenv("LMN_FFT_CB3") ? atoi(getenv("LMN_FFT_CB3")) : 5;
+    out[n++] = {lo, lo + take, take == 5 ? 5 : (npass > 1 && take <= 7 ? cb3 : FFT_HIGH_CB)};
     lo += take;
   }
   return n;
@@ -817,10 +831,12 @@ static void launch_staged_pass(uint32_t* data, uint64_t col_stride, const uint32
   if (env_cpb > 0) cpb = env_cpb;
   if (cpb > ncols) cpb = ncols;
   // the shapes of the prover's committed columns have compile-time-specialised kernels (fft_fixed.hip)
-  if (plen >= (1ull << log_n)) {
+  const bool full = plen >= (1ull << log_n);
+  const bool half_top = !INV && plen == (1ull << (log_n - 1)) && p.hi == log_n && p.lo > 0;   // LDE by one bit, top pass
+  if (full || half_top) {
     const uint32_t scale_log = scale == 1u ? 0u : (uint32_t)__builtin_ctz(scale);
     if (launch_fft_fixed_pass(INV, data, col_stride, psrc, pstride, p.lo, rbits, p.cb, log_n, tw, scale_log, ncols, cpb,
-                              block_index << (log_n - p.hi), pl.xcd_swizzle, s))
+                              block_index << (log_n - p.hi), pl.xcd_swizzle, !full, s))
       return;
   }
   unsigned gy = (unsigned)((ncols + cpb - 1) / cpb);
@@ -976,19 +992,31 @@ LMN_KERNEL k_fft_layer_simple(uint32_t* __restrict__ data, uint64_t col_stride, 
   }
 }
 
-LMN_KERNEL k_pack_blocks(const uint32_t* __restrict__ src, uint64_t src_stride, uint32_t* __restrict__ dst, uint32_t block_rows,
-                         int ncols, int nsel, PackSel sel) {
+LMN_KERNEL k_pack_blocks(uint32_t* __restrict__ cols, uint64_t col_stride, uint32_t* __restrict__ packed, uint32_t block_rows,
+                         int ncols, int nsel, PackSel sel, int unpack) {
   const uint32_t h = blockIdx.y % (uint32_t)nsel, c = (blockIdx.y / (uint32_t)nsel) % (uint32_t)ncols;
   const uint32_t s = blockIdx.y / (uint32_t)(nsel * ncols);
-  const uint32_t* sp = src + (uint64_t)c * src_stride + (uint64_t)sel.blk[s][h] * block_rows;
-  uint32_t* dp = dst + (((uint64_t)s * ncols + c) * nsel + h) * block_rows;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < block_rows; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+  uint32_t* cp = cols + (uint64_t)c * col_stride + (uint64_t)sel.blk[s][h] * block_rows;
+  uint32_t* pp = packed + (((uint64_t)s * ncols + c) * nsel + h) * block_rows;
+  if (unpack) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < block_rows; i += gridDim.x * blockDim.x) cp[i] = pp[i];
+  } else {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < block_rows; i += gridDim.x * blockDim.x) pp[i] = cp[i];
+  }
 }
 void launch_pack_blocks(const uint32_t* src, uint64_t src_stride, uint32_t* dst, uint32_t block_rows, int ncols, int nsel,
                         int world, const PackSel& sel, lmn_stream_t s) {
   if (ncols <= 0) return;
   LMN_LAUNCH(k_pack_blocks, dim3(std::min<unsigned>(cdiv(block_rows, TPB), 64u), (unsigned)(world * ncols * nsel)), dim3(TPB),
-             0, s, src, src_stride, dst, block_rows, ncols, nsel, sel);
+             0, s, const_cast<uint32_t*>(src), src_stride, dst, block_rows, ncols, nsel, sel, 0);
+}
+void launch_unpack_blocks(const uint32_t* packed, uint32_t* cols, uint64_t col_stride, uint32_t block_rows, int ncols, int world,
+                          lmn_stream_t s) {
+  if (ncols <= 0) return;
+  PackSel sel{};
+  for (int r = 0; r < world; ++r) sel.blk[r][0] = (uint32_t)r;
+  LMN_LAUNCH(k_pack_blocks, dim3(std::min<unsigned>(cdiv(block_rows, TPB), 64u), (unsigned)(world * ncols)), dim3(TPB), 0, s,
+             cols, col_stride, const_cast<uint32_t*>(packed), block_rows, ncols, 1, sel, 1);
 }
 
 void launch_fft_simple(uint32_t* data, uint64_t col_stride, int ncols, int log_n, const TwPtrs& tw, bool inverse,

@@ -718,8 +718,22 @@ bool Context::shard_all_to_all() const {
   return shard_.active && shard_.world > 1 && shard_.coll.all_to_all != nullptr && !off;
 }
 
+// column-parallel interpolation pays where the transforms are throughput-bound; small columns stay replicated (two more
+// collectives would cost more than the few microseconds of butterflies).  LMN_SHARD_A2A_MIN_LOG lowers the bar (tests).
+bool Context::shard_a2a_columns(int log_size) const {
+  static const int min_log = getenv("LMN_SHARD_A2A_MIN_LOG") ? atoi(getenv("LMN_SHARD_A2A_MIN_LOG")) : 13;
+  return shard_all_to_all() && cfg.log_blowup == 1 && log_size >= min_log && log_size >= 4;
+}
+// Row-parallel front end: every rank transposes and computes the logup fractions of its row block only; the blocks go to
+// the columns' owners by an all-to-all (the reverse of stage B).  Three more collectives per component: worth it for the
+// big tables (BASELINE config 5: 2^23 rows), not at 2^20.  LMN_SHARD_ROWS_MIN_LOG lowers the bar (tests).
+bool Context::shard_rows_front(int log_size) const {
+  static const int min_log = getenv("LMN_SHARD_ROWS_MIN_LOG") ? atoi(getenv("LMN_SHARD_ROWS_MIN_LOG")) : 22;
+  return shard_a2a_columns(log_size) && log_size >= min_log && ((1ull << log_size) >> shard_.g) >= 64;
+}
+
 Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size,
-                                                   int halo_first) {
+                                                   int halo_first, bool evals_row_blocks) {
   const uint64_t n = 1ull << log_size;
   CommitOut out;
   StageTimer t(this, g_log(this), stream_, C_FFT);
@@ -737,14 +751,30 @@ Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint3
   }
   const int g = shard_.g;
   const uint64_t L = 2 * n, Lb = L >> g;
-  // column-parallel interpolation pays where the transforms are throughput-bound; small columns stay replicated (two more
-  // collectives would cost more than the few microseconds of butterflies).  LMN_SHARD_A2A_MIN_LOG lowers the bar (tests).
-  static const int a2a_min_log = getenv("LMN_SHARD_A2A_MIN_LOG") ? atoi(getenv("LMN_SHARD_A2A_MIN_LOG")) : 13;
-  if (shard_all_to_all() && cfg.log_blowup == 1 && log_size >= a2a_min_log && log_size >= 4) {
-    // ---- stage A: this rank's share of the columns, interpolated and extended over ALL rows
+  if (evals_row_blocks && !shard_a2a_columns(log_size)) throw LmnError(LMN_ERR_INTERNAL, "row-block evaluations without stage A");
+  if (shard_a2a_columns(log_size)) {
     const uint32_t G = shard_.world, me = shard_.rank;
     for (uint32_t r = 0; r <= G; ++r) out.first[r] = (int)((uint64_t)r * ncols / G);
     const int c0 = out.first[me], nm = out.first[me + 1] - c0;
+    size_t so[8], sb[8], ro[8], rb[8];
+    if (evals_row_blocks) {
+      // ---- the row blocks of this rank's columns come in from every rank (block p of column c from rank p)
+      const uint64_t nb = n >> g;
+      uint32_t* blocks = arena_.alloc_words((size_t)std::max(nm, 1) * n);
+      for (uint32_t p = 0; p < G; ++p) {
+        so[p] = (size_t)out.first[p] * nb * 4;
+        sb[p] = (size_t)(out.first[p + 1] - out.first[p]) * nb * 4;
+        ro[p] = (size_t)p * nm * nb * 4;
+        rb[p] = (size_t)nm * nb * 4;
+      }
+      if (shard_.coll.all_to_all(shard_.coll.user, evals, so, sb, blocks, ro, rb, (void*)(uintptr_t)stream_) != 0)
+        throw LmnError(LMN_ERR_INTERNAL, "shard all_to_all failed");
+      timings.shard_a2a_bytes += (uint64_t)nm * (n - nb) * 4;
+      timings.shard_a2a_calls++;
+      launch_unpack_blocks(blocks, coeffs + (uint64_t)c0 * n, n, (uint32_t)nb, nm, (int)G, stream_);
+      evals = coeffs;   // stage A continues in place
+    }
+    // ---- stage A: this rank's share of the columns, interpolated and extended over ALL rows
     uint32_t* full = arena_.alloc_words((size_t)std::max(nm, 1) * L);
     if (nm > 0) {
       timings.fft_bytes += (uint64_t)nm * 20ull * n;
@@ -763,7 +793,6 @@ Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint3
     PackSel sel{};
     for (uint32_t s = 0; s < G; ++s) sel.blk[s][0] = s;
     launch_pack_blocks(full, L, sendbuf, (uint32_t)Lb, nm, 1, (int)G, sel, stream_);
-    size_t so[8], sb[8], ro[8], rb[8];
     for (uint32_t p = 0; p < G; ++p) {
       so[p] = (size_t)p * nm * Lb * 4;
       sb[p] = (size_t)nm * Lb * 4;
@@ -1281,6 +1310,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
     if (shard_.active) words += (4ull << (ls + 1)) + 4096;     // halo rows of the last logup column group
+    if (shard_rows_front(ls))                                  // received row blocks, gathered logup sums, scan output, coefficients
+      words += (uint64_t)(sp->n_cols + 8 * sp->n_rel + 16) << ls;
     if (shard_all_to_all()) {                                  // own columns over all rows, packed copy, halo exchange
       const uint64_t G = shard_.world;
       words += 2 * (((uint64_t)sp->n_cols / G + 1) + ((uint64_t)(4 * sp->n_rel) / G + 1)) * (2ull << ls) + 6 * (2ull << ls);
@@ -1388,23 +1419,31 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   DevTree tree1;
   uint32_t* d_bad = bad_flag_;  // persistent device word (zero between proofs), set by the transposes
   const uint32_t* h_bad = nullptr;
+  bool any_rows_front = false;
   {
     StageTimer st(this, log, stream_, C_TRANSPOSE);
     for (size_t t = 0; t < infos.size(); ++t) {
       auto& ti = infos[t];
+      uint64_t n = 1ull << ti.log_size;
+      const bool rows_front = shard_rows_front(ti.log_size);
+      // row-parallel front end of a sharded proof: only this rank's block of the (padded) rows is transposed - and, for
+      // host tables, uploaded
+      const uint64_t nb = rows_front ? n >> shard_.g : n, blk0 = rows_front ? (uint64_t)shard_.rank * nb : 0;
+      const uint64_t up0 = std::min<uint64_t>(blk0, ti.n_rows), up1 = std::min<uint64_t>(blk0 + nb, ti.n_rows);
       const uint32_t* d_rows = ti.rows;
       if (!ti.on_device) {
-        uint32_t* stg = arena_.alloc_words(ti.n_rows * ti.spec->n_cols);
-        lmn_h2d(stg, ti.rows, ti.n_rows * ti.spec->n_cols * 4, stream_);
-        d_rows = stg;
+        uint32_t* stg = arena_.alloc_words(std::max<uint64_t>(up1 - up0, 1) * ti.spec->n_cols);
+        if (up1 > up0) lmn_h2d(stg, ti.rows + up0 * ti.spec->n_cols, (up1 - up0) * ti.spec->n_cols * 4, stream_);
+        d_rows = stg - up0 * ti.spec->n_cols;   // indexed by table row: only rows [up0, up1) are ever read
       }
-      uint64_t n = 1ull << ti.log_size;
-      uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * n);
+      uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * nb);
       PadRow pad{};
       if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
       for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
-      launch_transpose_pad(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, pad, d_bad, stream_);
+      launch_transpose_pad_rows(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, nb, blk0, nb, pad, d_bad, stream_);
       inst[t].trace_evals = evals;
+      inst[t].rows_sharded = rows_front;
+      any_rows_front = any_rows_front || rows_front;
       proof.claim[ti.spec->kind] = ti.log_size;
     }
   }
@@ -1415,7 +1454,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       uint64_t n = 1ull << ci.log_size;
       int nc = ci.spec->n_cols;
       uint32_t* coeffs = arena_.alloc_words((size_t)nc * n);
-      const CommitOut co = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size);
+      const CommitOut co = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size, -1, ci.rows_sharded);
       ci.main_start = off;
       off += nc;
       for (int c = 0; c < nc; ++c)
@@ -1425,9 +1464,20 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
     lde_and_merkle(tree1);
-    h_bad = (const uint32_t*)stage_download(d_bad, 4);
+    uint32_t n_flags = 1;
+    if (any_rows_front) {   // every rank has only looked at its own rows: the ranks must agree on the verdict
+      n_flags = shard_.world;
+      uint32_t* flags = arena_.alloc_words(n_flags);
+      lmn_d2d(flags + shard_.rank, d_bad, 4, stream_);
+      gather_columns(flags, 0, 1, 1);
+      h_bad = (const uint32_t*)stage_download(flags, 4 * n_flags);
+    } else {
+      h_bad = (const uint32_t*)stage_download(d_bad, 4);
+    }
     lmn_sync(stream_);
-    if (*h_bad) {
+    uint32_t bad_any = 0;
+    for (uint32_t k = 0; k < n_flags; ++k) bad_any |= h_bad[k];
+    if (bad_any) {
       const uint32_t zero = 0u;
       lmn_h2d(d_bad, &zero, 4, stream_);
       lmn_sync(stream_);
@@ -1448,6 +1498,58 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       const ComponentSpec* sp = ci.spec;
       uint64_t n = 1ull << ci.log_size;
       int nic = 4 * sp->n_rel;
+      if (ci.rows_sharded) {
+        // ---- row-parallel logup: fractions and running sums of this rank's row block; the claimed sum and the
+        // coset-order prefix sum of the last column need all rows - 16 bytes per rank and 16 bytes per row are gathered
+        const uint32_t G = shard_.world, me = shard_.rank;
+        const uint64_t nb = n >> shard_.g, row0 = (uint64_t)me * nb;
+        uint32_t* iblk = arena_.alloc_words((size_t)nic * nb);
+        QM31* last_full = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
+        LogupArgs a{};
+        a.k = sp->n_rel;
+        for (int j = 0; j < sp->n_rel; ++j) {
+          const int es = sp->rel_elems[j];
+          if (!elems.drawn[es])
+            throw LmnError(LMN_ERR_INVALID_ARGUMENT, "component needs relation elements this protocol variant does not draw");
+          auto column = [&](int idx) -> const uint32_t* {
+            return sp->rel_pre[j] ? pre_evals[ci.pre_idx[idx]] + row0 : ci.trace_evals + (uint64_t)idx * nb;
+          };
+          a.val[j] = column(sp->rel_val[j]);
+          a.id[j] = sp->rel_id[j] >= 0 ? column(sp->rel_id[j]) : nullptr;
+          a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * nb;
+          a.neg[j] = sp->rel_neg[j];
+          a.z[j] = elems.z[es];
+          a.alpha[j] = elems.alpha[es];
+        }
+        a.inter = iblk;
+        a.last_tmp = last_full + row0;
+        const int nbk = logup_num_blocks((uint32_t)nb);
+        a.partials = arena_.alloc_words((size_t)nbk * 4);
+        a.n = (uint32_t)nb;
+        launch_logup_fracs(a, stream_);
+        QM31* local = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
+        launch_logup_reduce(a.partials, nbk, 1u, local, stream_);             // local[0] = sum over this rank's rows
+        uint32_t* slots = arena_.alloc_words(4 * (size_t)G);
+        lmn_d2d(slots + 4 * me, local, sizeof(QM31), stream_);
+        gather_columns(slots, 0, 1, 4);
+        QM31* d_cs = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
+        launch_logup_reduce(slots, (int)G, m_inv((uint32_t)(n % P31)), d_cs, stream_);   // claimed sum, shift
+        gather_columns((uint32_t*)last_full, 0, 1, nb * 4);
+        uint32_t* scan_out = arena_.alloc_words(4 * n);
+        QM31* bsums = (QM31*)arena_.alloc_bytes((size_t)logup_scan_num_blocks(ci.log_size) * sizeof(QM31));
+        launch_logup_scan(last_full, d_cs, ci.log_size, scan_out, bsums, stream_);
+        for (int k = 0; k < 4; ++k)
+          lmn_d2d(iblk + (uint64_t)(nic - 4 + k) * nb, scan_out + (uint64_t)k * n + row0, nb * 4, stream_);
+        ci.d_claimed_shift = d_cs;
+        ci.inter_start = off;
+        off += nic;
+        uint32_t* icoeffs = arena_.alloc_words((size_t)nic * n);
+        const CommitOut co = interpolate_for_commit(icoeffs, iblk, nic, ci.log_size, nic - 4, true);
+        ci.halo = co.halo;
+        for (int c = 0; c < nic; ++c)
+          tree2.cols.push_back({ci.log_size, icoeffs + (uint64_t)c * n, co.lde + (uint64_t)c * co.stride, co.sharded, co.owner_of(c)});
+        continue;
+      }
       uint32_t* ievals = arena_.alloc_words((size_t)nic * n);
       LogupArgs a{};
       a.k = sp->n_rel;

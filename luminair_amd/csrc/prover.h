@@ -49,6 +49,7 @@ struct Instance {
   uint32_t* halo = nullptr;               // sharded proofs with all_to_all: neighbour blocks of the last logup group
   const QM31* d_claimed_shift = nullptr;  // device [claimed, shift] (prover only)
   uint32_t* trace_evals = nullptr;        // device, n_cols x 2^log_size (prover only)
+  bool rows_sharded = false;              // sharded proofs: trace_evals holds this rank's block of 2^(log_size - g) rows only
   int pre_idx[2] = {-1, -1};    // tree-0 column indices of the component's preprocessed columns
 };
 // sum_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values
@@ -224,8 +225,13 @@ class Context {
       return r;
     }
   };
-  CommitOut interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size, int halo_first = -1);
+  // evals_row_blocks: `evals` holds this rank's row block of every column (row-parallel transposes / logup); the blocks
+  // travel to the columns' owners through one more all-to-all before stage A
+  CommitOut interpolate_for_commit(uint32_t* coeffs, const uint32_t* evals, int ncols, int log_size, int halo_first = -1,
+                                   bool evals_row_blocks = false);
   bool shard_all_to_all() const;
+  bool shard_a2a_columns(int log_size) const;   // stage A / B for columns of this size
+  bool shard_rows_front(int log_size) const;    // row-parallel transposes and logup fractions for tables of this size
   // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
   void lde_and_merkle(DevTree& tree);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its

@@ -73,9 +73,12 @@ def _make_ctx(pinned, pcs=None):
     return backend.Context(0, cfg, lib)
 
 
-def _worker(rank, world, port, fri_min_log, a2a, q):
-    # a2a: SURVEY 8e stages A / B (column-parallel interpolation + all-to-all into row blocks) for every column size
+def _worker(rank, world, port, fri_min_log, a2a, q, rows=False):
+    # a2a: SURVEY 8e stages A / B (column-parallel interpolation + all-to-all into row blocks) for every column size;
+    # rows: the row-parallel front end as well (transposes and logup fractions of the own row block only, blocks sent to
+    # the columns' owners) for every table with at least 64 rows per rank
     os.environ["LMN_SHARD_A2A_MIN_LOG"] = "4"
+    os.environ["LMN_SHARD_ROWS_MIN_LOG"] = "4" if rows else "99"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from luminair_amd.sharded import shard_context
@@ -125,12 +128,13 @@ def single_rank_proofs():
     return _single()
 
 
-@pytest.mark.parametrize("world,fri_min_log,a2a", [(2, 4, True), (4, 5, True), (8, 0, True), (2, 5, False), (8, 4, False)])
-def test_sharded_prove_is_byte_identical(world, fri_min_log, a2a, single_rank_proofs):
+@pytest.mark.parametrize("world,fri_min_log,a2a,rows", [(2, 4, True, False), (4, 5, True, True), (8, 0, True, True),
+                                                        (2, 5, True, True), (2, 5, False, False), (8, 4, False, False)])
+def test_sharded_prove_is_byte_identical(world, fri_min_log, a2a, rows, single_rank_proofs):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fri_min_log, a2a, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fri_min_log, a2a, q, rows)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -201,6 +205,7 @@ def _gpu_prove_all(lib, shard=None):
 
 
 def _gpu_worker(rank, world, port, fri_min_log, lib_path, q, a2a=True):
+    os.environ["LMN_SHARD_ROWS_MIN_LOG"] = "13" if (world == 4 and a2a) else "99"   # one world with the row-parallel front end
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from luminair_amd import backend, synthetic as syn

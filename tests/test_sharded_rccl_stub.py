@@ -20,6 +20,7 @@ STUB = os.path.join(ROOT, "tests", "emu", "libstub_rccl.so")
 def _worker(rank, world, fri_min_log, id_q, out_q):
     os.environ["LMN_RCCL_LIB"] = STUB
     os.environ["LMN_SHARD_A2A_MIN_LOG"] = "4"
+    os.environ["LMN_SHARD_ROWS_MIN_LOG"] = "4" if world != 2 else "99"   # row-parallel front end at world 4 and 8
     sys.path.insert(0, ROOT)
     from luminair_amd import backend
     boot = tsp._make_ctx(False)
