@@ -85,6 +85,19 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.
 constexpr int MERKLE_MAX_SEG = 4;
+// Experiment builds only (-DLMN_ABLATE, tools/build_variants.sh): env LMN_ABLATE is a mask of kernel families whose
+// launches are skipped, to read a family's MARGINAL cost under concurrent load off the change in proofs/s (the proofs
+// are garbage; the prover's OODS self-check is off in such a build).  1 merkle_fused, 2 transforms, 4 FRI quotients,
+// 8 constraint quotients, 16 OODS evaluation, 32 logup.
+#ifdef LMN_ABLATE
+inline unsigned ablate_mask() {
+  static const unsigned m = getenv("LMN_ABLATE") ? (unsigned)atoi(getenv("LMN_ABLATE")) : 0u;
+  return m;
+}
+#define LMN_ABLATED(bit) (::lmn::ablate_mask() & (bit))
+#else
+#define LMN_ABLATED(bit) false
+#endif
 constexpr int MERKLE_MAX_SUB = 3;     // per-lane register subtree: 2^3 start nodes
 constexpr int MERKLE_MAX_FUSED = 11;  // levels above the start level covered by one launch
 struct MerkleSegs {

@@ -882,6 +882,7 @@ bool fft_interp_extend_supported(int log_n) {
 }
 int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
                          uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
+  if (LMN_ABLATED(2u)) return 3;
   if (!fft_interp_extend_supported(log_n)) throw LmnError(-100, "interp_extend: unsupported size");
   const FftPass low{0, FFT_LOW_BITS, 0};
   launch_staged_pass<true>(coeffs, coeff_stride, evals, evals_stride, 1ull << log_n, low, log_n, itw, 1u, ncols, s);
@@ -908,10 +909,12 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
 
 int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int ncols, int log_n,
                 const TwPtrs& itw, lmn_stream_t s) {
+  if (LMN_ABLATED(2u)) return 1;
   return run_fft<true>(dst, dst_stride, src, src_stride, log_n, ncols, log_n, itw, s);
 }
 int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
                int log_n, const TwPtrs& tw, lmn_stream_t s) {
+  if (LMN_ABLATED(2u)) return 1;
   return run_fft<false>(dst, dst_stride, src, src_stride, log_src, ncols, log_n, tw, s);
 }
 
@@ -1590,6 +1593,7 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold) {
+  if (LMN_ABLATED(1u)) return;
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
   if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
       size % ((uint32_t)TPB << sub) != 0)
@@ -1764,6 +1768,7 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
 }
 
 void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s) {
+  if (LMN_ABLATED(32u)) return;
   dim3 g(logup_num_blocks(a.n)), b(TPB);
   switch (a.k) {
     case 1: LMN_LAUNCH(k_logup_fracs<1>, g, b, 0, s, a); break;
@@ -2274,6 +2279,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
 }
 
 void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
+  if (LMN_ABLATED(8u)) return;
   if (a.eval_log != a.log_size + 1) throw LmnError(-100, "composition: eval domain must be log_size+1");
   if (a.n_rows == 0 || (uint64_t)a.row0 + a.n_rows > (1ull << a.eval_log) || a.stride < a.n_rows || !a.prev_last)
     throw LmnError(-100, "composition: bad row block");
@@ -2400,6 +2406,7 @@ void launch_eval_at_point(const EvalJob* jobs, int njobs, const QM31* lo_tab, co
                           int max_log, QM31* partial_out, int max_chunks, lmn_stream_t s, uint32_t shard_rank,
                           uint32_t shard_world) {
   (void)max_log;
+  if (LMN_ABLATED(16u)) return;
   LMN_LAUNCH(k_eval_at_point, dim3(max_chunks, njobs), dim3(TPB), 0, s, jobs, lo_tab, hi_tab, hi_stride, partial_out,
              max_chunks, shard_rank, shard_world);
 }
@@ -2472,9 +2479,14 @@ LMN_HD uint32_t domain_y(const uint32_t* tw_y, uint32_t s) {
 // NB = number of sample-point batches (compile-time: exact loops, no dummy products); every lane owns
 // QUOT_ROWS rows a quarter of the domain apart and inverts all their denominator norms with ONE field
 // inversion (Montgomery batching: 3 products per element instead of a 37-product exponentiation per row).
-constexpr int QUOT_ROWS = 4;
+#ifndef LMN_QUOT_ROWS1
+#define LMN_QUOT_ROWS1 4
+#endif
+template <int NB>
+constexpr int quot_rows() { return NB == 1 ? LMN_QUOT_ROWS1 : 4; }   // rows per lane (a single batch leaves registers for more)
 template <int NB>
 LMN_KERNEL k_quotients(QuotientArgs a) {
+  constexpr int QUOT_ROWS = quot_rows<NB>();
   // (column pointer, alpha^k * c) table staged once per block in LDS: the per-column loop then
   // reads wave-uniform LDS words instead of chasing pointers through global memory
   LMN_SHARED QuotEntry tab[QUOT_MAX_ENTRIES];
@@ -2555,14 +2567,16 @@ LMN_KERNEL k_quotients(QuotientArgs a) {
 }
 
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
+  if (LMN_ABLATED(4u)) return;
   if (a.nbatch < 1 || a.nbatch > QUOT_MAX_BATCH) throw LmnError(-100, "quotients: bad batch count");
   if (a.batch_start[a.nbatch] > QUOT_MAX_ENTRIES) throw LmnError(-100, "quotients: too many column samples");
   if (a.log_size < 2 || a.log_rows < 2 || a.log_rows > a.log_size || (a.row0 & ((1u << a.log_rows) - 1u)) ||
       a.out_stride < (1ull << a.log_rows))
     throw LmnError(-100, "quotients: bad row block");
-  dim3 g(cdiv((1ull << a.log_rows) / QUOT_ROWS, TPB)), b(TPB);
+  if (a.nbatch == 1 && (1u << a.log_rows) < (unsigned)quot_rows<1>()) throw LmnError(-100, "quotients: row block too small");
+  dim3 g(cdiv((1ull << a.log_rows) / 4, TPB)), g1(cdiv((1ull << a.log_rows) / quot_rows<1>(), TPB)), b(TPB);
   switch (a.nbatch) {
-    case 1: LMN_LAUNCH(k_quotients<1>, g, b, 0, s, a); break;
+    case 1: LMN_LAUNCH(k_quotients<1>, g1, b, 0, s, a); break;
     case 2: LMN_LAUNCH(k_quotients<2>, g, b, 0, s, a); break;
     case 3: LMN_LAUNCH(k_quotients<3>, g, b, 0, s, a); break;
     default: LMN_LAUNCH(k_quotients<4>, g, b, 0, s, a); break;

@@ -1779,7 +1779,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   {
     QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
     QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha);
-    if (!q_eq(lhs, rhs)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
+    if (!q_eq(lhs, rhs) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
   }
 
   // ---- FRI quotients, one secure column per LDE size (descending)
@@ -2076,7 +2076,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     }
     uint32_t bound = 1u << cfg.log_last_layer;
     for (uint32_t j = bound; j < n; ++j)
-      if (!q_is_zero(coeffs[j])) throw LmnError(LMN_ERR_INTERNAL, "FRI: invalid last-layer degree");
+      if (!q_is_zero(coeffs[j]) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_INTERNAL, "FRI: invalid last-layer degree");
     coeffs.resize(bound);
     proof.last_layer_coeffs = coeffs;
     proof.last_layer_log_size = cfg.log_last_layer;

@@ -82,6 +82,17 @@ def test_emu_error_codes(emu_ctx):
     assert e.value.code == backend.ERR_INVALID_ARGUMENT
 
 
+def test_emu_table_size_limits_are_rejected_before_the_rows_are_read(emu_ctx):
+    """The largest table PcsConfig::default() leaves room for is 2^25 rows (composition LDE 2^27, tests/test_gpu_parity.py
+    proves one on the GPU); 2^25 + 1 .. 2^26 rows pad to 2^26 and are refused as too large, more than 2^26 rows as an
+    invalid table - both on the row COUNT, before any row is touched (the buffer here holds 16 rows)."""
+    rows = syn.config2_add_only(16, 3)[0][1]
+    for n_rows, text in (((1 << 25) + 1, "too large"), (1 << 26, "too large"), ((1 << 26) + 1, "2^26")):
+        with pytest.raises(backend.LuminairBackendError) as e:
+            emu_ctx.prove_tables([(0, rows, n_rows)])
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT and text in str(e.value), (n_rows, str(e.value))
+
+
 def test_emu_level2_ops(emu_ctx):
     from oracle import fft
     from oracle.field import P, QM31

@@ -655,6 +655,26 @@ def test_gpu_single_table_2_24_rows_equals_c_oracle_bytes(hip_lib_path, c_oracle
     assert len(got) == len(want) and _sha(got) == _sha(want)
 
 
+def test_gpu_maximum_table_size_2_25_rows(hip_lib_path):
+    """The largest table lmn_prove accepts with the default PcsConfig: one Add table of 2^25 rows (LDE 2^26 rows,
+    composition LDE and first FRI layer 2^27 rows, 2^27-leaf trees of 4 GiB per level, ~100 GB arena).  Too large for the
+    oracle on a test budget: checked by determinism and by the product verifier (itself oracle-checked on the smaller
+    sizes); one more row is refused (tests/test_emu_hostlogic.py checks the limits on the CPU)."""
+    from luminair_amd import backend
+    tabs = syn.config2_add_only(1 << 25, 11)
+    p = luminair_amd.Prover(0)
+    bufs = [(k, p.ctx.upload(r), len(r)) for k, r in tabs]
+    got = p.ctx.prove_tables(bufs)
+    assert p.ctx.prove_tables(bufs) == got
+    with pytest.raises(backend.LuminairBackendError) as e:
+        p.ctx.prove_tables([(k, b, n + 1) for k, b, n in bufs])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    for _, b, _ in bufs:
+        b.free()
+    p.ctx.close()
+    backend.default_library().verify(got, backend.VARIANT_KAT)
+
+
 def test_gpu_prove_submit_wait_from_one_thread(hip_lib_path):
     """Eight contexts kept busy by ONE host thread with lmn_prove_submit / lmn_prove_wait (what a single-threaded
     Rust caller of the reference's `prove` would do): every proof equals the synchronous one, and the single thread
