@@ -143,8 +143,20 @@ struct GatherEntry {
   uint32_t len;      // words
   uint32_t dst_off;  // word offset into out
 };
-void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, uint32_t* out,
-                   lmn_stream_t s);
+// A Merkle node that was never written (a fused launch leaves the levels its lanes keep in registers - 7/8 of a big
+// tree's hashes, of which a proof reads a few dozen - out of HBM): recomputed for the decommitment from the launch's
+// start level.  node = index at `depth` (0..2) levels above that start level; the 8 words go to out[dst_off..].
+struct MerkleRecompute {
+  const uint32_t* prev;  // start level of the launch that skipped the node (as given to launch_merkle_fused)
+  MerkleSegs sg;
+  int ncols;
+  uint32_t size;
+  uint32_t node;
+  int depth;
+  uint32_t dst_off;
+};
+void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, const MerkleRecompute* jobs,
+                   uint32_t n_jobs, uint32_t* out, lmn_stream_t s);
 
 // ---- trace generation for the elementwise primitives (the producer of the hot path's input)
 struct TraceNode {

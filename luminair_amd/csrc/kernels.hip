@@ -1425,7 +1425,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     cur_idx = node;
     if (j + 1 < per) merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, node + 64u, mn, fold);
     merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur);
-    store_hash(outs.p[0] + (uint64_t)node * 8, cur);
+    if (outs.p[0]) store_hash(outs.p[0] + (uint64_t)node * 8, cur);
   };
   for (uint32_t j = 0; j < per; j += 2) {
     leaf(j, mA, mB);
@@ -1450,7 +1450,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
       b2_compress_fresh(cur, m, 64u);
       jj >>= 1;
       ++lvl;
-      store_hash(outs.p[lvl] + (uint64_t)cur_idx * 8, cur);
+      if (outs.p[lvl]) store_hash(outs.p[lvl] + (uint64_t)cur_idx * 8, cur);
     }
     if (lvl < sub) {
 #pragma unroll
@@ -1600,6 +1600,9 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
     throw LmnError(-100, "merkle_fused: bad arguments");
   const dim3 g(cdiv(size >> sub, TPB)), b(TPB);
   const MerkleFold none{};
+  // a null p[l] (l < sub only: the levels a lane keeps in registers) is a level the caller does not want written
+  for (int l = sub; l <= nfused; ++l)
+    if (!outs.p[l]) throw LmnError(-100, "merkle_fused: only the per-lane levels may be left unwritten");
   if (fold) {
     if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
     LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
@@ -1698,18 +1701,43 @@ void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, i
 // gather
 // =============================================================================================
 LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,
-                    uint32_t* __restrict__ out) {
+                    const MerkleRecompute* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ out) {
   LMN_SERIAL_KERNEL();
   uint32_t e = blockIdx.x;
-  if (e >= n) return;
-  GatherEntry g = entries[e];
-  for (uint32_t k = threadIdx.x; k < g.len; k += blockDim.x) out[g.dst_off + k] = arena[g.src_off + k];
+  if (e < n) {
+    GatherEntry g = entries[e];
+    for (uint32_t k = threadIdx.x; k < g.len; k += blockDim.x) out[g.dst_off + k] = arena[g.src_off + k];
+    return;
+  }
+  e -= n;
+  if (e >= n_jobs) return;
+  // A tree node the fused launch kept in registers only: lane q of a quad hashes start node (node << depth) + q, the
+  // quad reduces the 2^depth hashes pairwise (every quad of the block does the same; block-uniform control flow).
+  const MerkleRecompute j = jobs[e];
+  const uint32_t q = threadIdx.x & 3u;
+  uint32_t h[8];
+  merkle_hash_start(j.prev, j.sg, j.ncols, j.size, (j.node << j.depth) + (q & ((1u << j.depth) - 1u)), h);
+  for (int s = 0; s < j.depth; ++s) {
+    const bool hi = ((q >> s) & 1u) != 0u;
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t other = lmn_shfl_xor(h[k], 1 << s);
+      m[k] = hi ? other : h[k];
+      m[8 + k] = hi ? h[k] : other;
+    }
+    b2_compress_fresh(h, m, 64u);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[j.dst_off + k] = h[k];
+  }
 }
 
-void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, uint32_t* out,
-                   lmn_stream_t s) {
-  if (n_entries == 0) return;
-  LMN_LAUNCH(k_gather, dim3(n_entries), dim3(64), 0, s, arena, entries, n_entries, out);
+void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, const MerkleRecompute* jobs,
+                   uint32_t n_jobs, uint32_t* out, lmn_stream_t s) {
+  if (n_entries + n_jobs == 0) return;
+  LMN_LAUNCH(k_gather, dim3(n_entries + n_jobs), dim3(64), 0, s, arena, entries, n_entries, jobs, n_jobs, out);
 }
 
 // =============================================================================================

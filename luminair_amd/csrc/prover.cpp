@@ -558,8 +558,12 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
 // columns) plus up to 8 following levels that have no columns of their own.
 void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                                   const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch,
-                                  QM31* alpha_out, uint32_t* root_copy, const MerkleFold* fold) {
+                                  QM31* alpha_out, uint32_t* root_copy, const MerkleFold* fold, std::vector<MerkleCut>* cuts) {
   bool chan_done = false;
+  auto layer = [&](int l) {   // storage of level l, allocated when the first launch writes it
+    if (!layers[l]) layers[l] = arena_.alloc_words((size_t)8 << l);
+    return layers[l];
+  };
   if (fold && (max_log <= 10 || per_level[max_log].size() != 4))
     throw LmnError(LMN_ERR_INTERNAL, "merkle: a folded leaf level needs a 4-column tree of more than 2^10 leaves");
   {
@@ -591,7 +595,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
       if (!seg_ok) {
         // rare scattered level: pointer-table kernel, one level per launch
         const uint32_t** dptrs = (const uint32_t**)stage_upload(lc.data(), lc.size() * sizeof(void*));
-        merkle_layer_timed(prev, dptrs, (int)lc.size(), 1u << level, layers[level]);
+        merkle_layer_timed(prev, dptrs, (int)lc.size(), 1u << level, layer(level));
         prev = layers[level];
         level -= 1;
         continue;
@@ -602,7 +606,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
       int nfused;
       if (level <= 10) {
         nfused = std::min(plain, 10);
-        for (int l = 0; l <= nfused; ++l) outs.p[l] = layers[level - l];
+        for (int l = 0; l <= nfused; ++l) outs.p[l] = layer(level - l);
         bool to_root = level - nfused == 0;
         launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, to_root ? ch : nullptr, alpha_out,
                             root_copy, stream_);
@@ -613,7 +617,14 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         int sub = std::max(0, std::min(std::min(MERKLE_MAX_SUB, nfused), level - 17));
         if (const char* e = getenv("LMN_MERKLE_SUB")) sub = std::min(std::min(atoi(e), nfused), MERKLE_MAX_SUB);
         nfused = std::min(nfused, sub + 8);
-        for (int l = 0; l <= nfused; ++l) outs.p[l] = layers[level - l];
+        // the `sub` levels a lane reduces in registers are not written when the caller can recompute what it needs of them
+        const int skip = cuts ? sub : 0;
+        for (int l = 0; l < skip; ++l) {
+          if (layers[level - l]) throw LmnError(LMN_ERR_INTERNAL, "merkle: a level to be skipped already has storage");
+          outs.p[l] = nullptr;
+        }
+        for (int l = skip; l <= nfused; ++l) outs.p[l] = layer(level - l);
+        if (skip) cuts->push_back({level, skip, prev, sg, (int)lc.size()});
         StageTimer tf(this, g_log(this), stream_, C_MERKLE_FUSED);
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_,
                             level == max_log ? fold : nullptr);
@@ -648,19 +659,19 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
   if (fold && sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: folded leaf levels are not sharded");
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].log;
   m.layers.assign(m.max_log + 1, nullptr);
+  m.cuts.clear();
   m.g = 0;
   if (cols_sorted.empty()) {
     m.root = b2_hash_words(nullptr, 0);
     return;
   }
   if (!sharded) {
-    for (int log = m.max_log; log >= 0; --log) m.layers[log] = arena_.alloc_words((size_t)8 << log);
     std::vector<std::vector<const uint32_t*>> per_level(m.max_log + 1);
     for (auto& c : cols_sorted) {
       if (c.sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: sharded column in a replicated tree");
       per_level[c.log].push_back(c.ptr);
     }
-    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy, fold);
+    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy, fold, merkle_cut_ ? &m.cuts : nullptr);
     return;
   }
   // Sharded tree (SURVEY.md §8e stage C/D): the aligned block of rows [rank * 2^(k-g), (rank+1) * 2^(k-g)) of every
@@ -1065,13 +1076,22 @@ struct Ref {
   const uint32_t* ptr;
   uint32_t len;
   int owner;
+  int job = -1;   // >= 0: not in memory - Merkle node to recompute (index into the plan's MerkleRecompute list), ptr is null
 };
 static Ref col_ref(const ColRef& c, uint64_t row, int g) {
   if (!c.sharded) return {c.ptr + row, 1, -1};
   const int sh = c.log - g;
   return {c.ptr + (row & ((1ull << sh) - 1)), 1, (int)(row >> sh)};
 }
-static Ref node_ref(const DevMerkle& m, int layer, uint64_t node) {
+static Ref node_ref(const DevMerkle& m, int layer, uint64_t node, std::vector<MerkleRecompute>& jobs) {
+  if (!m.layers[layer]) {   // a level its launch kept in registers (MerkleCut)
+    for (auto& c : m.cuts)
+      if (layer <= c.start_log && layer > c.start_log - c.depth) {
+        jobs.push_back({c.prev, c.sg, c.ncols, 1u << c.start_log, (uint32_t)node, c.start_log - layer, 0u});
+        return {nullptr, 8, -1, (int)jobs.size() - 1};
+      }
+    throw LmnError(LMN_ERR_INTERNAL, "merkle: layer without storage");
+  }
   if (m.g == 0 || layer <= m.g) return {m.layers[layer] + node * 8, 8, -1};
   const int sh = layer - m.g;
   return {m.layers[layer] + (node & ((1ull << sh) - 1)) * 8, 8, (int)(node >> sh)};
@@ -1093,6 +1113,7 @@ struct HostScratch {
   std::vector<DecommitPlan> plans;
   size_t used = 0;
   std::vector<GatherEntry> entries;
+  std::vector<MerkleRecompute> jobs;
   std::vector<std::pair<int, uint32_t>> runs;
   std::vector<ColRef> cols;
   DecommitPlan& next() {
@@ -1108,7 +1129,7 @@ static void release_host_scratch(void* p) { delete static_cast<HostScratch*>(p);
 // MerkleProver::decommit: emits device references in output order
 static void plan_merkle_decommit(const DevMerkle& m, const std::vector<ColRef>& cols_sorted, int g,
                                  const std::map<int, std::vector<uint32_t>>& queries, std::vector<Ref>& queried,
-                                 std::vector<Ref>& hash_wit, std::vector<Ref>& col_wit) {
+                                 std::vector<Ref>& hash_wit, std::vector<Ref>& col_wit, std::vector<MerkleRecompute>& jobs) {
   size_t pos = 0;
   std::vector<uint32_t> last, total;
   last.reserve(16);
@@ -1134,11 +1155,11 @@ static void plan_merkle_decommit(const DevMerkle& m, const std::vector<ColRef>& 
         if (pi < last.size() && last[pi] == 2 * node)
           ++pi;
         else
-          hash_wit.push_back(node_ref(m, log + 1, 2ull * node));
+          hash_wit.push_back(node_ref(m, log + 1, 2ull * node, jobs));
         if (pi < last.size() && last[pi] == 2 * node + 1)
           ++pi;
         else
-          hash_wit.push_back(node_ref(m, log + 1, 2ull * node + 1));
+          hash_wit.push_back(node_ref(m, log + 1, 2ull * node + 1, jobs));
       }
       bool is_q = ci < colq.size() && colq[ci] == node;
       if (is_q) ++ci;
@@ -1268,6 +1289,13 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   if (have_stream2_) lmn_sync(stream2_);
 #endif
   wait_before_level_ = -1;
+  // big trees are stored without the levels their fused launches keep in registers (MerkleCut); sharded proofs and the
+  // level-2 ops (whose handles expose every layer) keep whole trees
+  struct CutScope {
+    bool& flag;
+    ~CutScope() { flag = false; }
+  } cut_scope{merkle_cut_};
+  merkle_cut_ = !shard_.active && getenv("LMN_MERKLE_FULL") == nullptr;
 
   // ---- validate + size
   struct TableInfo {
@@ -1322,7 +1350,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   words += (4ull << comp_log) * 2 + row_split(4ull << max_lde);  // composition values/coeffs + lde
   if (shard_all_to_all()) words += 2ull << max_lde;              // one composition column over all rows + its packed copy
   words += row_split((4ull << max_lde) * 3);                   // quotient columns (all sizes) + fri layers
-  words += row_split(7 * (16ull << max_lde));                  // merkle trees (4 trace + fri first + inner)
+  if (merkle_cut_ && max_lde >= 21)
+    // trees without their register levels (MerkleCut): 1/8 of the nodes of a tree of 2^20 leaves and more; one whole leaf
+    // level for the first FRI tree, whose largest level is a launch of its own when a smaller quotient column joins below it
+    words += (16ull << max_lde) + 6 * (3ull << max_lde) + (16ull << 20);
+  else
+    words += row_split(7 * (16ull << max_lde));                // merkle trees (4 trace + fri first + inner)
   if (shard_.active) words += 64ull << std::min(max_lde, std::max(shard_.fri_min_log, 12) + 2);  // replicated small FRI layers + their trees
   words += (16u << 20);                                        // slack: tables, partials, gather buffers
   ensure_twiddles(max_lde);
@@ -2110,6 +2143,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     if (!host_scratch) host_scratch = new HostScratch();
     HostScratch& hs = *static_cast<HostScratch*>(host_scratch);
     hs.used = 0;
+    hs.jobs.clear();
     hs.plans.reserve(inner.size() + 5);  // plans are handed out by reference: no reallocation while planning
     std::vector<Plan>& plans = hs.plans;  // [first, inner..., tree0..3]
     {
@@ -2120,7 +2154,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         plan_fri_witness(c4, g, pos_by_log[quots[qk].log], dec[quots[qk].log], p.fri_wit);
       }
       std::vector<Ref> dummy;
-      plan_merkle_decommit(first_merkle, first_cols, g, dec, dummy, p.hash_wit, p.col_wit);
+      plan_merkle_decommit(first_merkle, first_cols, g, dec, dummy, p.hash_wit, p.col_wit, hs.jobs);
     }
     std::vector<uint32_t> lq = fold_positions(queries, 1);
     for (auto& fl : inner) {
@@ -2132,7 +2166,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       const ColRef(&c4)[4] = *reinterpret_cast<const ColRef(*)[4]>(lc.data());
       plan_fri_witness(c4, g, lq, dec[fl.log], p.fri_wit);
       std::vector<Ref> dummy;
-      plan_merkle_decommit(fl.merkle, lc, g, dec, dummy, p.hash_wit, p.col_wit);
+      plan_merkle_decommit(fl.merkle, lc, g, dec, dummy, p.hash_wit, p.col_wit, hs.jobs);
       lq = fold_positions(lq, 1);
     }
     for (auto* t : trees) {
@@ -2146,7 +2180,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
         if (!qmap.count(c.log_size + lb)) qmap[c.log_size + lb] = pos_by_log[c.log_size + lb];
       }
       std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
-      plan_merkle_decommit(t->merkle, sorted, g, qmap, p.queried, p.hash_wit, p.col_wit);
+      plan_merkle_decommit(t->merkle, sorted, g, qmap, p.queried, p.hash_wit, p.col_wit, hs.jobs);
     }
     // Every rank plans the same list; it fetches the runs it holds into its own slot of the output buffer, the
     // slots are all-gathered (a few KB per rank) and each run is then read from its owner's slot.
@@ -2157,7 +2191,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     uint32_t out_words = 0;
     auto add_refs = [&](const std::vector<Ref>& refs) {
       for (auto& r : refs) {
-        if (r.owner < 0 || r.owner == (int)shard_.rank) entries.push_back({arena_.word_offset(r.ptr), r.len, out_words});
+        if (r.job >= 0)
+          hs.jobs[r.job].dst_off = out_words;   // unsharded proofs only: one output slot
+        else if (r.owner < 0 || r.owner == (int)shard_.rank)
+          entries.push_back({arena_.word_offset(r.ptr), r.len, out_words});
         if (sh) runs.push_back({r.owner, r.len});
         out_words += r.len;
       }
@@ -2177,9 +2214,13 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       // the entry table is read once, one entry per lane: the kernel takes it straight from pinned host memory
       GatherEntry* d_e = (GatherEntry*)pin_alloc((entries.size() + 1) * sizeof(GatherEntry));
       memcpy(d_e, entries.data(), entries.size() * sizeof(GatherEntry));
+      if (!hs.jobs.empty() && sh) throw LmnError(LMN_ERR_INTERNAL, "sharded proofs keep whole trees");
+      MerkleRecompute* d_j = (MerkleRecompute*)pin_alloc((hs.jobs.size() + 1) * sizeof(MerkleRecompute));
+      memcpy(d_j, hs.jobs.data(), hs.jobs.size() * sizeof(MerkleRecompute));
       uint32_t* d_o = arena_.alloc_words((size_t)slots * out_words);
       hm.mark("decommit planned");
-      launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_o, stream_);
+      if (hm.on) fprintf(stderr, "[host] decommit: %zu runs gathered, %zu tree nodes recomputed\n", entries.size(), hs.jobs.size());
+      launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_j, (uint32_t)hs.jobs.size(), d_o, stream_);
       if (sh) gather_columns(d_o, 0, 1, out_words);
       gathered = (const uint32_t*)stage_download(d_o, (size_t)slots * out_words * 4);
       lmn_sync(stream_);

@@ -97,11 +97,24 @@ struct ColRef {
   bool sharded;
 };
 
+// A fused Merkle launch whose lanes kept their per-lane subtree in registers only: layers start_log, start_log - 1, ...,
+// start_log - depth + 1 of the tree do not exist in HBM (7/8 of a big tree's 32-byte nodes, 1 GB of writes per 2^20-row
+// proof, of which the decommitment reads a few dozen).  What the decommitment needs of them is recomputed from the
+// launch's start level (MerkleRecompute, k_gather).
+struct MerkleCut {
+  int start_log, depth;
+  const uint32_t* prev;
+  MerkleSegs sg;
+  int ncols;
+};
+
 struct DevMerkle {
   int max_log = -1;
   // layers[k]: 2^k hashes of 8 words.  In a sharded tree (g > 0) the layers k > g hold only this rank's
   // 2^(k-g) nodes (node n lives on rank n >> (k - g)); layers k <= g are complete on every rank.
+  // A null layer was not written: see `cuts`.
   std::vector<uint32_t*> layers;
+  std::vector<MerkleCut> cuts;
   int g = 0;
   Hash32 root;
   const uint32_t* root_pinned = nullptr;  // pending async download of layers[0]
@@ -241,9 +254,11 @@ class Context {
   void build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch = nullptr,
                     QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr, bool sharded = false,
                     const MerkleFold* fold = nullptr);
+  // null entries of `layers` are allocated from the arena as the launches reach them; with `cuts` given, the levels a
+  // fused launch keeps in registers stay null and are recorded there instead
   void build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                            const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch, QM31* alpha_out,
-                           uint32_t* root_copy, const MerkleFold* fold = nullptr);
+                           uint32_t* root_copy, const MerkleFold* fold = nullptr, std::vector<MerkleCut>* cuts = nullptr);
   // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
   void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
@@ -291,6 +306,7 @@ class Context {
   bool have_stream2_ = false;
   lmn_event_t wait_before_level_ev_{};
   int wait_before_level_ = -1;    // build_merkle_levels: make stream_ wait for wait_before_level_ev_ before this level
+  bool merkle_cut_ = false;       // inside prove() of an unsharded proof: trees are stored without their register levels
   Arena arena_;
   int tw_max_log_ = 0;
   // twiddle tables: Y[m] (m>=1), X[k] (k>=2), forward + inverse, device pointers

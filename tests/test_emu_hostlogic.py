@@ -56,6 +56,23 @@ def test_emu_matches_oracle(emu_ctx, name, tabs):
     assert got == want, name
 
 
+@pytest.mark.parametrize("name,tabs", [
+    ("chain-2^12", syn.chain_graph(1 << 12, 7)),
+    ("mixed 2^13 + 2^11 (a level with children and columns is a skipped start level)",
+     [(0, syn.chain_graph(5000, 4)[0][1]), (1, syn.chain_graph(2000, 5)[1][1])]),
+])
+def test_emu_trees_stored_without_their_register_levels(emu_ctx, name, tabs, monkeypatch):
+    """Big trees are stored without the levels a fused launch keeps in registers (MerkleCut, prover.h); what the
+    decommitment needs of them is recomputed inside the gather launch (MerkleRecompute).  On the GPU this starts at 2^18
+    leaves; LMN_MERKLE_SUB=3 makes the emulation build take the same path from 2^13 leaves on.  Same bytes as the oracle,
+    and as the whole-tree storage (LMN_MERKLE_FULL)."""
+    monkeypatch.setenv("LMN_MERKLE_SUB", "3")
+    got, want = _both(emu_ctx, tabs)
+    assert got == want, name
+    monkeypatch.setenv("LMN_MERKLE_FULL", "1")
+    assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
+
+
 def test_emu_error_codes(emu_ctx):
     with pytest.raises(backend.LuminairBackendError) as e:
         emu_ctx.prove_tables([(0, np.zeros((0, 15), np.uint32), 0)])
