@@ -116,6 +116,11 @@ struct MerkleFold {
   const uint32_t* itw;   // inverse twiddles of the fold (one per leaf)
   const QM31* alpha;     // device: the folding randomness drawn by the previous layer's channel step
   uint32_t* dst;         // this layer: 4 coordinate columns of `size` words, stride `size`
+  // Not a fold - a tree whose largest level (2*size leaves of `below_ncols` <= 8 contiguous columns, no children) sits
+  // directly under a level with columns of its own: the start level hashes its two leaves itself instead of reading
+  // their hashes, so the leaf level is neither written nor read back (2 x 32 B per leaf) and needs no launch.
+  const uint32_t* below;
+  int below_ncols;
 };
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold = nullptr);
@@ -151,6 +156,8 @@ struct MerkleRecompute {
   MerkleSegs sg;
   int ncols;
   uint32_t size;
+  const uint32_t* below; // MerkleFold::below of that launch (children = hashes of two leaves), or null
+  int below_ncols;
   uint32_t node;
   int depth;
   uint32_t dst_off;

@@ -1222,6 +1222,42 @@ LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs
   merkle_hash_from(prev, sg, ncols, size, i, m, h);
 }
 
+// MerkleFold::below: raw words of leaves 2i (m[0..7]) and 2i+1 (m[8..15]) of the level under the start level
+LMN_D void merkle_load_below(const uint32_t* __restrict__ below, int below_ncols, uint32_t size, uint32_t i, uint32_t m[16]) {
+  const uint64_t L = 2ull * size;
+  const uint32_t* __restrict__ bp = below + 2ull * i;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < below_ncols) {
+      m[k] = bp[(uint64_t)k * L];
+      m[8 + k] = bp[(uint64_t)k * L + 1];
+    } else {
+      m[k] = 0u;
+      m[8 + k] = 0u;
+    }
+  }
+}
+// start node i = H(H(leaf 2i) || H(leaf 2i+1) || own columns) from the raw leaf words of merkle_load_below
+LMN_D void merkle_hash_below(const MerkleSegs& sg, int ncols, uint32_t size, int below_ncols, uint32_t i, const uint32_t m[16],
+                             uint32_t h[8]) {
+  uint32_t ml[16], mr[16], hl[8], hr[8];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    ml[k] = k < 8 ? m[k] : 0u;
+    mr[k] = k < 8 ? m[8 + k] : 0u;
+  }
+  b2_compress_fresh(hl, ml, 4u * (uint32_t)below_ncols);
+  b2_compress_fresh(hr, mr, 4u * (uint32_t)below_ncols);
+  uint32_t m2[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    m2[k] = hl[k];
+    m2[8 + k] = hr[k];
+  }
+  // merkle_hash_from only asks whether the node HAS children; their hashes are in m2
+  merkle_hash_from(reinterpret_cast<const uint32_t*>(sg.base[0]), sg, ncols, size, i, m2, h);
+}
+
 LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
   uint4* o4 = reinterpret_cast<uint4*>(o);
   o4[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -1376,14 +1412,18 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
     m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
     m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
     m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+  } else if (MODE == 4) {
+    merkle_load_below(fold.below, fold.below_ncols, size, i, m);
   } else {
     merkle_load_first(prev, sg, ncols, size, i, m);
   }
 }
 template <int MODE>
 LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
-                            uint32_t i, uint32_t m[16], uint32_t h[8]) {
-  if (MODE == 3) {
+                            uint32_t i, uint32_t m[16], uint32_t h[8], const MerkleFold& fold = MerkleFold{}) {
+  if (MODE == 4) {
+    merkle_hash_below(sg, ncols, size, fold.below_ncols, i, m, h);
+  } else if (MODE == 3) {
     b2_compress_fresh(h, m, 16u);
   } else if (MODE == 1) {
     b2_compress_fresh(h, m, 4u * (uint32_t)ncols);
@@ -1424,7 +1464,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
     if (j + 1 < per) merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, node + 64u, mn, fold);
-    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur, fold);
     if (outs.p[0]) store_hash(outs.p[0] + (uint64_t)node * 8, cur);
   };
   for (uint32_t j = 0; j < per; j += 2) {
@@ -1603,7 +1643,11 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
   // a null p[l] (l < sub only: the levels a lane keeps in registers) is a level the caller does not want written
   for (int l = sub; l <= nfused; ++l)
     if (!outs.p[l]) throw LmnError(-100, "merkle_fused: only the per-lane levels may be left unwritten");
-  if (fold) {
+  if (fold && fold->below) {
+    if (prev || fold->src || ncols < 1 || fold->below_ncols < 1 || fold->below_ncols > 8)
+      throw LmnError(-100, "merkle_fused: a start level over its own leaf level has columns, no stored children and <= 8 leaf columns");
+    LMN_LAUNCH(k_merkle_fused<4>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+  } else if (fold) {
     if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
     LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
   } else if (!prev && ncols <= 16 && sg.n[0] == ncols)
@@ -1716,7 +1760,14 @@ LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __res
   const MerkleRecompute j = jobs[e];
   const uint32_t q = threadIdx.x & 3u;
   uint32_t h[8];
-  merkle_hash_start(j.prev, j.sg, j.ncols, j.size, (j.node << j.depth) + (q & ((1u << j.depth) - 1u)), h);
+  const uint32_t i0 = (j.node << j.depth) + (q & ((1u << j.depth) - 1u));
+  if (j.below) {
+    uint32_t mb[16];
+    merkle_load_below(j.below, j.below_ncols, j.size, i0, mb);
+    merkle_hash_below(j.sg, j.ncols, j.size, j.below_ncols, i0, mb, h);
+  } else {
+    merkle_hash_start(j.prev, j.sg, j.ncols, j.size, i0, h);
+  }
   for (int s = 0; s < j.depth; ++s) {
     const bool hi = ((q >> s) & 1u) != 0u;
     uint32_t m[16];

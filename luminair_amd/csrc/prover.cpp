@@ -570,28 +570,50 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
     StageTimer t(this, g_log(this), stream_, C_MERKLE);
     const uint32_t* prev = nullptr;
     int level = max_log;
+    MerkleFold below{};   // the leaf level of a tree whose next level has columns too: hashed by that level's launch
+    // from 2^19 leaves on (below that the launches are latency-bound and the separate leaf launch is the cheaper form);
+    // LMN_MERKLE_BELOW_MIN_LOG lowers the threshold for the emulation tests
+    const char* below_env = getenv("LMN_MERKLE_BELOW_MIN_LOG");
+    const int below_min_log = below_env ? std::max(12, atoi(below_env)) : 19;
+    // runs of contiguous equal-size columns of a level; false if there are more than MERKLE_MAX_SEG of them
+    auto make_segs = [&](int lv, MerkleSegs& sg) {
+      int nseg = 0;
+      for (auto* c : per_level[lv]) {
+        if (nseg > 0 && c == sg.base[nseg - 1] + ((uint64_t)sg.n[nseg - 1] << lv)) {
+          sg.n[nseg - 1]++;
+        } else if (nseg < MERKLE_MAX_SEG) {
+          sg.base[nseg] = c;
+          sg.n[nseg] = 1;
+          ++nseg;
+        } else {
+          return false;
+        }
+      }
+      return true;
+    };
     while (level >= 0) {
       auto& lc = per_level[level];
       if (level == wait_before_level_) {   // this level's columns were produced on the second stream
         lmn_stream_wait_event(stream_, wait_before_level_ev_);
         wait_before_level_ = -1;
       }
-      // runs of contiguous equal-size columns
-      MerkleSegs sg{};
-      int nseg = 0;
-      bool seg_ok = true;
-      for (size_t k = 0; k < lc.size(); ++k) {
-        if (nseg > 0 && lc[k] == sg.base[nseg - 1] + ((uint64_t)sg.n[nseg - 1] << level)) {
-          sg.n[nseg - 1]++;
-        } else if (nseg < MERKLE_MAX_SEG) {
-          sg.base[nseg] = lc[k];
-          sg.n[nseg] = 1;
-          ++nseg;
-        } else {
-          seg_ok = false;
-          break;
+      if (cuts && !fold && !prev && level == max_log && level >= below_min_log && !lc.empty() && lc.size() <= 8 &&
+          !per_level[level - 1].empty()) {
+        MerkleSegs sl{}, snext{};
+        if (make_segs(level, sl) && sl.n[0] == (int)lc.size() && make_segs(level - 1, snext)) {
+          below.below = lc[0];
+          below.below_ncols = (int)lc.size();
+          cuts->push_back({level, 1, nullptr, sl, (int)lc.size()});   // a node of this level = the hash of its leaf
+          timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull);
+          timings.merkle_fused_compressions += (uint64_t)1 << level;
+          timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull);
+          timings.merkle_compressions += (uint64_t)1 << level;
+          level -= 1;
+          continue;
         }
       }
+      MerkleSegs sg{};
+      const bool seg_ok = make_segs(level, sg);
       if (!seg_ok) {
         // rare scattered level: pointer-table kernel, one level per launch
         const uint32_t** dptrs = (const uint32_t**)stage_upload(lc.data(), lc.size() * sizeof(void*));
@@ -604,6 +626,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
       while (level - plain - 1 >= 0 && per_level[level - plain - 1].empty()) ++plain;
       MerkleLevels outs{};
       int nfused;
+      bool over_leaves = false;
       if (level <= 10) {
         nfused = std::min(plain, 10);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = layer(level - l);
@@ -624,15 +647,18 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
           outs.p[l] = nullptr;
         }
         for (int l = skip; l <= nfused; ++l) outs.p[l] = layer(level - l);
-        if (skip) cuts->push_back({level, skip, prev, sg, (int)lc.size()});
+        over_leaves = below.below != nullptr;
+        if (skip) cuts->push_back({level, skip, prev, sg, (int)lc.size(), below.below, below.below_ncols});
         StageTimer tf(this, g_log(this), stream_, C_MERKLE_FUSED);
         launch_merkle_fused(prev, sg, (int)lc.size(), 1u << level, outs, sub, nfused, stream_,
-                            level == max_log ? fold : nullptr);
+                            over_leaves ? &below : (level == max_log ? fold : nullptr));
+        below = MerkleFold{};
         timings.merkle_fused_launches++;
         // a folded leaf level also reads the pair it folds (32 B) and writes the layer (16 B) instead of reading it (16 B)
         if (fold && level == max_log) timings.merkle_fused_bytes += ((uint64_t)1 << level) * 32ull;
-        uint64_t words = (prev ? 16 : 0) + lc.size();
-        timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
+        const bool kids = prev || over_leaves;   // SURVEY's byte formula: as if the children's hashes were read
+        uint64_t words = (kids ? 16 : 0) + lc.size();
+        timings.merkle_fused_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (kids ? 64ull : 0ull));
         timings.merkle_fused_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
         for (int l = 1; l <= nfused; ++l) {
           timings.merkle_fused_bytes += ((uint64_t)1 << (level - l)) * 96ull;
@@ -640,10 +666,11 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         }
       }
       timings.merkle_launches++;
-      timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (prev ? 64ull : 0ull));
+      const bool had_kids = prev || over_leaves;
+      timings.merkle_bytes += ((uint64_t)1 << level) * (4ull * lc.size() + 32ull + (had_kids ? 64ull : 0ull));
       for (int l = 1; l <= nfused; ++l) timings.merkle_bytes += ((uint64_t)1 << (level - l)) * 96ull;
       {
-        uint64_t words = (prev ? 16 : 0) + lc.size();
+        uint64_t words = (had_kids ? 16 : 0) + lc.size();
         timings.merkle_compressions += ((uint64_t)1 << level) * std::max<uint64_t>(1, (words + 15) / 16);
         for (int l = 1; l <= nfused; ++l) timings.merkle_compressions += (uint64_t)1 << (level - l);
       }
@@ -1087,7 +1114,7 @@ static Ref node_ref(const DevMerkle& m, int layer, uint64_t node, std::vector<Me
   if (!m.layers[layer]) {   // a level its launch kept in registers (MerkleCut)
     for (auto& c : m.cuts)
       if (layer <= c.start_log && layer > c.start_log - c.depth) {
-        jobs.push_back({c.prev, c.sg, c.ncols, 1u << c.start_log, (uint32_t)node, c.start_log - layer, 0u});
+        jobs.push_back({c.prev, c.sg, c.ncols, 1u << c.start_log, c.below, c.below_ncols, (uint32_t)node, c.start_log - layer, 0u});
         return {nullptr, 8, -1, (int)jobs.size() - 1};
       }
     throw LmnError(LMN_ERR_INTERNAL, "merkle: layer without storage");
@@ -1351,9 +1378,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   if (shard_all_to_all()) words += 2ull << max_lde;              // one composition column over all rows + its packed copy
   words += row_split((4ull << max_lde) * 3);                   // quotient columns (all sizes) + fri layers
   if (merkle_cut_ && max_lde >= 21)
-    // trees without their register levels (MerkleCut): 1/8 of the nodes of a tree of 2^20 leaves and more; one whole leaf
-    // level for the first FRI tree, whose largest level is a launch of its own when a smaller quotient column joins below it
-    words += (16ull << max_lde) + 6 * (3ull << max_lde) + (16ull << 20);
+    // trees without their register levels (MerkleCut): 1/8 of the nodes of a tree of 2^20 leaves and more
+    // (bounds: up to four trees whose leaf level has more than 8 columns next to a smaller component's - that level is a
+    // launch of its own and stays whole - and 1/8 + the block tops of everything else)
+    words += 4 * (8ull << max_lde) + 7 * (3ull << max_lde) + (16ull << 20);
   else
     words += row_split(7 * (16ull << max_lde));                // merkle trees (4 trace + fri first + inner)
   if (shard_.active) words += 64ull << std::min(max_lde, std::max(shard_.fri_min_log, 12) + 2);  // replicated small FRI layers + their trees

@@ -106,6 +106,8 @@ struct MerkleCut {
   const uint32_t* prev;
   MerkleSegs sg;
   int ncols;
+  const uint32_t* below = nullptr;   // the launch hashed the leaf level under its start level itself (MerkleFold::below)
+  int below_ncols = 0;
 };
 
 struct DevMerkle {

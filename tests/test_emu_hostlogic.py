@@ -60,6 +60,8 @@ def test_emu_matches_oracle(emu_ctx, name, tabs):
     ("chain-2^12", syn.chain_graph(1 << 12, 7)),
     ("mixed 2^13 + 2^11 (a level with children and columns is a skipped start level)",
      [(0, syn.chain_graph(5000, 4)[0][1]), (1, syn.chain_graph(2000, 5)[1][1])]),
+    ("mixed 2^13 + 2^12 (adjacent sizes: the larger component's leaf level sits under the smaller one's)",
+     [(0, syn.chain_graph(5000, 4)[0][1]), (1, syn.chain_graph(3000, 5)[1][1])]),
 ])
 def test_emu_trees_stored_without_their_register_levels(emu_ctx, name, tabs, monkeypatch):
     """Big trees are stored without the levels a fused launch keeps in registers (MerkleCut, prover.h); what the
@@ -69,6 +71,10 @@ def test_emu_trees_stored_without_their_register_levels(emu_ctx, name, tabs, mon
     monkeypatch.setenv("LMN_MERKLE_SUB", "3")
     got, want = _both(emu_ctx, tabs)
     assert got == want, name
+    # the leaf level of a tree whose next level has columns too (the first FRI tree of every proof; mixed-size trees) is
+    # hashed by that level's launch and never stored (MerkleFold::below); on the GPU from 2^19 leaves on
+    monkeypatch.setenv("LMN_MERKLE_BELOW_MIN_LOG", "12")
+    assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
     monkeypatch.setenv("LMN_MERKLE_FULL", "1")
     assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
 
