@@ -116,6 +116,10 @@ struct MerkleFold {
   const uint32_t* itw;   // inverse twiddles of the fold (one per leaf)
   const QM31* alpha;     // device: the folding randomness drawn by the previous layer's channel step
   uint32_t* dst;         // this layer: 4 coordinate columns of `size` words, stride `size`
+  // A quotient column of 2*size rows that joins this layer (fold_circle_into_line with accumulation, same alpha):
+  // leaf i = fold(src)[i] * alpha^2 + fold(src2)[i]; null if none
+  const uint32_t* src2;
+  const uint32_t* itw2;
   // Not a fold - a tree whose largest level (2*size leaves of `below_ncols` <= 8 contiguous columns, no children) sits
   // directly under a level with columns of its own: the start level hashes its two leaves itself instead of reading
   // their hashes, so the leaf level is neither written nor read back (2 x 32 B per leaf) and needs no launch.

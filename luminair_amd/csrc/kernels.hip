@@ -1382,7 +1382,15 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
     const uint32_t* __restrict__ sp = fold.src + 2ull * i;
     const QM31 a{sp[0], sp[L], sp[2 * L], sp[3 * L]};
     const QM31 b{sp[1], sp[L + 1], sp[2 * L + 1], sp[3 * L + 1]};
-    const QM31 r = q_add(q_add(a, b), q_mul(*fold.alpha, q_mul_m(q_sub(a, b), fold.itw[i])));
+    const QM31 alpha = *fold.alpha;
+    QM31 r = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), fold.itw[i])));
+    if (fold.src2) {   // block-uniform: a quotient column joins this layer (k_fold with accumulate = 1)
+      const uint32_t* __restrict__ sq = fold.src2 + 2ull * i;
+      const QM31 c{sq[0], sq[L], sq[2 * L], sq[3 * L]};
+      const QM31 d{sq[1], sq[L + 1], sq[2 * L + 1], sq[3 * L + 1]};
+      const QM31 rc = q_add(q_add(c, d), q_mul(alpha, q_mul_m(q_sub(c, d), fold.itw2[i])));
+      r = q_add(q_mul(r, q_mul(alpha, alpha)), rc);
+    }
     uint32_t* __restrict__ o = fold.dst + i;
     o[0] = r.a;
     o[(uint64_t)size] = r.b;

@@ -1991,10 +1991,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       const uint32_t* src = nullptr;
       int src_log = 0;
       const QM31* alpha = nullptr;
+      const uint32_t* join = nullptr;   // a quotient column of the source's size that joins the layer (circle fold, accumulated)
     } pend;
     auto materialise = [&](uint32_t* dst) {
       if (!pend.on) return;
       fold(pend.circle, dst, false, pend.src, pend.src_log, false, pend.alpha, 0);
+      if (pend.join) fold(true, dst, false, pend.join, pend.src_log, false, pend.alpha, 1);
       pend.on = false;
     };
     static const bool fuse_folds = getenv("LMN_NO_FOLD_FUSION") == nullptr;
@@ -2045,7 +2047,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       std::vector<ColRef> lc;
       secure_cols(layer, layer_log, lay_sh, lc);
       if (pend.on) {
-        const MerkleFold mf{pend.src, pend.circle ? itwY_[pend.src_log] : itwX_[pend.src_log + 1], pend.alpha, layer};
+        MerkleFold mf{pend.src, pend.circle ? itwY_[pend.src_log] : itwX_[pend.src_log + 1], pend.alpha, layer};
+        if (pend.join) {
+          mf.src2 = pend.join;
+          mf.itw2 = itwY_[pend.src_log];
+        }
         build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, false, &mf);
         pend.on = false;
       } else {
@@ -2057,8 +2063,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       const bool next_sh = sharded_log(next_log);
       uint32_t* next = layer_alloc(next_log, next_sh);
       const bool joins = qi < quots.size() && quots[qi].log - 1 == next_log;
-      if (!sh && fuse_folds && !joins && next_log > 10) {
-        pend = {true, false, layer, layer_log, d_alpha};
+      static const bool fuse_joins = getenv("LMN_NO_JOIN_FUSION") == nullptr;
+      if (!sh && fuse_folds && next_log > 10 && (!joins || (fuse_joins && !quots[qi].sharded))) {
+        pend = {true, false, layer, layer_log, d_alpha, joins ? quots[qi].vals : nullptr};
+        if (joins) ++qi;   // (quotient sizes are distinct: at most one column joins a layer)
       } else {
         fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
       }
