@@ -2566,13 +2566,31 @@ LMN_HD uint32_t domain_y(const uint32_t* tw_y, uint32_t s) {
 // NB = number of sample-point batches (compile-time: exact loops, no dummy products); every lane owns
 // QUOT_ROWS rows a quarter of the domain apart and inverts all their denominator norms with ONE field
 // inversion (Montgomery batching: 3 products per element instead of a 37-product exponentiation per row).
+// Rows per lane: 4 for one batch, 2 for two batches (the headline shape) - with the register budget of 8 waves per SIMD
+// (64 VGPRs, no spills) those two launches fill the chip in whole rounds (16 waves per SIMD in two rounds of 8; at 87
+// VGPRs the 8 waves per SIMD of the two-batch launch ran as 5 + 3): 0.167 -> 0.150 ms per proof, + 2 % proofs/s.
+// Three and four batches keep 4 rows at the compiler's own budget (they would spill at 64).
 #ifndef LMN_QUOT_ROWS1
 #define LMN_QUOT_ROWS1 4
 #endif
+#ifndef LMN_QUOT_ROWS2
+#define LMN_QUOT_ROWS2 2
+#endif
 template <int NB>
-constexpr int quot_rows() { return NB == 1 ? LMN_QUOT_ROWS1 : 4; }   // rows per lane (a single batch leaves registers for more)
+constexpr int quot_rows() { return NB == 1 ? LMN_QUOT_ROWS1 : (NB == 2 ? LMN_QUOT_ROWS2 : 4); }   // rows per lane
 template <int NB>
-LMN_KERNEL k_quotients(QuotientArgs a) {
+LMN_D void quotients_body(const QuotientArgs& a);
+template <int NB>
+LMN_KERNEL k_quotients(QuotientArgs a) { quotients_body<NB>(a); }
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
+template <int NB>
+__attribute__((amdgpu_waves_per_eu(8, 8))) LMN_KERNEL k_quotients_occ(QuotientArgs a) { quotients_body<NB>(a); }
+#else
+template <int NB>
+LMN_KERNEL k_quotients_occ(QuotientArgs a) { quotients_body<NB>(a); }
+#endif
+template <int NB>
+LMN_D void quotients_body(const QuotientArgs& a) {
   constexpr int QUOT_ROWS = quot_rows<NB>();
   // (column pointer, alpha^k * c) table staged once per block in LDS: the per-column loop then
   // reads wave-uniform LDS words instead of chasing pointers through global memory
@@ -2661,10 +2679,11 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
       a.out_stride < (1ull << a.log_rows))
     throw LmnError(-100, "quotients: bad row block");
   if (a.nbatch == 1 && (1u << a.log_rows) < (unsigned)quot_rows<1>()) throw LmnError(-100, "quotients: row block too small");
-  dim3 g(cdiv((1ull << a.log_rows) / 4, TPB)), g1(cdiv((1ull << a.log_rows) / quot_rows<1>(), TPB)), b(TPB);
+  dim3 g(cdiv((1ull << a.log_rows) / 4, TPB)), g1(cdiv((1ull << a.log_rows) / quot_rows<1>(), TPB)),
+      g2(cdiv((1ull << a.log_rows) / quot_rows<2>(), TPB)), b(TPB);
   switch (a.nbatch) {
-    case 1: LMN_LAUNCH(k_quotients<1>, g1, b, 0, s, a); break;
-    case 2: LMN_LAUNCH(k_quotients<2>, g, b, 0, s, a); break;
+    case 1: LMN_LAUNCH(k_quotients_occ<1>, g1, b, 0, s, a); break;
+    case 2: LMN_LAUNCH(k_quotients_occ<2>, g2, b, 0, s, a); break;
     case 3: LMN_LAUNCH(k_quotients<3>, g, b, 0, s, a); break;
     default: LMN_LAUNCH(k_quotients<4>, g, b, 0, s, a); break;
   }

@@ -65,10 +65,15 @@ def test_hot_kernels_do_not_spill_and_keep_their_register_budget(device_asm):
             _, md = ks[name]
             assert md["vgpr_spill"] == 0, (name, md)
             assert md["vgpr"] <= 64, (name, md)      # 8 waves per SIMD: these kernels live on latency hiding
-    for part in ("k_quotientsILi1E", "k_quotientsILi2E", "k_compositionILi0E", "k_logup_fracs", "k_eval_at_point",
+    for part in ("k_quotientsILi3E", "k_quotientsILi4E", "k_compositionILi0E", "k_logup_fracs", "k_eval_at_point",
                  "k_transpose_pad"):
         for name in _find(ks, part):
             assert ks[name][1]["vgpr_spill"] == 0, (name, ks[name][1])
+    # the one- and two-batch FRI quotient launches run at 8 waves per SIMD (16 waves per SIMD in two whole rounds)
+    for part in ("k_quotients_occILi1E", "k_quotients_occILi2E"):
+        for name in _find(ks, part):
+            md = ks[name][1]
+            assert md["vgpr_spill"] == 0 and md["vgpr"] <= 64, (name, md)
 
 
 def _classes(body):
