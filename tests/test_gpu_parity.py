@@ -463,6 +463,31 @@ def test_gpu_config2b_full_size_verifies(gpu_prover_pinned):
     verify(p, ProtocolVariant.PINNED)
 
 
+@pytest.mark.parametrize("name,kat_tabs,pinned_tabs", [
+    # trees of 2^18 / 2^19 leaves: one / two register levels per lane are left out of the stored tree; the first FRI tree's
+    # leaf level (2^19) is hashed by the launch of the level above it (the threshold of MerkleFold::below)
+    ("add-2^17", syn.config2_add_only(1 << 17, 21), None),
+    # two component sizes: a level with children AND columns is the start level of a launch that skips its register levels
+    ("add-2^18 + mul-2^17", [(0, syn.chain_graph(1 << 18, 22)[0][1]), (1, syn.chain_graph(1 << 17, 23)[1][1])], None),
+    # Inputs 2^19 rows over Add 2^18 rows: trace tree with a 7-column leaf level under a 15-column level, interaction tree
+    # with a 4-column leaf level under an 8-column level - both fused into the upper level's launch
+    ("2b: add-2^18 + inputs-2^19", None, syn.config2_graph_faithful(1 << 18, 24)),
+])
+def test_gpu_tree_storage_thresholds_equal_c_oracle_bytes(gpu_prover, gpu_prover_pinned, c_oracle, name, kat_tabs, pinned_tabs):
+    """Sizes at which the Merkle storage form changes (MerkleCut depth 1 / 2 / 3, the fused leaf level): proof bytes
+    against the C oracle - the decommitment of such a proof recomputes the tree nodes that were never written."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    if kat_tabs is not None:
+        want = to_bincode(prove(kat_tabs, kernels=c_oracle))
+        got = _gpu_bytes(gpu_prover, kat_tabs)
+    else:
+        want = to_bincode(prove(pinned_tabs, variant=ProtocolVariant.PINNED, kernels=c_oracle))
+        got = _gpu_bytes(gpu_prover_pinned, pinned_tabs)
+    assert len(got) == len(want) and _sha(got) == _sha(want), name
+
+
 def test_gpu_less_than_2_18_rows_equals_c_oracle_bytes(gpu_prover_pinned, c_oracle):
     """Add + LessThan (7 logup relations, range-check LUT in tree 0) + Inputs at 2^18 rows, byte-for-byte."""
     from oracle.channel import ProtocolVariant
