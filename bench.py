@@ -39,7 +39,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 rows of the Add trace (default 20 = BASELINE config 2)")
     ap.add_argument("--inflight", type=int, default=8,
-                    help="independent proofs in flight per GPU (one prover context + HIP stream + ~3 GB arena each); "
+                    help="independent proofs in flight per GPU (one prover context + HIP stream + ~1.8 GB arena each); "
                          "8 measured best on MI355X for both 20-step and 192-step regions (DESIGN.md section 7)")
     ap.add_argument("--host-rows", action="store_true",
                     help="hand the trace rows over as host buffers (PCIe-inclusive rate; never the headline value)")
