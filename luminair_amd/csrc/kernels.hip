@@ -68,8 +68,10 @@ constexpr int TR_ROWS = 64;
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
                            uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic,
                            uint64_t out_stride, uint64_t blk_row0) {
-  LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x (ncols + 1)
-  const int stride = ncols + 1;
+  LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x stride
+  // odd row stride: the column-major read below walks rows at that stride, and an even one (16 words for the 15 columns of
+  // Add) maps the 64 rows of a column onto 2 of the 32 LDS banks
+  const int stride = ncols | 1;
   const uint64_t row0 = blk_row0 + (uint64_t)blockIdx.x * TR_ROWS;
   const int total = TR_ROWS * ncols;
   for (int k = threadIdx.x; k < total; k += blockDim.x) {
@@ -1270,12 +1272,16 @@ LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
 // LDS by per-lane sigma offsets.  ~400 issue slots instead of ~1000: single-hash latency 0.93 us vs 2.0 us
 // on MI355X (tools/microbench4.hip) - used where a level is too narrow to fill lanes anyway.
 // Returns words q and 4+q of the digest.  Must be executed by all four lanes of the quad.
+// WS = 0: the 16 message words are contiguous at msg; WS > 0: the two child hashes live in a word-major node array
+// (word k of node j at base[k * WS + j]): message word w = msg[(w & 7) * WS + (w >> 3)] with msg = base + 2 * parent.
+template <uint32_t WS = 0u>
 LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint32_t& o_hi, uint32_t t0 = 64u) {
+#define LMN_B2_QW(w) (WS ? msg[((w) & 7u) * WS + ((w) >> 3)] : msg[(w)])
 #ifdef LMN_EMU
   // CPU emulation (tests only): a cross-lane rendezvous per DPP move would be a block-wide fiber switch;
   // every lane hashes the block alone and keeps its two words.  The DPP path is checked on the GPU.
   uint32_t h[8], m[16];
-  for (int k = 0; k < 16; ++k) m[k] = msg[k];
+  for (uint32_t k = 0; k < 16; ++k) m[k] = LMN_B2_QW(k);
   b2_compress_fresh(h, m, t0);
   o_lo = h[q];
   o_hi = h[4 + q];
@@ -1290,8 +1296,8 @@ LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint3
   {                                                                       \
     const uint64_t S = LMN_B2_SIGMA_PACK(__VA_ARGS__);                    \
     const uint32_t lo = (uint32_t)(S >> sh8), hi = (uint32_t)(S >> (32u + sh8)); \
-    const uint32_t x0 = msg[lo & 15u], y0 = msg[(lo >> 4) & 15u];        \
-    const uint32_t x1 = msg[hi & 15u], y1 = msg[(hi >> 4) & 15u];        \
+    const uint32_t x0 = LMN_B2_QW(lo & 15u), y0 = LMN_B2_QW((lo >> 4) & 15u); \
+    const uint32_t x1 = LMN_B2_QW(hi & 15u), y1 = LMN_B2_QW((hi >> 4) & 15u); \
     LMN_B2_G(a, b, c, d, x0, y0)                                          \
     b = lmn_quad_perm(b, 0x39);                                           \
     c = lmn_quad_perm(c, 0x4E);                                           \
@@ -1314,12 +1320,15 @@ LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint3
 #undef LMN_B2_QUAD_ROUND
   o_lo = h_lo ^ a ^ c;
   o_hi = iv_hi ^ b ^ d;
+#undef LMN_B2_QW
 }
 
-// One level of an in-LDS Merkle climb: the children of this block's `n_par` parents sit in sh[j*16 ..];
-// parent j is written back to sh[j*8 ..] and to out[(node0 + j)*8 ..].  Levels with at most 128 parents
-// (two quad-waves per SIMD of the CU) use four lanes per hash, which is faster there; wider levels are
-// throughput-bound inside the CU and keep one lane per hash.  Block-uniform arguments; ends WITHOUT a barrier.
+// One level of an in-LDS Merkle climb.  The block's nodes live WORD-MAJOR in sh (word k of node j at sh[k * BLOCK + j]:
+// lanes that walk nodes touch consecutive banks - the node-major form, 8 or 16 words per lane, put a whole wave on two
+// banks): the children of this block's `n_par` parents are nodes 0 .. 2 * n_par - 1, parent j replaces node j and is
+// written to out[(node0 + j)*8 ..].  Levels with at most 128 parents (two quad-waves per SIMD of the CU) use four lanes
+// per hash, which is faster there; wider levels are throughput-bound inside the CU and keep one lane per hash.
+// Block-uniform arguments; ends WITHOUT a barrier.
 template <int BLOCK>
 LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t node0, uint32_t n_par) {
   __syncthreads();
@@ -1328,11 +1337,11 @@ LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t n
     const bool on = g < n_par;
     uint32_t o_lo = 0u, o_hi = 0u;
     const bool wave_on = ((threadIdx.x & ~63u) >> 2) < n_par;  // wave-uniform
-    if (wave_on) b2_quad_parent(sh + g * 16u, q, o_lo, o_hi);
+    if (wave_on) b2_quad_parent<(uint32_t)BLOCK>(sh + 2u * g, q, o_lo, o_hi);
     __syncthreads();
     if (on) {
-      sh[g * 8u + q] = o_lo;
-      sh[g * 8u + 4u + q] = o_hi;
+      sh[q * BLOCK + g] = o_lo;
+      sh[(4u + q) * BLOCK + g] = o_hi;
       uint32_t* o = out + (uint64_t)(node0 + g) * 8;
       o[q] = o_lo;
       o[4u + q] = o_hi;
@@ -1343,14 +1352,17 @@ LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t n
     if (on) {
       uint32_t m[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) m[k] = sh[threadIdx.x * 16 + k];
+      for (int k = 0; k < 8; ++k) {
+        m[k] = sh[k * BLOCK + 2u * threadIdx.x];
+        m[8 + k] = sh[k * BLOCK + 2u * threadIdx.x + 1u];
+      }
       b2_compress_fresh(cur, m, 64u);
       store_hash(out + (uint64_t)(node0 + threadIdx.x) * 8, cur);
     }
     __syncthreads();
     if (on) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = cur[k];
+      for (int k = 0; k < 8; ++k) sh[k * BLOCK + threadIdx.x] = cur[k];
     }
   }
 }
@@ -1509,7 +1521,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   {
     const uint32_t local = cur_idx - blockIdx.x * TPB;  // this block owns level-`sub` nodes [b*TPB, (b+1)*TPB)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sh[local * 8 + k] = cur[k];
+    for (int k = 0; k < 8; ++k) sh[k * TPB + local] = cur[k];   // word-major (merkle_lds_level)
   }
   merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub);
 }
@@ -1558,9 +1570,9 @@ LMN_D void chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_al
 // Block-cooperative form of chan_mix_root_draw for kernels that already hold the root in LDS: called by ALL
 // threads of the block (block-uniform control flow); the hashing runs on the first quad with the
 // quad-cooperative Blake2s (0.9 us per hash instead of 2 us).  `scratch`: 28 words of LDS that do not
-// overlap `root`.  Ends with a barrier and returns the drawn alpha to every thread.
-LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32_t* scratch, QM31* out_alpha,
-                                    uint32_t* root_copy) {
+// overlap the root's 8 words.  Ends with a barrier and returns the drawn alpha to every thread.
+LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32_t root_stride, uint32_t* scratch,
+                                    QM31* out_alpha, uint32_t* root_copy) {
   uint32_t* msg = scratch;       // 16 words: digest || root, then digest || counter
   uint32_t* wbuf = scratch + 16;  // 8 words: drawn words
   const uint32_t tid = threadIdx.x, q = tid & 3u;
@@ -1568,7 +1580,7 @@ LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32
   __syncthreads();
   if (tid < 8u) {
     msg[tid] = ch->digest[tid];
-    const uint32_t r = root[tid];
+    const uint32_t r = root[tid * root_stride];   // word k of the root at root[k * root_stride] (word-major node array)
     msg[8u + tid] = r;
     root_copy[tid] = r;
   }
@@ -1631,12 +1643,13 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     merkle_hash_mode<MODE>(prev, sg, ncols, size, i, m, cur);
     store_hash(outs.p[0] + (uint64_t)i * 8, cur);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+    for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
   }
   LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
   merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
   // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
-  if (ch != nullptr && (size >> nfused) == 1u) chan_mix_root_draw_block(ch, sh, sh + 16, alpha_out, root_copy);
+  if (ch != nullptr && (size >> nfused) == 1u)
+    chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
 }
 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
@@ -1721,10 +1734,10 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
       b2_compress_fresh(cur, m, 16u);
       store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sh[i * 8 + k] = cur[k];
+      for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
     }
     for (int l = L - 1; l >= 0; --l) merkle_lds_level<MERKLE_SMALL_BLOCK>(sh, ly.merkle[l], 0u, 1u << l);
-    const QM31 alpha = chan_mix_root_draw_block(ch, sh, sh + 16, &alphas_out[li], roots_out + li * 8);
+    const QM31 alpha = chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, &alphas_out[li], roots_out + li * 8);
     const uint32_t n = size >> 1;
     if (i < n) {
       QM31 a{ly.vals[2 * i], ly.vals[size + 2 * i], ly.vals[2 * size + 2 * i], ly.vals[3 * size + 2 * i]};
