@@ -2063,7 +2063,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       const bool next_sh = sharded_log(next_log);
       uint32_t* next = layer_alloc(next_log, next_sh);
       const bool joins = qi < quots.size() && quots[qi].log - 1 == next_log;
-      static const bool fuse_joins = getenv("LMN_NO_JOIN_FUSION") == nullptr;
+      const bool fuse_joins = getenv("LMN_NO_JOIN_FUSION") == nullptr;   // (read per proof: the tests toggle it)
       if (!sh && fuse_folds && next_log > 10 && (!joins || (fuse_joins && !quots[qi].sharded))) {
         pend = {true, false, layer, layer_log, d_alpha, joins ? quots[qi].vals : nullptr};
         if (joins) ++qi;   // (quotient sizes are distinct: at most one column joins a layer)

@@ -488,6 +488,20 @@ def test_gpu_tree_storage_thresholds_equal_c_oracle_bytes(gpu_prover, gpu_prover
     assert len(got) == len(want) and _sha(got) == _sha(want), name
 
 
+def test_gpu_storage_and_fusion_switches_do_not_change_the_proof(gpu_prover, monkeypatch):
+    """The forms this round replaced stay selectable for measurements (LMN_MERKLE_FULL: every tree level written;
+    LMN_MERKLE_BELOW_MIN_LOG=99: separate leaf launch under a column level; LMN_NO_JOIN_FUSION: a joining quotient column
+    folded by its own launches): each yields the bytes of the default form (which the other tests pin on the oracle)."""
+    tabs = syn.config2_add_only(1 << 20, 42)
+    want = _sha(_gpu_bytes(gpu_prover, tabs))
+    for env in ({"LMN_MERKLE_FULL": "1"}, {"LMN_MERKLE_BELOW_MIN_LOG": "99"}, {"LMN_NO_JOIN_FUSION": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert _sha(_gpu_bytes(gpu_prover, tabs)) == want, env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_gpu_less_than_2_18_rows_equals_c_oracle_bytes(gpu_prover_pinned, c_oracle):
     """Add + LessThan (7 logup relations, range-check LUT in tree 0) + Inputs at 2^18 rows, byte-for-byte."""
     from oracle.channel import ProtocolVariant
