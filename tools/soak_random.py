@@ -13,11 +13,14 @@ from oracle.prover import prove
 from oracle.cbackend import CKernels
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+# "big": tables of up to 2^20 rows - random size mixes across the thresholds of the tree storage forms (MerkleCut depth 1 - 3,
+# leaf levels fused into the level above, quotient columns joining FRI layers)
+scales = (400, 700, 1100, 1500) if len(sys.argv) > 2 and sys.argv[2] == "big" else (1, 40, 150, 400)
 p = luminair_amd.Prover(0, protocol_variant=luminair_amd.backend.VARIANT_PINNED)
 ck = CKernels()
 bad, t0, rows = [], time.time(), 0
 for seed in range(100, 100 + n):
-    scale = (1, 40, 150, 400)[seed % 4]
+    scale = scales[seed % 4]
     tabs, luts = random_pie(seed, scale)
     rows += sum(len(r) for _, r in tabs)
     got = p.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts)).to_bincode()
