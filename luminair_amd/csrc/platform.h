@@ -14,6 +14,8 @@
 
 #ifndef LMN_EMU
 #include <hip/hip_runtime.h>
+#include <time.h>
+#include <chrono>
 #define LMN_HD __host__ __device__ __forceinline__
 #define LMN_D __device__ __forceinline__
 #ifdef LMN_BATCH
@@ -105,17 +107,43 @@ inline void lmn_sync(lmn_stream_t s) {
     LMN_HIP_CHECK(hipEventSynchronize(ev));
     return;
   }
+  // Mode 0 polls.  A proof that has the GPU to itself never waits longer than about a millisecond, and polling is what keeps
+  // its latency low; under concurrent load every wait lasts several milliseconds (the GPU is shared), eight polling contexts
+  // kept eight CPUs busy, and N ranks in one CPU-limited container starved each other's launch threads
+  // (tools/host_cpu_per_proof.py).  So a wait that outlasts LMN_SPIN_US (default 1200 us) goes on in 50 us sleeps, and a
+  // thread whose recent waits did so starts sleeping after 100 us already; a few short waits bring it back to polling.
+  static const long spin_us = getenv("LMN_SPIN_US") ? atol(getenv("LMN_SPIN_US")) : 1200;
+  static thread_local int long_waits = 0;   // 0 .. 8: how many of the recent waits on this thread outlasted spin_us
+  const long limit_us = long_waits >= 2 ? 100 : spin_us;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto waited_us = [&] {
+    return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_start).count();
+  };
+  bool sleeping = false;
   for (int it = 0;; ++it) {
     hipError_t e = hipStreamQuery(s);
-    if (e == hipSuccess) return;
+    if (e == hipSuccess) break;
     if (e != hipErrorNotReady) LMN_HIP_CHECK(e);
     if (mode == 2 && it > 64) {
       LMN_HIP_CHECK(hipStreamSynchronize(s));
       return;
     }
+    if (sleeping) {
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, nullptr);
+      continue;
+    }
+    if (spin_us >= 0 && (it & 15) == 15 && waited_us() > limit_us) sleeping = true;
 #if defined(__x86_64__)
     for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
 #endif
+  }
+  if (spin_us >= 0) {
+    if (sleeping && waited_us() > spin_us) {
+      if (long_waits < 8) ++long_waits;
+    } else if (long_waits > 0) {
+      --long_waits;
+    }
   }
 }
 inline void* lmn_host_alloc_pinned(size_t bytes) {
