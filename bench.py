@@ -406,7 +406,13 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = timed_region(step, args.steps, args.warmup, barrier, device_sync)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    # host CPU this rank spent in the warm-up + timed steps (user + system, all threads): what N ranks need from a
+    # CPU-limited container (tools/host_cpu_per_proof.py; the library's waits back off to sleeps under load)
+    host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     agg = aggregate(elapsed, world, args.steps, reduce_max, inflight)
     ms_per_proof = 1e3 / (agg["value"] / world)        # per-GPU time per proof at this throughput
     # the rounds 1-3 form of the driver's command: 20 single proofs after 5, a 30 ms region that starts and ends drained
@@ -577,6 +583,7 @@ def main(argv=None):
                    "proof_bytes": len(out["proof"])},
         "prove_latency_ms": latency_ms,
         "prove_latency_p95_ms": latency_p95_ms,
+        "host_cpu_ms_per_proof": round(1e3 * host_cpu_s / max(1, (args.steps + args.warmup) * inflight), 3),
         "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         "roofline": roofline,
         "roofline_other": roofline_other,
