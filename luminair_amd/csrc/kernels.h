@@ -146,6 +146,16 @@ struct FriTailLayer {
 void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
                      uint32_t* roots_out, lmn_stream_t s);
 
+// ---- twiddle tables on the device (a11): entry h of a table of 2^bits entries is the y (coord 0) or x (coord 1)
+// coordinate of the point init + bit_reverse(h, bits) * step of a half coset; sx / sy = step * 2^k.  Four forms are written:
+// the value, its inverse, and both doubled (TwPtrs::d).
+struct TwGen {
+  uint32_t ix, iy;
+  uint32_t sx[30], sy[30];
+};
+void launch_twiddles(int bits, const TwGen& g, int coord, uint32_t* tw, uint32_t* itw, uint32_t* tw2, uint32_t* itw2,
+                     lmn_stream_t s);
+
 // ---- gather: out[dst_off[e] + k] = arena[src_off[e] + k], k < len[e]
 struct GatherEntry {
   uint64_t src_off;  // word offset into arena

@@ -1763,6 +1763,36 @@ void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, i
 }
 
 // =============================================================================================
+// a11  twiddle tables: the points of a half coset by double-and-add from the step's doublings (<= 26 group additions per
+// entry) instead of a serial walk on the host - 2^26 entries and their inverses in milliseconds
+// =============================================================================================
+LMN_KERNEL k_twiddles(int bits, TwGen g, int coord, uint32_t* __restrict__ tw, uint32_t* __restrict__ itw,
+                      uint32_t* __restrict__ tw2, uint32_t* __restrict__ itw2) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= (1u << bits)) return;
+  const uint32_t j = bits ? (__brev(h) >> (32 - bits)) : 0u;
+  uint32_t x = g.ix, y = g.iy;
+  for (int k = 0; k < bits; ++k) {
+    if ((j >> k) & 1u) {
+      const uint32_t nx = m_sub(m_mul(x, g.sx[k]), m_mul(y, g.sy[k]));
+      y = m_add(m_mul(x, g.sy[k]), m_mul(y, g.sx[k]));
+      x = nx;
+    }
+  }
+  const uint32_t v = coord ? x : y, vi = m_inv(v);
+  tw[h] = v;
+  itw[h] = vi;
+  tw2[h] = 2u * v;
+  itw2[h] = 2u * vi;
+}
+
+void launch_twiddles(int bits, const TwGen& g, int coord, uint32_t* tw, uint32_t* itw, uint32_t* tw2, uint32_t* itw2,
+                     lmn_stream_t s) {
+  if (bits < 0 || bits > 29) throw LmnError(-100, "twiddles: bad size");
+  LMN_LAUNCH(k_twiddles, dim3(cdiv(1ull << bits, TPB)), dim3(TPB), 0, s, bits, g, coord, tw, itw, tw2, itw2);
+}
+
+// =============================================================================================
 // gather
 // =============================================================================================
 LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,

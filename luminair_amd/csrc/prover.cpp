@@ -9,6 +9,8 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <set>
 
 namespace lmn {
@@ -456,6 +458,91 @@ void Context::trace_contiguous(const int32_t* input, uint64_t in_size, const lmn
 //   Y[m][h] = y(half_coset_m.at(bitrev(h, m-1))), h < 2^(m-1)      (layer 0 of domain m)
 //   X[k][h] = x(half_coset_k.at(bitrev(h, k-2))), h < 2^(k-2)      (layer 1 of domain k)
 // Layer i >= 1 of domain m is X[m-i+1] (doubling a canonic half coset gives the next smaller one).
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
+// Twiddle tables are a function of the domain size alone: one set per device, built on the device (k_twiddles) and shared by
+// every context of the process.  The registry holds weak references - the last context that goes away frees the tables -
+// and a context that needs a larger domain than the current set builds a new one (the contexts still using the old one
+// keep it alive).  The batch library's members run in lock-step (no member may skip launches another one makes) and the
+// emulation build has no device: both keep one host-built set per context (below).
+namespace {
+struct TwiddleSet {
+  int device = 0, max_log = 0;
+  void* slab = nullptr;
+  std::vector<uint32_t*> Y, X, iY, iX, Y2, X2, iY2, iX2;
+  ~TwiddleSet() {
+    if (slab) {
+      (void)hipSetDevice(device);
+      (void)hipFree(slab);
+    }
+  }
+};
+std::mutex g_tw_mu;
+std::map<int, std::weak_ptr<TwiddleSet>> g_tw;
+}  // namespace
+
+void Context::ensure_twiddles(int M) {
+  if (M <= tw_max_log_) return;
+  if (M > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
+  std::lock_guard<std::mutex> lk(g_tw_mu);
+  std::shared_ptr<TwiddleSet> set = g_tw[device_].lock();
+  if (!set || set->max_log < M) {
+    set = std::make_shared<TwiddleSet>();
+    set->device = device_;
+    set->max_log = M;
+    // 8 tables per size (y and x coordinate; value / inverse / both doubled), each at a 256-byte boundary
+    auto slot = [](uint64_t words) { return (words + 63) & ~(uint64_t)63; };
+    uint64_t total = 0;
+    for (int m = 1; m <= M; ++m) total += 4 * slot(1ull << (m - 1)) + (m >= 2 ? 4 * slot(1ull << (m - 2)) : 0);
+    set->slab = lmn_dev_malloc(total * 4);
+    uint32_t* at = (uint32_t*)set->slab;
+    auto take = [&](uint64_t words) {
+      uint32_t* p = at;
+      at += slot(words);
+      return p;
+    };
+    for (auto* v : {&set->Y, &set->X, &set->iY, &set->iX, &set->Y2, &set->X2, &set->iY2, &set->iX2}) v->assign(M + 1, nullptr);
+    for (int m = M; m >= 1; --m) {
+      // half coset of CanonicCoset(m): initial index 2^(30-m), step 2^(32-m), 2^(m-1) points
+      TwGen g{};
+      const Pt init = pt_of_index(1u << (30 - m));
+      g.ix = init.x;
+      g.iy = init.y;
+      Pt st = pt_of_index(m >= 2 ? (1u << (32 - m)) : 0u);
+      for (int k = 0; k < 30; ++k) {
+        g.sx[k] = st.x;
+        g.sy[k] = st.y;
+        st = pt_double(st);
+      }
+      const uint64_t half = 1ull << (m - 1);
+      set->Y[m] = take(half);
+      set->iY[m] = take(half);
+      set->Y2[m] = take(half);
+      set->iY2[m] = take(half);
+      launch_twiddles(m - 1, g, 0, set->Y[m], set->iY[m], set->Y2[m], set->iY2[m], stream_);
+      if (m >= 2) {
+        const uint64_t quarter = 1ull << (m - 2);
+        set->X[m] = take(quarter);
+        set->iX[m] = take(quarter);
+        set->X2[m] = take(quarter);
+        set->iX2[m] = take(quarter);
+        launch_twiddles(m - 2, g, 1, set->X[m], set->iX[m], set->X2[m], set->iX2[m], stream_);
+      }
+    }
+    lmn_sync(stream_);   // every stream of the process may read the tables from here on
+    g_tw[device_] = set;
+  }
+  twY_ = set->Y;
+  twX_ = set->X;
+  itwY_ = set->iY;
+  itwX_ = set->iX;
+  twY2_ = set->Y2;
+  twX2_ = set->X2;
+  itwY2_ = set->iY2;
+  itwX2_ = set->iX2;
+  tw_max_log_ = set->max_log;
+  tw_shared_ = set;
+}
+#else
 void Context::ensure_twiddles(int M) {
   if (M <= tw_max_log_) return;
   if (M > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
@@ -522,6 +609,7 @@ void Context::ensure_twiddles(int M) {
   }
   tw_max_log_ = M;
 }
+#endif
 
 TwPtrs Context::tw(int m) const {
   TwPtrs t{};

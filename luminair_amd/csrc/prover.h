@@ -315,6 +315,7 @@ class Context {
   std::vector<uint32_t*> twY_, twX_, itwY_, itwX_;
   std::vector<uint32_t*> twY2_, twX2_, itwY2_, itwX2_;  // the same tables, entries doubled (TwPtrs::d)
   std::vector<void*> tw_allocs_;
+  std::shared_ptr<void> tw_shared_;   // the device's twiddle set, shared by the contexts of a process (prover.cpp)
   friend struct StageTimer;
 };
 
