@@ -488,6 +488,46 @@ def test_gpu_tree_storage_thresholds_equal_c_oracle_bytes(gpu_prover, gpu_prover
     assert len(got) == len(want) and _sha(got) == _sha(want), name
 
 
+_TWIDDLE_LIFETIME_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1])
+import luminair_amd
+from luminair_amd import synthetic as syn
+sha = lambda p, t: hashlib.sha256(p.prove(luminair_amd.LuminairPie.from_tables(t)).to_bincode()).hexdigest()
+small, big = syn.config2_add_only(1 << 10, 31), syn.config2_add_only(1 << 15, 32)
+a = luminair_amd.Prover(0)
+want_small = sha(a, small)                 # a builds the process's first set: enough for 2^10 rows
+b = luminair_amd.Prover(0)
+want_big = sha(b, big)                     # b needs a larger one and builds it
+assert sha(a, small) == want_small         # a still works on the set it holds
+assert sha(a, big) == want_big             # ... and moves to the larger set
+b.ctx.close()                              # the builder of the larger set goes away
+assert sha(a, big) == want_big and sha(a, small) == want_small
+c = luminair_amd.Prover(0)
+assert sha(c, big) == want_big
+a.ctx.close()
+assert sha(c, small) == want_small
+c.ctx.close()
+d = luminair_amd.Prover(0)                 # every holder is gone: the registry's weak reference has expired, d builds anew
+assert sha(d, small) == want_small and sha(d, big) == want_big
+print(want_small, want_big)
+"""
+
+
+def test_gpu_twiddle_sets_are_shared_and_outlive_their_builder(gpu_prover, root):
+    """The twiddle tables are one set per device, shared by the contexts of the process and replaced by a larger set when a
+    context needs one (prover.cpp `ensure_twiddles`).  In a fresh process: a context keeps proving with the set it holds
+    after the context that built it is gone, moves to a larger set built by someone else, a set is rebuilt after all of its
+    holders are gone - and every context yields the bytes this process's prover gives for the same tables."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _TWIDDLE_LIFETIME_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got_small, got_big = r.stdout.split()[-2:]
+    assert got_small == _sha(_gpu_bytes(gpu_prover, syn.config2_add_only(1 << 10, 31)))
+    assert got_big == _sha(_gpu_bytes(gpu_prover, syn.config2_add_only(1 << 15, 32)))
+
+
 def test_gpu_storage_and_fusion_switches_do_not_change_the_proof(gpu_prover, monkeypatch):
     """The forms this round replaced stay selectable for measurements (LMN_MERKLE_FULL: every tree level written;
     LMN_MERKLE_BELOW_MIN_LOG=99: separate leaf launch under a column level; LMN_NO_JOIN_FUSION: a joining quotient column
