@@ -71,6 +71,30 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_budget():
+    """CPUs this process may use: the affinity mask, cut by the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota)"""
+    try:
+        n = float(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        n = float(os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is None:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                quota = q / per if q > 0 else None
+            else:
+                quota = parse(txt)
+            if quota:
+                n = min(n, quota)
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return n
+
+
 def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -311,6 +335,13 @@ def main(argv=None):
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if args.shard_proof:
         return shard_proof_main(args, rank, local_rank, world)
+    # N ranks x `inflight` polling contexts in one CPU-limited container starve each other's launch threads (a rank held to
+    # 2 CPUs loses 10 - 20 %, profiles/r4_host_cpu_wait_policy.jsonl): when the node's CPU budget is below what the default needs - a
+    # rank's ~3.4 busy CPUs, the library's waits sleep between polls from the start (LMN_SPIN_US=0: 1.7 CPUs per rank, - 1 %
+    # proofs/s where CPUs are plentiful).  Set before the library is loaded; an explicit LMN_SPIN_US wins.
+    budget = cpu_budget()
+    if world > 1 and budget < 4 * world:
+        os.environ.setdefault("LMN_SPIN_US", "0")
     import numpy as np
     import torch
     import luminair_amd
@@ -580,6 +611,7 @@ def main(argv=None):
                    "parallelism": "proof-sharded x%d" % world,
                    "proofs_in_flight_per_gpu": inflight, "ranks_in_process_group": ranks_seen,
                    "collective_backend": ("nccl (RCCL)" if has_cuda else "gloo") if use_dist else None,
+                   "host_cpu_budget": round(budget, 1), "host_wait_spin_us": os.environ.get("LMN_SPIN_US", "1200 (default)"),
                    "proof_bytes": len(out["proof"])},
         "prove_latency_ms": latency_ms,
         "prove_latency_p95_ms": latency_p95_ms,
