@@ -25,11 +25,11 @@ extern "C" {
 #endif
 
 /* ABI version of this header.  It is bumped whenever a struct crossing the boundary changes size or layout (4: lmn_view
- * gained `offset`, 56 -> 64 bytes).  A caller compares LMN_API_VERSION (what it was compiled against) with
+ * gained `offset`, 56 -> 64 bytes; 6: `protocol_variant` became a set of LMN_PV_* bits, LMN_VARIANT_PINNED 1 -> 0x1f).  A caller compares LMN_API_VERSION (what it was compiled against) with
  * lmn_abi_version() (what the loaded library implements) once at start-up; luminair_amd/backend.py does.
  * Structs passed in (lmn_view, lmn_node_info, lmn_settings, lmn_config) must be zero-initialised before their fields
  * are set, so that fields added by a later version read as 0. */
-#define LMN_API_VERSION 5
+#define LMN_API_VERSION 6
 uint32_t lmn_abi_version(void);
 
 /* Error codes mirror LuminairError (/root/reference/crates/utils/src/lib.rs:5-34). */
@@ -65,11 +65,45 @@ uint32_t lmn_abi_version(void);
 #define LMN_KIND_INPUTS 15
 #define LMN_KIND_CONTIGUOUS 16
 
-/* Protocol variants (SURVEY.md §8c "known deltas"): 0 = the variant pinned by the reference's only
- * known-answer proof (ui/demo/public/proof); 1 = LuminAIR HEAD claim layout + Inputs component,
- * channel encodings unverified ("parity unpinned"). */
-#define LMN_VARIANT_KAT 0
-#define LMN_VARIANT_PINNED 1
+/* Protocol flags (SURVEY.md §8c "known deltas KAT-era -> pinned rev"; Appendix A.3).  The reference's only known-answer
+ * proof (ui/demo/public/proof) was made by an older LuminAIR / stwo than the sources at HEAD; every observable
+ * difference between the two is ONE independent bit of `lmn_config.protocol_variant` (since ABI version 6; before, the
+ * field was an enum 0 / 1), so that a proof made by any build of the reference can be pinned by search
+ * (tools/pin_variant.py tries every combination through lmn_verify_diagnose).  All bits clear = the KAT protocol, every
+ * byte of which is pinned.  LMN_VARIANT_PINNED = what the reference at HEAD is believed to run; its transcript bits are
+ * from memory of the un-vendored stwo ("parity unpinned").
+ *
+ * Transcript bits:
+ *   CLAIM17        LuminairClaim / LuminairInteractionClaim have 17 Option slots (crates/air/src/lib.rs:30-48) instead of 8
+ *   LUT_DRAWS4     LookupElements::draw draws sin, exp2, log2, range_check (lookups/mod.rs:44-51) instead of one LUT relation
+ *   MIX_U64_HASHED mix_u64(v) = blake2s(digest || lo32 LE || hi32 LE) instead of the bare compression function on [lo, hi, 0..]
+ *   DRAW_CTR_U32   draw = blake2s(digest || counter u32 LE || 0x00) instead of digest || counter zero-padded to 32 bytes
+ *   POW_PREFIXED   proof of work = trailing zeros of blake2s(blake2s(0x12345678 LE || 12 zero bytes || digest || pow_bits LE)
+ *                  || nonce u64 LE), nonce then mixed with mix_u64 - instead of the trailing zeros of the digest after
+ *                  mix_u64(nonce)
+ * Constraint-form bits (numerair's `eval_fixed_*` helpers are un-vendored; the KAT pins eval_fixed_add and the first
+ * eval_fixed_mul constraint, and that eval_fixed_mul occupies two constraint slots):
+ *   MUL_ONE_SLOT   eval_fixed_mul emits one constraint (KAT: two, the second contributing zero whenever rem == 0)
+ *   RECIP_/SQRT_/REM_TWO_SLOTS  the helper emits a second (zero) slot as KAT-era eval_fixed_mul does (default: one)
+ *   RECIP_/SQRT_/REM_NEG        the helper's constraint has the opposite sign: input*out + rem - scale^2,
+ *                  out^2 + rem - input*scale, rhs*quotient + rem - lhs (default: scale^2 - (input*out + rem), ...) */
+#define LMN_PV_CLAIM17 0x0001u
+#define LMN_PV_LUT_DRAWS4 0x0002u
+#define LMN_PV_MIX_U64_HASHED 0x0004u
+#define LMN_PV_DRAW_CTR_U32 0x0008u
+#define LMN_PV_POW_PREFIXED 0x0010u
+#define LMN_PV_MUL_ONE_SLOT 0x0100u
+#define LMN_PV_RECIP_TWO_SLOTS 0x0200u
+#define LMN_PV_RECIP_NEG 0x0400u
+#define LMN_PV_SQRT_TWO_SLOTS 0x0800u
+#define LMN_PV_SQRT_NEG 0x1000u
+#define LMN_PV_REM_TWO_SLOTS 0x2000u
+#define LMN_PV_REM_NEG 0x4000u
+#define LMN_PV_TRANSCRIPT_MASK 0x001fu
+#define LMN_PV_FORMS_MASK 0x7f00u
+#define LMN_PV_ALL (LMN_PV_TRANSCRIPT_MASK | LMN_PV_FORMS_MASK)
+#define LMN_VARIANT_KAT 0u
+#define LMN_VARIANT_PINNED LMN_PV_TRANSCRIPT_MASK
 
 /* Replaces PcsConfig::default() (prover.rs:36) + DEFAULT_FP_SCALE (crates/air/src/lib.rs:23-24). */
 typedef struct lmn_config {
@@ -78,7 +112,7 @@ typedef struct lmn_config {
   uint32_t log_last_layer;   /* default 0 */
   uint32_t n_queries;        /* default 3 */
   uint32_t fp_scale;         /* default 12 */
-  uint32_t protocol_variant; /* LMN_VARIANT_* */
+  uint32_t protocol_variant; /* OR of LMN_PV_* bits: LMN_VARIANT_KAT (0), LMN_VARIANT_PINNED, or any combination */
 } lmn_config;
 
 #define LMN_TABLE_ROWS_ON_DEVICE 1u
@@ -135,6 +169,16 @@ typedef struct lmn_range {
 int lmn_lut_log_size(const lmn_range* ranges, uint32_t n_ranges, uint32_t* log_size_out);
 int lmn_lut_from_ranges(uint32_t lut_kind /* LMN_LUT_* */, const lmn_range* ranges, uint32_t n_ranges, uint32_t log_size,
                         uint32_t* col0_out, uint32_t* col1_out);
+/* The same with the f64 -> Fixed rounding stated (since ABI version 6; `Fixed::from_f64` is in the un-vendored numerair,
+ * so the rule is one of the axes tools/pin_variant.py searches when it is given the reference's preprocessed root):
+ * HALF_AWAY = `f64::round` (what lmn_lut_from_ranges uses), HALF_EVEN = round-half-to-even, TRUNC = `as i64` (towards
+ * zero), FLOOR = `f64::floor`. */
+#define LMN_ROUND_HALF_AWAY 0u
+#define LMN_ROUND_HALF_EVEN 1u
+#define LMN_ROUND_TRUNC 2u
+#define LMN_ROUND_FLOOR 3u
+int lmn_lut_from_ranges_r(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_ranges, uint32_t log_size, uint32_t rounding,
+                          uint32_t* col0_out, uint32_t* col1_out);
 
 typedef struct lmn_ctx lmn_ctx;
 
@@ -193,7 +237,7 @@ int lmn_get_timings(const lmn_ctx* ctx, lmn_timings* out);
  * Host-only (the reference verifier is CPU code too); needs no context and no GPU.  Returns LMN_OK,
  * LMN_ERR_INVALID_LOGUP, LMN_ERR_VERIFICATION or LMN_ERR_SERIALIZATION; the message of the last
  * failure on this thread is available through lmn_last_error(NULL). */
-int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant);
+int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant /* LMN_PV_* bits */);
 /* lmn_verify checks the proof against PcsConfig::default() (pow 5, blow-up 2, 3 queries, last layer degree 0), as
  * verifier.rs:36 does; a deployment with other parameters states them here.  The security parameters are the
  * verifier's: a proof whose embedded config differs from `expected` is rejected (LMN_ERR_VERIFICATION).  Field
@@ -203,6 +247,62 @@ int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_setting
  * like the reference, the verifier takes the preprocessed root from the proof). */
 int lmn_verify_with_config(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings,
                            const lmn_config* expected);
+
+/* lmn_verify that does not stop at the first failed check (since ABI version 6): the replay goes on as far as the
+ * proof's shape allows and reports which checks passed.  The checks depend on different parts of the protocol, which
+ * is what makes a proof from an unknown build of the reference diagnosable (tools/pin_variant.py runs this for every
+ * combination of LMN_PV_* bits):
+ *   PARSE          the bytes deserialize under the claim layout (CLAIM17) - LMN_ERR_SERIALIZATION otherwise
+ *   SHAPE          tree / sampled-value / FRI-layer counts are what the claim implies
+ *   LOGUP_SUM      the claimed sums cancel (no transcript dependence)
+ *   OODS           composition identity at the OODS point: transcript up to the OODS draw (claim mix, relation draws,
+ *                  composition randomness) AND every constraint form of the components present
+ *   POW            proof-of-work nonce: the whole transcript up to the nonce; pow_bits bits of evidence only
+ *   TREE_DECOMMIT  the four trace trees' decommitments at the drawn query positions: the whole transcript including
+ *                  the query draw, and the Merkle hashing; independent of the constraint forms
+ *   FRI_DECOMMIT   the FRI layers' decommitments (same dependence)
+ *   FRI_FOLDS      FRI quotients from sampled + queried values fold to the last layer: OODS point, quotient and fold
+ *                  randomness; independent of the constraint forms
+ * `steps` records the channel digest after every mix of the replay, in order (a maintainer prints the same digests from
+ * the Rust prover to find the first diverging step).  Returns LMN_OK when the replay ran to the end (whatever the checks
+ * said), else the error that stopped it (its text in `first_failure` if no check had failed before).  `report` is
+ * always filled as far as the replay got. */
+#define LMN_CHECK_PARSE 0x0001u
+#define LMN_CHECK_SHAPE 0x0002u
+#define LMN_CHECK_LOGUP_SUM 0x0004u
+#define LMN_CHECK_OODS 0x0008u
+#define LMN_CHECK_POW 0x0010u
+#define LMN_CHECK_TREE_DECOMMIT 0x0020u
+#define LMN_CHECK_FRI_DECOMMIT 0x0040u
+#define LMN_CHECK_FRI_FOLDS 0x0080u
+#define LMN_CHECK_ALL 0x00ffu
+#define LMN_STEP_ROOT_PREPROCESSED 0u /* mix_root(commitments[0]), prover.rs:59 */
+#define LMN_STEP_CLAIM 1u             /* LuminairClaim::mix_into, crates/air/src/lib.rs:52-104 */
+#define LMN_STEP_ROOT_MAIN 2u         /* prover.rs:179 */
+#define LMN_STEP_INTERACTION_CLAIM 3u /* mix_felts(claimed_sum) per component, components/mod.rs:209-211 */
+#define LMN_STEP_ROOT_INTERACTION 4u  /* prover.rs:298 */
+#define LMN_STEP_ROOT_COMPOSITION 5u  /* inside stwo::prover::prove, prover.rs:312 */
+#define LMN_STEP_SAMPLED_VALUES 6u
+#define LMN_STEP_FRI_FIRST_LAYER 7u
+#define LMN_STEP_FRI_INNER_LAYER 8u   /* index = layer number */
+#define LMN_STEP_FRI_LAST_LAYER 9u
+#define LMN_STEP_POW_NONCE 10u
+#define LMN_MAX_TRANSCRIPT_STEPS 48
+typedef struct lmn_transcript_step {
+  uint32_t step;  /* LMN_STEP_* */
+  uint32_t index;
+  uint8_t digest[32];
+} lmn_transcript_step;
+typedef struct lmn_verify_report {
+  uint32_t checks_run;    /* LMN_CHECK_* bits of the checks the replay reached */
+  uint32_t checks_passed; /* ... that held */
+  uint32_t checks_failed; /* ... that did not (a check with several parts fails if any part does) */
+  uint32_t n_steps;
+  lmn_transcript_step steps[LMN_MAX_TRANSCRIPT_STEPS];
+  char first_failure[128]; /* text of the first failed check or of the error that stopped the replay */
+} lmn_verify_report;
+int lmn_verify_diagnose(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings,
+                        const lmn_config* expected, lmn_verify_report* report);
 
 /* Page-locked host memory for tables handed over as HOST buffers (`lmn_table.rows` without LMN_TABLE_ROWS_ON_DEVICE -
  * the reference's own calling convention: `prove(pie, settings)` takes the pie by value in host memory,
@@ -376,7 +476,8 @@ int lmn_op_fold_line(lmn_ctx* ctx, const uint32_t* src, uint32_t log_src, const 
 /* FriOps::fold_circle_into_line: dst (4 x 2^(log_src-1), in/out) = dst * alpha^2 + fold(src), src on the
  * canonic circle domain of log_src. */
 int lmn_op_fold_circle_into_line(lmn_ctx* ctx, uint32_t* dst, const uint32_t* src, uint32_t log_src, const uint32_t alpha[4]);
-/* GrindOps::grind: smallest nonce whose mix_u64 into `digest` leaves >= pow_bits trailing zero bits (host). */
+/* GrindOps::grind: smallest nonce accepted by the proof-of-work check of `protocol_variant` (LMN_PV_POW_PREFIXED,
+ * LMN_PV_MIX_U64_HASHED) on channel state `digest` (host). */
 int lmn_op_grind(const uint8_t digest[32], uint32_t pow_bits, uint32_t protocol_variant, uint64_t* nonce_out);
 /* PolyOps::evaluate restricted to one aligned block of rows (single-commitment sharding over GPUs):
  * rows [block * 2^(log_domain - log_blocks), (block + 1) * 2^(log_domain - log_blocks)) of every column's
@@ -464,9 +565,16 @@ int lmn_col_logup(lmn_ctx* ctx, uint32_t kind, const lmn_col* main, const lmn_co
 int lmn_col_composition(lmn_ctx* ctx, uint32_t kind, const lmn_col* main_lde, const lmn_col* inter_lde,
                         const lmn_col* pre_lde, const uint32_t* elems, const uint32_t claimed_sum[4],
                         const uint32_t* coeffs, uint32_t n_coeffs, lmn_col* acc);
-/* number of constraints of component `kind` (local + one per relation) and of its relations */
+/* number of constraint slots the kernels of component `kind` emit (local + one per relation; the KAT-era shape:
+ * eval_fixed_mul two slots, eval_fixed_recip / _sqrt / _rem one) and of its relations */
 uint32_t lmn_kind_constraints(uint32_t kind);
 uint32_t lmn_kind_relations(uint32_t kind);
+/* Those slots under the constraint-form bits of `protocol_flags` (LMN_PV_*_SLOT(S), LMN_PV_*_NEG; since ABI version 6):
+ * proto_index_out[k] = index of kernel slot k among the component's constraints in the protocol (-1: the protocol has no
+ * such constraint, its coefficient is 0), sign_out[k] = +1 / -1 (the coefficient of slot k is sign * alpha^(N-1-i) for
+ * global constraint index i); 16 entries each.  Returns the number of constraints the component contributes to the
+ * composition polynomial under these flags (0: unsupported kind).  What lmn_col_composition's caller builds `coeffs` from. */
+uint32_t lmn_kind_constraint_layout(uint32_t kind, uint32_t protocol_flags, int32_t proto_index_out[16], int32_t sign_out[16]);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,28 @@ LMN_OK = 0
 ERR_EMPTY_TRACE, ERR_MAIN_TRACE, ERR_INTERACTION_TRACE, ERR_CONSTRAINTS = -1, -2, -3, -4
 ERR_SERIALIZATION, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_INTERNAL = -5, -6, -7, -8, -100
 ERR_VERIFICATION, ERR_INVALID_LOGUP = -9, -10
-VARIANT_KAT, VARIANT_PINNED = 0, 1
+# lmn_config.protocol_variant: OR of LMN_PV_* bits (include/luminair_hip.h).  All clear = the protocol of the reference's
+# known-answer proof; VARIANT_PINNED = what the reference at HEAD is believed to run (transcript bits from memory of the
+# un-vendored stwo: unpinned).  tools/pin_variant.py finds the combination a given proof was made with.
+PV_CLAIM17, PV_LUT_DRAWS4, PV_MIX_U64_HASHED, PV_DRAW_CTR_U32, PV_POW_PREFIXED = 0x1, 0x2, 0x4, 0x8, 0x10
+PV_MUL_ONE_SLOT, PV_RECIP_TWO_SLOTS, PV_RECIP_NEG, PV_SQRT_TWO_SLOTS, PV_SQRT_NEG, PV_REM_TWO_SLOTS, PV_REM_NEG = (
+    0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000)
+PV_TRANSCRIPT_MASK, PV_FORMS_MASK = 0x1f, 0x7f00
+PV_NAMES = {PV_CLAIM17: "claim17", PV_LUT_DRAWS4: "lut_draws4", PV_MIX_U64_HASHED: "mix_u64_hashed",
+            PV_DRAW_CTR_U32: "draw_ctr_u32", PV_POW_PREFIXED: "pow_prefixed", PV_MUL_ONE_SLOT: "mul_one_slot",
+            PV_RECIP_TWO_SLOTS: "recip_two_slots", PV_RECIP_NEG: "recip_neg", PV_SQRT_TWO_SLOTS: "sqrt_two_slots",
+            PV_SQRT_NEG: "sqrt_neg", PV_REM_TWO_SLOTS: "rem_two_slots", PV_REM_NEG: "rem_neg"}
+VARIANT_KAT, VARIANT_PINNED = 0, PV_TRANSCRIPT_MASK
+CHECK_PARSE, CHECK_SHAPE, CHECK_LOGUP_SUM, CHECK_OODS, CHECK_POW, CHECK_TREE_DECOMMIT, CHECK_FRI_DECOMMIT, CHECK_FRI_FOLDS = (
+    1, 2, 4, 8, 16, 32, 64, 128)
+CHECK_ALL = 0xff
+CHECK_NAMES = {CHECK_PARSE: "parse", CHECK_SHAPE: "shape", CHECK_LOGUP_SUM: "logup_sum", CHECK_OODS: "oods",
+               CHECK_POW: "pow", CHECK_TREE_DECOMMIT: "tree_decommit", CHECK_FRI_DECOMMIT: "fri_decommit",
+               CHECK_FRI_FOLDS: "fri_folds"}
+STEP_NAMES = ["root_preprocessed", "claim", "root_main", "interaction_claim", "root_interaction", "root_composition",
+              "sampled_values", "fri_first_layer", "fri_inner_layer", "fri_last_layer", "pow_nonce"]
+ROUND_HALF_AWAY, ROUND_HALF_EVEN, ROUND_TRUNC, ROUND_FLOOR = 0, 1, 2, 3
+MAX_TRANSCRIPT_STEPS = 48
 TABLE_ROWS_ON_DEVICE = 1
 
 
@@ -99,7 +120,19 @@ class LmnTimings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-API_VERSION = 5   # LMN_API_VERSION of include/luminair_hip.h
+class LmnTranscriptStep(C.Structure):
+    _fields_ = [("step", C.c_uint32), ("index", C.c_uint32), ("digest", C.c_uint8 * 32)]
+
+
+class LmnVerifyReport(C.Structure):
+    """`lmn_verify_report`: which checks of the verifier a proof passes under one set of protocol flags, and the
+    channel digest after every mix of the replay."""
+    _fields_ = [("checks_run", C.c_uint32), ("checks_passed", C.c_uint32), ("checks_failed", C.c_uint32),
+                ("n_steps", C.c_uint32), ("steps", LmnTranscriptStep * MAX_TRANSCRIPT_STEPS),
+                ("first_failure", C.c_char * 128)]
+
+
+API_VERSION = 6   # LMN_API_VERSION of include/luminair_hip.h
 
 EXPORTS = ["lmn_abi_version", "lmn_kind_padding_row", "lmn_strerror", "lmn_last_error", "lmn_default_config", "lmn_kind_columns", "lmn_ctx_create",
            "lmn_ctx_destroy", "lmn_prove", "lmn_prove_submit", "lmn_prove_wait", "lmn_free", "lmn_get_timings", "lmn_set_profiling", "lmn_upload", "lmn_device_free", "lmn_verify",
@@ -108,7 +141,7 @@ EXPORTS = ["lmn_abi_version", "lmn_kind_padding_row", "lmn_strerror", "lmn_last_
            "lmn_op_fft_selftest", "lmn_op_accumulate_quotients", "lmn_op_fold_line", "lmn_op_fold_circle_into_line",
            "lmn_op_grind", "lmn_device_alloc", "lmn_download", "lmn_trace_elementwise", "lmn_trace_sum_reduce",
            "lmn_trace_elementwise_v", "lmn_trace_contiguous", "lmn_trace_lut", "lmn_trace_lut_ranges", "lmn_trace_less_than", "lmn_trace_max_reduce", "lmn_upload_to", "lmn_device_copy", "lmn_op_evaluate_block",
-           "lmn_verify_with_config", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
+           "lmn_verify_with_config", "lmn_verify_diagnose", "lmn_kind_constraint_layout", "lmn_lut_log_size", "lmn_lut_from_ranges", "lmn_lut_from_ranges_r", "lmn_col_alloc", "lmn_col_from_cpu", "lmn_col_to_cpu", "lmn_col_free", "lmn_col_ncols",
            "lmn_col_log_size", "lmn_col_device_ptr", "lmn_col_view", "lmn_col_bit_reverse", "lmn_col_precompute_twiddles",
            "lmn_col_interpolate", "lmn_col_evaluate", "lmn_col_evaluate_block", "lmn_col_extend", "lmn_col_eval_at_point",
            "lmn_col_commit", "lmn_tree_root", "lmn_tree_log_size", "lmn_tree_layer_to_cpu", "lmn_tree_free",
@@ -188,6 +221,12 @@ class Library:
         lib.lmn_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.lmn_lut_log_size.argtypes = [C.POINTER(LmnRange), C.c_uint32, C.POINTER(C.c_uint32)]
         lib.lmn_lut_from_ranges.argtypes = [C.c_uint32, C.POINTER(LmnRange), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lmn_lut_from_ranges_r.argtypes = [C.c_uint32, C.POINTER(LmnRange), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_void_p]
+        lib.lmn_verify_diagnose.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(LmnSettings), C.POINTER(LmnConfig),
+                                            C.POINTER(LmnVerifyReport)]
+        lib.lmn_kind_constraint_layout.restype = C.c_uint32
+        lib.lmn_kind_constraint_layout.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         VP, U32 = C.c_void_p, C.c_uint32
         lib.lmn_col_alloc.argtypes = [VP, U32, U32, C.POINTER(VP)]
         lib.lmn_col_from_cpu.argtypes = [VP, VP, U32, U32, C.POINTER(VP)]
@@ -317,6 +356,28 @@ class Library:
         if rc != LMN_OK:
             msg = self.lib.lmn_last_error(None).decode() or self.lib.lmn_strerror(rc).decode()
             raise LuminairBackendError(rc, msg)
+
+
+    def diagnose(self, proof: bytes, variant: int, config: Optional[LmnConfig] = None,
+                 settings: Optional[LmnSettings] = None):
+        """`lmn_verify_diagnose`: (return code, LmnVerifyReport) - which verifier checks `proof` passes under the
+        protocol flags `variant`, without stopping at the first failure."""
+        cfg = LmnConfig()
+        if config is not None:
+            C.memmove(C.byref(cfg), C.byref(config), C.sizeof(LmnConfig))
+        else:
+            self.lib.lmn_default_config(C.byref(cfg))
+        cfg.protocol_variant = variant
+        rep = LmnVerifyReport()
+        sp = C.byref(settings) if settings is not None else None
+        rc = self.lib.lmn_verify_diagnose(proof, len(proof), sp, C.byref(cfg), C.byref(rep))
+        return rc, rep
+
+    def constraint_layout(self, kind: int, variant: int):
+        """(n_protocol, proto_index[16], sign[16]) of `lmn_kind_constraint_layout`."""
+        pi, sg = (C.c_int32 * 16)(), (C.c_int32 * 16)()
+        n = int(self.lib.lmn_kind_constraint_layout(kind, variant, pi, sg))
+        return n, list(pi), list(sg)
 
 
 _default_library: Optional[Library] = None

@@ -245,6 +245,17 @@ int lmn_verify_with_config(const uint8_t* proof_bincode, size_t proof_len, const
   return rc;
 }
 
+int lmn_verify_diagnose(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings,
+                        const lmn_config* expected, lmn_verify_report* report) {
+  if (!proof_bincode || !expected || !report) return LMN_ERR_INVALID_ARGUMENT;
+  memset(report, 0, sizeof *report);
+  lmn_ctx tmp{nullptr, {}};
+  int rc = guard(&tmp, [&] { lmn::verify_proof(proof_bincode, proof_len, *expected, settings, report); });
+  if (rc != LMN_OK && !report->first_failure[0]) snprintf(report->first_failure, sizeof report->first_failure, "%s", tmp.last_error.c_str());
+  g_create_error = tmp.last_error;
+  return rc;
+}
+
 int lmn_verify(const uint8_t* proof_bincode, size_t proof_len, const lmn_settings* settings, uint32_t protocol_variant) {
   lmn_config c;
   lmn_default_config(&c);  // PcsConfig::default(), as the reference verifier hard-codes it
@@ -332,7 +343,7 @@ int lmn_op_fold_circle_into_line(lmn_ctx* ctx, uint32_t* dst, const uint32_t* sr
 }
 
 int lmn_op_grind(const uint8_t digest[32], uint32_t pow_bits, uint32_t protocol_variant, uint64_t* nonce_out) {
-  if (!digest || !nonce_out || pow_bits > 40 || protocol_variant > LMN_VARIANT_PINNED) return LMN_ERR_INVALID_ARGUMENT;
+  if (!digest || !nonce_out || pow_bits > 40 || (protocol_variant & ~LMN_PV_ALL)) return LMN_ERR_INVALID_ARGUMENT;
   lmn::Channel ch(protocol_variant);
   lmn::Hash32 d;
   memcpy(d.w, digest, 32);
@@ -481,7 +492,13 @@ int lmn_lut_log_size(const lmn_range* ranges, uint32_t n_ranges, uint32_t* log_s
 }
 int lmn_lut_from_ranges(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_ranges, uint32_t log_size, uint32_t* col0_out,
                         uint32_t* col1_out) {
-  if (!col0_out || !col1_out || lut_kind > LMN_LUT_LOG2 || log_size > 26) return LMN_ERR_INVALID_ARGUMENT;
+  return lmn_lut_from_ranges_r(lut_kind, ranges, n_ranges, log_size, LMN_ROUND_HALF_AWAY, col0_out, col1_out);
+}
+
+int lmn_lut_from_ranges_r(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_ranges, uint32_t log_size, uint32_t rounding,
+                          uint32_t* col0_out, uint32_t* col1_out) {
+  if (!col0_out || !col1_out || lut_kind > LMN_LUT_LOG2 || log_size > 26 || rounding > LMN_ROUND_FLOOR)
+    return LMN_ERR_INVALID_ARGUMENT;
   std::vector<int64_t> vals;
   int rc = lut_values(ranges, n_ranges, vals);
   if (rc != LMN_OK) return rc;
@@ -505,7 +522,11 @@ int lmn_lut_from_ranges(uint32_t lut_kind, const lmn_range* ranges, uint32_t n_r
       if (vals[i] <= 0) return LMN_ERR_INVALID_ARGUMENT;
       y = std::log2(x);
     }
-    const double r = std::round(y * scale);
+    const double ys = y * scale;
+    const double r = rounding == LMN_ROUND_HALF_AWAY   ? std::round(ys)
+                     : rounding == LMN_ROUND_HALF_EVEN ? std::nearbyint(ys)   // default FE_TONEAREST = ties to even
+                     : rounding == LMN_ROUND_TRUNC     ? std::trunc(ys)
+                                                       : std::floor(ys);
     if (!(std::fabs(r) < (double)(1ll << 30))) return LMN_ERR_INVALID_ARGUMENT;
     col0_out[i] = to_m31(vals[i]);
     col1_out[i] = to_m31((int64_t)r);

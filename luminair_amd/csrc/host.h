@@ -6,6 +6,7 @@
 #include <map>
 #include <vector>
 
+#include "../../include/luminair_hip.h"
 #include "blake2s.h"
 #include "field.h"
 
@@ -83,10 +84,13 @@ inline Hash32 b2_hash_bytes(const uint8_t* data, size_t n) {
   return r;
 }
 
-// Blake2sChannel.  variant 0 = KAT-pinned encodings.
+// Blake2sChannel.  `flags` = lmn_config.protocol_variant (LMN_PV_* bits, luminair_hip.h): all
+// transcript bits clear = the KAT-pinned encodings; each bit switches one encoding to what stwo at the pinned rev is
+// believed to use (un-vendored: unpinned).
 class Channel {
  public:
-  explicit Channel(uint32_t variant) : variant_(variant) { memset(digest_.w, 0, sizeof digest_.w); }
+  explicit Channel(uint32_t flags) : variant_(flags) { memset(digest_.w, 0, sizeof digest_.w); }
+  uint32_t flags() const { return variant_; }
   const Hash32& digest() const { return digest_; }
   void set_digest(const Hash32& d) { update(d); }
 
@@ -109,7 +113,7 @@ class Channel {
   }
   void mix_u64(uint64_t v) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    if (variant_ == 0) {
+    if (!(variant_ & LMN_PV_MIX_U64_HASHED)) {
       uint32_t h[8], m[16] = {0};
       memcpy(h, digest_.w, 32);
       m[0] = lo;
@@ -128,7 +132,7 @@ class Channel {
   }
   Hash32 draw_random_words() {
     Hash32 r;
-    if (variant_ == 0) {
+    if (!(variant_ & LMN_PV_DRAW_CTR_U32)) {
       uint32_t w[16] = {0};
       memcpy(w, digest_.w, 32);
       w[8] = n_sent_;  // u64 counter zero-padded to 32 bytes
@@ -180,7 +184,32 @@ class Channel {
       if (digest_.w[w]) return 32 * w + (uint32_t)__builtin_ctz(digest_.w[w]);
     return 128;
   }
+  // Proof of work.  KAT form: the digest after mix_u64(nonce) must end in >= pow_bits zero bits.  POW_PREFIXED form
+  // (stwo `Channel::verify_pow_nonce` at the pinned rev, from memory): blake2s(blake2s(0x12345678 LE || 12 zero bytes ||
+  // digest || pow_bits LE) || nonce LE) must; the nonce is mixed afterwards either way.
+  Hash32 pow_prefixed_digest(uint32_t pow_bits) const {
+    uint32_t w[13] = {0x12345678u, 0u, 0u, 0u};
+    memcpy(w + 4, digest_.w, 32);
+    w[12] = pow_bits;
+    return b2_hash_words(w, 13);
+  }
+  static uint32_t trailing_zeros_of(const Hash32& d) {
+    for (int w = 0; w < 4; ++w)
+      if (d.w[w]) return 32 * w + (uint32_t)__builtin_ctz(d.w[w]);
+    return 128;
+  }
+  bool verify_pow_nonce(uint32_t pow_bits, uint64_t nonce) const {
+    if (variant_ & LMN_PV_POW_PREFIXED) return pow_check_prefixed(pow_prefixed_digest(pow_bits), pow_bits, nonce);
+    Channel c = *this;
+    c.mix_u64(nonce);
+    return c.trailing_zeros() >= pow_bits;
+  }
   uint64_t grind(uint32_t pow_bits) const {
+    if (variant_ & LMN_PV_POW_PREFIXED) {
+      const Hash32 pre = pow_prefixed_digest(pow_bits);
+      for (uint64_t nonce = 0;; ++nonce)
+        if (pow_check_prefixed(pre, pow_bits, nonce)) return nonce;
+    }
     for (uint64_t nonce = 0;; ++nonce) {
       Channel c = *this;
       c.mix_u64(nonce);
@@ -189,6 +218,13 @@ class Channel {
   }
 
  private:
+  static bool pow_check_prefixed(const Hash32& pre, uint32_t pow_bits, uint64_t nonce) {
+    uint32_t w[10];
+    memcpy(w, pre.w, 32);
+    w[8] = (uint32_t)nonce;
+    w[9] = (uint32_t)(nonce >> 32);
+    return trailing_zeros_of(b2_hash_words(w, 10)) >= pow_bits;
+  }
   void update(const Hash32& d) {
     digest_ = d;
     n_sent_ = 0;

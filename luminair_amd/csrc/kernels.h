@@ -77,7 +77,7 @@ void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int 
 struct DevChannel {
   uint32_t digest[8];
   uint32_t n_sent;
-  uint32_t variant;
+  uint32_t variant;   // draw encoding: 0 = digest || counter padded to 32 bytes (KAT), 1 = digest || u32 counter || 0x00 (LMN_PV_DRAW_CTR_U32)
 };
 void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
                                lmn_stream_t s);

@@ -1534,8 +1534,8 @@ LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
 #pragma unroll
   for (int k = 9; k < 16; ++k) m[k] = 0u;
   b2_init(out);
-  // KAT variant: digest || u64 counter zero-padded to 32 bytes (64-byte message);
-  // PINNED variant: digest || u32 counter || 0x00 (37-byte message)
+  // KAT encoding: digest || u64 counter zero-padded to 32 bytes (64-byte message);
+  // LMN_PV_DRAW_CTR_U32: digest || u32 counter || 0x00 (37-byte message)
   b2_compress(out, m, ch->variant == 0u ? 64u : 37u, 0xffffffffu);
   ch->n_sent += 1u;
 }

@@ -564,6 +564,16 @@ uint32_t lmn_kind_constraints(uint32_t kind) {
   const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
   return s ? (uint32_t)(s->n_local + s->n_rel) : 0u;
 }
+uint32_t lmn_kind_constraint_layout(uint32_t kind, uint32_t protocol_flags, int32_t proto_index_out[16], int32_t sign_out[16]) {
+  const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
+  if (!s || !proto_index_out || !sign_out || (protocol_flags & ~LMN_PV_ALL)) return 0u;
+  const lmn::ConstraintLayout L = lmn::constraint_layout(*s, protocol_flags);
+  for (int k = 0; k < 16; ++k) {
+    proto_index_out[k] = k < L.n_kernel ? L.proto_index[k] : -1;
+    sign_out[k] = k < L.n_kernel && L.neg[k] ? -1 : 1;
+  }
+  return (uint32_t)L.n_protocol;
+}
 uint32_t lmn_kind_relations(uint32_t kind) {
   const lmn::ComponentSpec* s = lmn::component_spec((int)kind);
   return s ? (uint32_t)s->n_rel : 0u;

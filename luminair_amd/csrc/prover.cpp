@@ -50,7 +50,33 @@ const ComponentSpec* component_spec(int kind) {
   return nullptr;
 }
 
-RelElems draw_relation_elements(Channel& channel, uint32_t protocol_variant) {
+ConstraintLayout constraint_layout(const ComponentSpec& sp, uint32_t flags) {
+  ConstraintLayout L;
+  L.n_kernel = sp.n_local + sp.n_rel;
+  // kernel slot 1 is the eval_fixed_* constraint of Mul / Recip / Sqrt / Rem; Mul's kernel slot 2 is its zero slot
+  bool drop_slot2 = false, extra_after1 = false, neg1 = false;
+  switch (sp.kind) {
+    case LMN_KIND_MUL: drop_slot2 = (flags & LMN_PV_MUL_ONE_SLOT) != 0; break;
+    case LMN_KIND_RECIP: extra_after1 = (flags & LMN_PV_RECIP_TWO_SLOTS) != 0; neg1 = (flags & LMN_PV_RECIP_NEG) != 0; break;
+    case LMN_KIND_SQRT: extra_after1 = (flags & LMN_PV_SQRT_TWO_SLOTS) != 0; neg1 = (flags & LMN_PV_SQRT_NEG) != 0; break;
+    case LMN_KIND_REM: extra_after1 = (flags & LMN_PV_REM_TWO_SLOTS) != 0; neg1 = (flags & LMN_PV_REM_NEG) != 0; break;
+    default: break;
+  }
+  int p = 0;
+  for (int k = 0; k < L.n_kernel; ++k) {
+    L.neg[k] = k == 1 && neg1;
+    if (k == 2 && drop_slot2) {
+      L.proto_index[k] = -1;
+      continue;
+    }
+    L.proto_index[k] = p++;
+    if (k == 1 && extra_after1) ++p;   // the helper's second (zero) slot
+  }
+  L.n_protocol = p;
+  return L;
+}
+
+RelElems draw_relation_elements(Channel& channel, uint32_t protocol_flags) {
   RelElems e;
   auto draw = [&](int set) {
     std::vector<QM31> d = channel.draw_felts(2);
@@ -62,7 +88,7 @@ RelElems draw_relation_elements(Channel& channel, uint32_t protocol_variant) {
   };
   draw(ELEMS_NODE);
   draw(ELEMS_SIN);  // the KAT era drew a single LUT relation; HEAD: sin, exp2, log2, range_check
-  if (protocol_variant != LMN_VARIANT_KAT) {
+  if (protocol_flags & LMN_PV_LUT_DRAWS4) {
     draw(ELEMS_EXP2);
     draw(ELEMS_LOG2);
     draw(ELEMS_RANGE_CHECK);
@@ -178,7 +204,7 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
   if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
   if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
   if (cfg.pow_bits > 40) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad pow_bits");
-  if (cfg.protocol_variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  if (cfg.protocol_variant & ~LMN_PV_ALL) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant (unknown LMN_PV_* bits)");
   if (cfg.fp_scale != 12) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only fp_scale = 12 is supported");
 #ifndef LMN_EMU
   int n = 0;
@@ -1106,7 +1132,7 @@ static std::vector<QM31> local_constraints(int kind, const std::vector<QM31>& c)
 
 QM31 eval_composition_at_point(const std::vector<Instance>& inst,
                                const std::vector<std::vector<std::vector<QM31>>>& sv, QPt oods, const RelElems& elems,
-                               QM31 comp_alpha) {
+                               QM31 comp_alpha, uint32_t protocol_flags) {
   QM31 acc = q_zero();
   for (auto& ci : inst) {
     const ComponentSpec* sp = ci.spec;
@@ -1137,7 +1163,12 @@ QM31 eval_composition_at_point(const std::vector<Instance>& inst,
     QM31 x = oods.x;
     for (int k = 0; k < ci.log_size - 1; ++k) x = q_sub_m(q_add(q_sqr(x), q_sqr(x)), 1u);
     QM31 zinv = q_inv(x);
-    for (auto& c : cons) acc = q_add(q_mul(acc, comp_alpha), q_mul(c, zinv));
+    // kernel-slot values -> the protocol's constraint list (constraint-form bits: slots added / dropped, signs)
+    const ConstraintLayout L = constraint_layout(*sp, protocol_flags);
+    std::vector<QM31> proto(L.n_protocol, q_zero());
+    for (int k = 0; k < L.n_kernel; ++k)
+      if (L.proto_index[k] >= 0) proto[L.proto_index[k]] = L.neg[k] ? q_neg(cons[k]) : cons[k];
+    for (auto& c : proto) acc = q_add(q_mul(acc, comp_alpha), q_mul(c, zinv));
   }
   return acc;
 }
@@ -1393,7 +1424,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
 #endif
   if (!tables || n_tables == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "no trace tables");
   const int lb = (int)cfg.log_blowup;
-  const int n_slots = cfg.protocol_variant == LMN_VARIANT_KAT ? 8 : 17;
+  const int n_slots = claim_slots(cfg.protocol_variant);
   HostMarks hm;
   EventLog* log = g_log(this);
   log->reset();
@@ -1761,7 +1792,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // ---- stwo::prover::prove (prover.rs:312): composition polynomial
   const QM31 comp_alpha = channel.draw_felt();
   int n_total = 0;
-  for (auto& ci : inst) n_total += ci.spec->n_local + ci.spec->n_rel;
+  for (auto& ci : inst) n_total += constraint_layout(*ci.spec, cfg.protocol_variant).n_protocol;
   std::vector<QM31> powers(n_total);
   powers[0] = q_one();
   for (int k = 1; k < n_total; ++k) powers[k] = q_mul(powers[k - 1], comp_alpha);
@@ -1819,9 +1850,12 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       a.pre = ci.pre_idx[0] >= 0 ? tree0.cols[ci.pre_idx[0]].lde : nullptr;
       a.pre2 = ci.pre_idx[1] >= 0 ? tree0.cols[ci.pre_idx[1]].lde : nullptr;
       a.claimed_shift = ci.d_claimed_shift;
-      int nc = ci.spec->n_local + ci.spec->n_rel;
-      for (int k = 0; k < nc; ++k) a.coeff[k] = powers[n_total - 1 - (k0 + k)];
-      k0 += nc;
+      const ConstraintLayout L = constraint_layout(*ci.spec, cfg.protocol_variant);
+      for (int k = 0; k < L.n_kernel; ++k) {
+        a.coeff[k] = L.proto_index[k] < 0 ? q_zero() : powers[n_total - 1 - (k0 + L.proto_index[k])];
+        if (L.neg[k]) a.coeff[k] = q_neg(a.coeff[k]);
+      }
+      k0 += L.n_protocol;
       for (int b = 0; b < 2; ++b) {
         Pt p = domain_point(e, (uint32_t)b << ci.log_size);
         uint32_t x = p.x;
@@ -1927,7 +1961,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
   {
     QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
-    QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha);
+    QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha, cfg.protocol_variant);
     if (!q_eq(lhs, rhs) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
   }
 
@@ -2037,7 +2071,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     DevChannel hc{};
     memcpy(hc.digest, channel.digest().w, 32);
     hc.n_sent = 0;
-    hc.variant = cfg.protocol_variant;
+    hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
     DevChannel* d_ch = (DevChannel*)stage_upload(&hc, sizeof hc);
     QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
     uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);

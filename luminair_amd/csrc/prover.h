@@ -38,7 +38,21 @@ struct RelElems {
   bool drawn[N_ELEMS] = {false, false, false, false, false};
 };
 class Channel;
-RelElems draw_relation_elements(Channel& channel, uint32_t protocol_variant);
+RelElems draw_relation_elements(Channel& channel, uint32_t protocol_flags);
+inline int claim_slots(uint32_t protocol_flags) { return (protocol_flags & LMN_PV_CLAIM17) ? 17 : 8; }
+
+// Constraint slots of a component under the protocol's constraint-form bits (LMN_PV_*_SLOT(S) / _NEG, luminair_hip.h).
+// "Kernel slot" k = the k-th value k_composition<KIND> (and local_constraints() on the host) emits: the local constraints
+// in `evaluate` order with the KAT-era shape (eval_fixed_mul: two slots; recip / sqrt / rem: one), then one per relation.
+// The protocol may give a helper one slot more or less and the opposite sign; that only changes WHICH power of the
+// composition randomness multiplies a kernel slot, so it is decided here on the host and the kernels never see the bits.
+struct ConstraintLayout {
+  int n_kernel = 0;      // n_local + n_rel
+  int n_protocol = 0;    // constraints the component contributes to the composition polynomial (zero slots included)
+  int proto_index[16];   // per kernel slot: index among the component's protocol constraints; -1 = no such constraint
+  bool neg[16];          // the protocol's constraint is minus the kernel's value
+};
+ConstraintLayout constraint_layout(const ComponentSpec& sp, uint32_t protocol_flags);
 
 // one component of a proof: shared by the prover and the host-side verifier
 struct Instance {
@@ -54,14 +68,15 @@ struct Instance {
 };
 // sum_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values
 QM31 eval_composition_at_point(const std::vector<Instance>& inst, const std::vector<std::vector<std::vector<QM31>>>& sv,
-                               QPt oods, const RelElems& elems, QM31 comp_alpha);
+                               QPt oods, const RelElems& elems, QM31 comp_alpha, uint32_t protocol_flags);
 // tree-0 layout implied by the components present: fills Instance::pre_idx, returns the columns' log
 // sizes in tree order (a LUT column has the log size of its lookup component)
 std::vector<int> assign_preprocessed(std::vector<Instance>& inst);
 // verify(proof, settings): crates/verifiers/rust/src/verifier.rs:21-143 (host only, no GPU work)
 // `expect`: the verifier's own PcsConfig + protocol variant (a proof announcing another config is rejected);
 // `settings` (may be null): cross-checked against the tree-0 layout the claim implies
-void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings);
+void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings,
+                  lmn_verify_report* report = nullptr);
 
 // bump allocator over one device slab; reset per proof
 class Arena {

@@ -237,20 +237,53 @@ bool rebuild_pairs(const std::vector<uint32_t>& qpos, const std::map<uint32_t, Q
 
 }  // namespace
 
-void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings) {
+// `rep` == nullptr: lmn_verify (the first failed check throws).  Otherwise lmn_verify_diagnose: a failed check is
+// recorded and the replay goes on as far as the proof's shape allows, so that one pass tells WHICH part of the
+// protocol disagrees (tools/pin_variant.py): the checks depend on different parts of the transcript and of the AIR.
+void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, const lmn_settings* settings,
+                  lmn_verify_report* rep) {
   const uint32_t variant = expect.protocol_variant;
-  if (variant > 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant");
+  if (variant & ~LMN_PV_ALL) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad protocol_variant (unknown LMN_PV_* bits)");
+  if (rep) memset(rep, 0, sizeof *rep);
+  // check(bit, ok, what): lmn_verify semantics without a report; with one, record and continue
+  auto check = [&](uint32_t bit, bool ok, const std::string& what, int code = LMN_ERR_VERIFICATION) {
+    if (rep) {
+      rep->checks_run |= bit;
+      if (ok) {
+        if (!(rep->checks_failed & bit)) rep->checks_passed |= bit;
+      } else {
+        rep->checks_passed &= ~bit;
+        rep->checks_failed |= bit;
+        if (!rep->first_failure[0]) snprintf(rep->first_failure, sizeof rep->first_failure, "%s", what.c_str());
+      }
+      return;
+    }
+    if (!ok) {
+      if (code == LMN_ERR_INVALID_LOGUP) throw LmnError(LMN_ERR_INVALID_LOGUP, what);
+      fail(what);
+    }
+  };
+  auto step = [&](uint32_t id, uint32_t index, const Channel& ch) {
+    if (!rep || rep->n_steps >= LMN_MAX_TRANSCRIPT_STEPS) return;
+    lmn_transcript_step& st = rep->steps[rep->n_steps++];
+    st.step = id;
+    st.index = index;
+    memcpy(st.digest, ch.digest().w, 32);
+  };
   if (expect.log_blowup != 1 || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
       expect.pow_bits > 40)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad expected PCS config");
-  const int n_slots = variant == LMN_VARIANT_KAT ? 8 : 17;
+  const int n_slots = claim_slots(variant);
+  if (rep) rep->checks_run |= LMN_CHECK_PARSE;
   Proof p = parse_proof(data, len, n_slots);
+  if (rep) rep->checks_passed |= LMN_CHECK_PARSE;
   // The security parameters are the VERIFIER's (the reference builds PcsConfig::default() itself,
   // crates/verifiers/rust/src/verifier.rs:36, and never reads them from the proof): a proof that announces other
   // ones - fewer queries, no proof of work - is rejected, whatever else it contains.
   if (p.pow_bits != expect.pow_bits || p.log_blowup != expect.log_blowup || p.log_last_layer != expect.log_last_layer ||
       p.n_queries != expect.n_queries)
     fail("proof was made for a different PCS config than the verifier's");
+  if (rep) rep->checks_run |= LMN_CHECK_SHAPE;
   if (p.last_layer_log_size != p.log_last_layer) fail("last layer degree bound");
   const int lb = (int)p.log_blowup;
   if (p.commitments.size() != 4 || p.sampled_values.size() != 4 || p.decommitments.size() != 4 ||
@@ -315,20 +348,26 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
   // ---- transcript replay (verifier.rs:61-106)
   Channel ch(variant);
   ch.mix_root(p.commitments[0]);
+  step(LMN_STEP_ROOT_PREPROCESSED, 0, ch);
   for (int kind = 0; kind < n_slots; ++kind)
     if (p.claim[kind] >= 0) ch.mix_u64((uint64_t)p.claim[kind]);
+  step(LMN_STEP_CLAIM, 0, ch);
   ch.mix_root(p.commitments[1]);
+  step(LMN_STEP_ROOT_MAIN, 0, ch);
   const RelElems elems = draw_relation_elements(ch, variant);
   for (auto& ci : inst)
     for (int j = 0; j < ci.spec->n_rel; ++j)
       if (!elems.drawn[ci.spec->rel_elems[j]]) fail("component needs relation elements this protocol variant does not draw");
   QM31 tot = q_zero();
   for (auto& ci : inst) tot = q_add(tot, ci.claimed);
-  if (!q_is_zero(tot)) throw LmnError(LMN_ERR_INVALID_LOGUP, "InvalidLogUp");   // log_sum_valid, verifier.rs:97-99
+  check(LMN_CHECK_LOGUP_SUM, q_is_zero(tot), "InvalidLogUp", LMN_ERR_INVALID_LOGUP);   // log_sum_valid, verifier.rs:97-99
   for (auto& ci : inst) ch.mix_felts({ci.claimed});
+  step(LMN_STEP_INTERACTION_CLAIM, 0, ch);
   ch.mix_root(p.commitments[2]);
+  step(LMN_STEP_ROOT_INTERACTION, 0, ch);
   const QM31 comp_alpha = ch.draw_felt();
   ch.mix_root(p.commitments[3]);
+  step(LMN_STEP_ROOT_COMPOSITION, 0, ch);
   QM31 tt = ch.draw_felt();
   QM31 t2 = q_sqr(tt);
   QM31 tinv = q_inv(q_add_m(t2, 1u));
@@ -359,8 +398,8 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
   {
     auto& s3 = p.sampled_values[3];
     QM31 lhs = q_from_partial_evals(s3[0][0], s3[1][0], s3[2][0], s3[3][0]);
-    QM31 rhs = eval_composition_at_point(inst, p.sampled_values, oods, elems, comp_alpha);
-    if (!q_eq(lhs, rhs)) fail("OodsNotMatching");
+    QM31 rhs = eval_composition_at_point(inst, p.sampled_values, oods, elems, comp_alpha, variant);
+    check(LMN_CHECK_OODS, q_eq(lhs, rhs), "OodsNotMatching");
   }
   {
     std::vector<QM31> flat;
@@ -368,6 +407,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
       for (auto& c : t)
         for (auto& v : c) flat.push_back(v);
     ch.mix_felts(flat);
+    step(LMN_STEP_SAMPLED_VALUES, 0, ch);
   }
   const QM31 quot_alpha = ch.draw_felt();
 
@@ -378,20 +418,21 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
   std::vector<int> sizes(size_set.begin(), size_set.end());
   const int top = sizes[0];
   ch.mix_root(p.first_layer.commitment);
+  step(LMN_STEP_FRI_FIRST_LAYER, 0, ch);
   std::vector<QM31> alphas{ch.draw_felt()};
   for (auto& l : p.inner_layers) {
     ch.mix_root(l.commitment);
+    step(LMN_STEP_FRI_INNER_LAYER, (uint32_t)alphas.size() - 1u, ch);
     alphas.push_back(ch.draw_felt());
   }
   if ((int)p.inner_layers.size() != top - 1 - ((int)p.log_last_layer + lb)) fail("inner layer count");
   if (p.last_layer_coeffs.size() != (size_t)1 << p.log_last_layer) fail("last layer degree");
   ch.mix_felts(p.last_layer_coeffs);
-  {
-    Channel c = ch;
-    c.mix_u64(p.proof_of_work);
-    if (c.trailing_zeros() < p.pow_bits) fail("ProofOfWork");
-  }
+  step(LMN_STEP_FRI_LAST_LAYER, 0, ch);
+  if (rep) rep->checks_passed |= LMN_CHECK_SHAPE;   // every shape the transcript depends on was as the claim implies
+  check(LMN_CHECK_POW, ch.verify_pow_nonce(p.pow_bits, p.proof_of_work), "ProofOfWork");
   ch.mix_u64(p.proof_of_work);
+  step(LMN_STEP_POW_NONCE, 0, ch);
   std::vector<uint32_t> queries;
   {
     std::set<uint32_t> qs;
@@ -414,9 +455,12 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
       logs.push_back(l + lb);
       qmap[l + lb] = pos_by_log[l + lb];
     }
-    if (!merkle_verify(p.commitments[t], logs, qmap, p.queried_values[t], p.decommitments[t]))
-      fail("Merkle tree " + std::to_string(t));
+    check(LMN_CHECK_TREE_DECOMMIT, merkle_verify(p.commitments[t], logs, qmap, p.queried_values[t], p.decommitments[t]),
+          "Merkle tree " + std::to_string(t));
   }
+  // With wrong query positions (a failed tree decommitment) the queried values do not line up with the positions
+  // below: the remaining checks would only report shape errors.
+  if (rep && (rep->checks_failed & LMN_CHECK_TREE_DECOMMIT)) return;
 
   // ---- FRI answers: quotient values at the queried positions, per LDE size
   struct ColRef {
@@ -514,8 +558,8 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
         qv.insert(qv.end(), {v.a, v.b, v.c, v.d});
       }
     }
-    if (!merkle_verify(p.first_layer.commitment, logs, dec_by_log, qv, p.first_layer.decommitment))
-      fail("FRI first layer Merkle");
+    check(LMN_CHECK_FRI_DECOMMIT, merkle_verify(p.first_layer.commitment, logs, dec_by_log, qv, p.first_layer.decommitment),
+          "FRI first layer Merkle");
   }
   auto fold_circle = [&](const std::map<uint32_t, QM31>& vals, int ls, QM31 alpha) {
     std::map<uint32_t, QM31> out;
@@ -545,8 +589,8 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     }
     std::map<int, std::vector<uint32_t>> dq;
     dq[layer_log] = dpos;
-    if (!merkle_verify(l.commitment, {layer_log, layer_log, layer_log, layer_log}, dq, qv, l.decommitment))
-      fail("FRI inner layer " + std::to_string(li) + " Merkle");
+    check(LMN_CHECK_FRI_DECOMMIT, merkle_verify(l.commitment, {layer_log, layer_log, layer_log, layer_log}, dq, qv, l.decommitment),
+          "FRI inner layer " + std::to_string(li) + " Merkle");
     QM31 alpha = alphas[li + 1];
     std::map<uint32_t, QM31> nxt;
     for (uint32_t pos : dpos) {
@@ -586,7 +630,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
       }
       val = q_add(val, term);
     }
-    if (!q_eq(val, kv.second)) fail("FRI last layer");
+    check(LMN_CHECK_FRI_FOLDS, q_eq(val, kv.second), "FRI last layer");
   }
 }
 

@@ -111,6 +111,44 @@ class Component:
         return self.n_local + len(self.relations)
 
 
+# constraint-form bits (oracle.channel.ProtocolVariant / LMN_PV_* of include/luminair_hip.h)
+PV_MUL_ONE_SLOT, PV_RECIP_TWO_SLOTS, PV_RECIP_NEG, PV_SQRT_TWO_SLOTS, PV_SQRT_NEG, PV_REM_TWO_SLOTS, PV_REM_NEG = (
+    0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000)
+
+
+def constraint_layout(comp: "Component", flags: int):
+    """(n_protocol, proto_index, neg): how the values `comp.local` + relations produce (the KAT-era shape: eval_fixed_mul
+    two slots, eval_fixed_recip / _sqrt / _rem one; "kernel slots") map to the constraints the component contributes
+    to the composition polynomial under the constraint-form bits.  Slot 1 is the eval_fixed_* constraint of Mul / Recip
+    / Sqrt / Rem, Mul's slot 2 its zero slot.  proto_index[k] = None: the protocol has no such constraint."""
+    flags = int(flags)
+    drop2 = comp.kind == KIND_MUL and bool(flags & PV_MUL_ONE_SLOT)
+    two, neg_bit = {KIND_RECIP: (PV_RECIP_TWO_SLOTS, PV_RECIP_NEG), KIND_SQRT: (PV_SQRT_TWO_SLOTS, PV_SQRT_NEG),
+                    KIND_REM: (PV_REM_TWO_SLOTS, PV_REM_NEG)}.get(comp.kind, (0, 0))
+    extra, neg1 = bool(flags & two), bool(flags & neg_bit)
+    proto_index, neg, p = [], [], 0
+    for k in range(comp.n_constraints):
+        neg.append(k == 1 and neg1)
+        if k == 2 and drop2:
+            proto_index.append(None)
+            continue
+        proto_index.append(p)
+        p += 2 if (k == 1 and extra) else 1
+    return p, proto_index, neg
+
+
+def component_coeffs(comp: "Component", flags: int, powers, n_total: int, k0: int):
+    """Coefficient (power of the composition randomness, signed; 0 for a slot the protocol lacks) of every kernel
+    slot of a component whose first protocol constraint has global index k0.  Returns (coeffs, n_protocol)."""
+    n_proto, proto_index, neg = constraint_layout(comp, flags)
+    zero = powers[0] - powers[0]
+    out = []
+    for pi, ng in zip(proto_index, neg):
+        c = zero if pi is None else powers[n_total - 1 - (k0 + pi)]
+        out.append(-c if ng else c)
+    return out, n_proto
+
+
 def _transition(not_last, pairs, nxt_idx, idx):
     out = [not_last * (n - c) for n, c in pairs]
     out.append(not_last * (nxt_idx - idx - 1))

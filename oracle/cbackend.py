@@ -14,6 +14,7 @@ from typing import List
 
 import numpy as np
 
+from . import air
 from .circle import CanonicCoset, LineDomain, coset_order_storage_indices, coset_vanishing_x
 from .fft import domain_twiddles, point_mappings
 from .field import P, QM31, ONE, m_inv_vec
@@ -171,8 +172,8 @@ class CKernels:
             comp = ci.comp
             e = ci.log_size + 1
             E = 1 << e
-            nc = comp.n_constraints
-            cp = np.array([powers[n_total - 1 - (k0 + k)].v for k in range(nc)], dtype=U32)
+            cpq, nc = air.component_coeffs(comp, ci.flags, powers, n_total, k0)
+            cp = np.array([c.v for c in cpq], dtype=U32)
             k0 += nc
             main_e = self._evaluate(np.stack([np.asarray(tree1.coeffs[i], dtype=U32) for i in range(*ci.main_span)]), e)
             inter_e = self._evaluate(np.stack([np.asarray(tree2.coeffs[i], dtype=U32) for i in range(*ci.inter_span)]), e)

@@ -118,6 +118,7 @@ class ComponentInstance:
     inter_span: Tuple[int, int]   # [start, end) in tree 2
     claimed_sum: QM31
     pre_idx: Tuple[int, ...] = ()  # tree-0 column indices of the component's preprocessed columns
+    flags: int = 0                 # protocol flags (constraint-form bits decide the coefficient of every constraint slot)
 
 
 def prev_row_indices(log_size: int, eval_log: int) -> np.ndarray:
@@ -313,8 +314,7 @@ class NumpyKernels:
         k0 = 0
         for ci in instances:
             e = ci.log_size + 1
-            nc = ci.comp.n_constraints
-            cp = [powers[n_total - 1 - (k0 + k)] for k in range(nc)]
+            cp, nc = air.component_coeffs(ci.comp, ci.flags, powers, n_total, k0)
             k0 += nc
             main_e = np.stack([evaluate(tree1.coeffs[i], e) for i in range(*ci.main_span)])
             inter_e = np.stack([evaluate(tree2.coeffs[i], e) for i in range(*ci.inter_span)])
@@ -376,7 +376,7 @@ class ProverTrace:
 
 
 def claim_slots(variant: ProtocolVariant) -> int:
-    return air.N_KINDS_KAT if variant == ProtocolVariant.KAT else air.N_KINDS
+    return air.N_KINDS if int(variant) & ProtocolVariant.CLAIM17 else air.N_KINDS_KAT
 
 
 def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfig(),
@@ -442,7 +442,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     # PHASE 2: interaction trace, prover.rs:186-298
     z, alpha_rel = channel.draw_felts(2)          # NodeElements (relation!(NodeElements, 2))
     # LookupElements::draw (lookups/mod.rs:44-51): KAT era 1 LUT relation; HEAD: sin, exp2, log2, range_check
-    n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
+    n_lut_rel = 4 if int(variant) & ProtocolVariant.LUT_DRAWS4 else 1
     lut_draws = [tuple(channel.draw_felts(2)) for _ in range(n_lut_rel)]
     elems = relation_elements((z, alpha_rel), lut_draws)
     tr.z, tr.alpha_rel = z, alpha_rel
@@ -463,7 +463,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
         iclaim[kind] = claimed
         # TraceLocationAllocator hands out spans in component (struct) order
         instances.append(ComponentInstance(comp, claim[kind], (main_off, main_off + comp.n_cols),
-                                           (len(inter_cols), len(inter_cols) + len(base_cols)), claimed, pre_idx))
+                                           (len(inter_cols), len(inter_cols) + len(base_cols)), claimed, pre_idx, int(variant)))
         main_off += comp.n_cols
         inter_cols.extend(base_cols)
     for kind in range(n_slots):
@@ -477,7 +477,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     # stwo::prover::prove
     comp_alpha = channel.draw_felt()
     tr.composition_alpha = comp_alpha
-    n_total = sum(ci.comp.n_constraints for ci in instances)
+    n_total = sum(air.constraint_layout(ci.comp, ci.flags)[0] for ci in instances)
     powers = [ONE]
     for _ in range(n_total - 1):
         powers.append(powers[-1] * comp_alpha)

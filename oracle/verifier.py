@@ -57,7 +57,13 @@ def eval_composition_at_point(instances, sampled_values, oods, elems, comp_alpha
         for _ in range(ci.log_size - 1):
             x = x * x * 2 - 1
         zinv = x.inverse()
-        for c in cons:
+        # kernel-slot values -> the protocol's constraint list (constraint-form bits: slots added / dropped, signs)
+        n_proto, proto_index, neg = air.constraint_layout(comp, ci.flags)
+        proto = [ZERO] * n_proto
+        for c, pi, ng in zip(cons, proto_index, neg):
+            if pi is not None:
+                proto[pi] = -c if ng else c
+        for c in proto:
             acc = acc * comp_alpha + c * zinv
     return acc
 
@@ -75,7 +81,7 @@ def _preprocessed_ids(claim):
     return pre_ids
 
 
-def _instances_from_claim(claim, iclaim):
+def _instances_from_claim(claim, iclaim, flags=0):
     from .prover import ComponentInstance
     pre_ids = _preprocessed_ids(claim)
     inst = []
@@ -86,7 +92,7 @@ def _instances_from_claim(claim, iclaim):
         comp = COMPONENTS[kind]
         ni = 4 * len(comp.relations)
         inst.append(ComponentInstance(comp, ls, (m_off, m_off + comp.n_cols), (i_off, i_off + ni), iclaim[kind],
-                                      tuple([cid for cid, _ in pre_ids].index(pc) for pc in comp.pre_cols)))
+                                      tuple([cid for cid, _ in pre_ids].index(pc) for pc in comp.pre_cols), int(flags)))
         m_off += comp.n_cols
         i_off += ni
     return inst
@@ -103,7 +109,7 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT,
     s = proof.proof
     lb = s.log_blowup
     channel = Blake2sChannel(variant)
-    inst = _instances_from_claim(proof.claim, proof.interaction_claim)
+    inst = _instances_from_claim(proof.claim, proof.interaction_claim, int(variant))
     if not inst:
         raise VerificationError("empty claim")
     if len(s.commitments) != 4:
@@ -122,7 +128,7 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT,
             channel.mix_u64(ls)
     channel.mix_root(s.commitments[1])
     z, alpha_rel = channel.draw_felts(2)
-    n_lut_rel = 1 if variant == ProtocolVariant.KAT else 4
+    n_lut_rel = 4 if int(variant) & ProtocolVariant.LUT_DRAWS4 else 1
     from .prover import relation_elements
     lut_draws = [tuple(channel.draw_felts(2)) for _ in range(n_lut_rel)]
     elems = relation_elements((z, alpha_rel), lut_draws)
@@ -186,9 +192,7 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT,
         raise VerificationError("last layer degree")
     channel.mix_felts(s.last_layer_coeffs)
     # PoW
-    c = channel.clone()
-    c.mix_u64(s.proof_of_work)
-    if c.trailing_zeros() < s.pow_bits:
+    if not channel.verify_pow_nonce(s.pow_bits, s.proof_of_work):
         raise VerificationError("ProofOfWork")
     channel.mix_u64(s.proof_of_work)
     queries = draw_queries(channel, max_log, s.n_queries)

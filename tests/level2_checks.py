@@ -26,7 +26,7 @@ def check_quotient_fold_grind_ops(ctx, log):
     dst = rng.integers(0, P, size=(L // 2, 4), dtype=np.uint64)
     assert np.array_equal(ctx.fold_circle_into_line(dst.T, sec.T, alpha.v).T.astype(np.uint64),
                           fold_circle_into_line(dst, sec, alpha, log))
-    for variant in (0, 1):
+    for variant in (0, 0x1f, 0x4, 0x10, 0x0c):   # KAT, PINNED, hashed mix_u64 alone, prefixed proof of work alone, ...
         from oracle.channel import ProtocolVariant
         ch = Blake2sChannel(ProtocolVariant(variant))
         ch.mix_u64(12345 + variant)
@@ -34,8 +34,10 @@ def check_quotient_fold_grind_ops(ctx, log):
         c2 = Blake2sChannel(ProtocolVariant(variant))
         c2.digest = ch.digest
         assert nonce == c2.grind(9)
-        c2.mix_u64(nonce)
-        assert c2.trailing_zeros() >= 9
+        assert c2.verify_pow_nonce(9, nonce) and (nonce == 0 or not c2.verify_pow_nonce(9, nonce - 1))
+        if not variant & 0x10:   # KAT form of the proof of work: the digest after the mix shows the zeros
+            c2.mix_u64(nonce)
+            assert c2.trailing_zeros() >= 9
 
 
 def check_device_trace_generation(ctx, n, seed=21):

@@ -12,6 +12,7 @@ from typing import List, Optional
 
 import numpy as np
 
+from oracle import air
 from oracle.field import QM31
 from oracle.merkle import MerkleTree
 
@@ -156,8 +157,8 @@ class Level2Kernels:
         k0 = 0
         for ci in instances:
             e = ci.log_size + 1
-            nc = ci.comp.n_constraints
-            coeffs = [powers[n_total - 1 - (k0 + k)].v for k in range(nc)]
+            cpq, nc = air.component_coeffs(ci.comp, ci.flags, powers, n_total, k0)
+            coeffs = [c.v for c in cpq]
             k0 += nc
             if e not in acc:
                 acc[e] = self.ctx.col_zeros(4, e)

@@ -33,7 +33,8 @@ def test_product_verifier_accepts_the_reference_kat(lib, kat_bytes):
 
 @pytest.mark.parametrize("tabs,variant", [
     (syn.chain_graph(300, 3), 0), (syn.config3_mixed(10, 9, 9, 8), 0), (syn.linear_layer(20, 7, 2, True), 0),
-    (syn.config2_graph_faithful(100, 3), 1), (syn.less_than_graph(100, 3), 1),
+    (syn.config2_graph_faithful(100, 3), backend.VARIANT_PINNED), (syn.less_than_graph(100, 3), backend.VARIANT_PINNED),
+    (syn.chain_graph(100, 5), backend.PV_MIX_U64_HASHED | backend.PV_POW_PREFIXED | backend.PV_MUL_ONE_SLOT | backend.PV_RECIP_NEG),
 ])
 def test_product_verifier_accepts_oracle_proofs(lib, tabs, variant):
     b = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], variant=ProtocolVariant(variant)))
