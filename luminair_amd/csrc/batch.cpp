@@ -3,7 +3,10 @@
 #ifdef LMN_BATCH
 #include "../../include/luminair_hip_batch.h"
 
+#include <sys/mman.h>
+#include <sys/syscall.h>
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -18,7 +21,14 @@ namespace lmn {
 
 thread_local BatchGroup* tls_batch_group = nullptr;
 thread_local int tls_batch_member = 0;
-static thread_local BatchGroup* tls_solo_group = nullptr;
+// A thread that launches outside any batch (the caller of lmn_batch_create / lmn_batch_prove, an lmn_prove_submit worker,
+// plain lmn_prove) gets a group of one.  It is released when the thread ends - except on the main thread, whose
+// thread-local destructors run while the HIP runtime may already be shutting down.
+struct SoloGroupHolder {
+  BatchGroup* g = nullptr;
+  ~SoloGroupHolder();
+};
+static thread_local SoloGroupHolder tls_solo;
 struct BounceOut {   // device -> pageable host memory: lands in a page-locked slot, copied out after the group's wait
   void* dst;
   const void* slot;
@@ -94,14 +104,25 @@ static bool pinned_device_address(const void* p, size_t n, uint64_t* out) {
   return false;
 }
 
-void batch_group_init(BatchGroup& g, int slots) {
+SoloGroupHolder::~SoloGroupHolder() {
+  if (!g) return;
+  if ((long)syscall(SYS_gettid) != (long)getpid()) {
+    batch_group_release(*g);
+    delete g;
+  }
+  g = nullptr;
+}
+
+// `solo`: a group of one never batches transfers (batch_copy declines outside a batch) and may simply drain its stream
+// when its launch table is full: 1 MiB of table halves and no bounce memory instead of 24 + 24 + 8 MiB per thread.
+void batch_group_init(BatchGroup& g, int slots, bool solo) {
   g.slots = slots;
   g.n_alloc = slots;
-  g.half_bytes = BATCH_HALF_BYTES;
+  g.half_bytes = solo ? (size_t)(512u << 10) : BATCH_HALF_BYTES;
   batch_check_hip(hipHostMalloc((void**)&g.host, 2 * g.half_bytes, hipHostMallocDefault), "hipHostMalloc");
   batch_check_hip(hipMalloc((void**)&g.dev, 2 * g.half_bytes), "hipMalloc");
   batch_register_pinned(g.host, 2 * g.half_bytes);
-  g.bounce_bytes = std::min<size_t>(4u << 20, std::max<size_t>(256u << 10, BATCH_BOUNCE_TOTAL / (2 * (size_t)slots)));
+  g.bounce_bytes = solo ? (size_t)4096 : std::min<size_t>(4u << 20, std::max<size_t>(256u << 10, BATCH_BOUNCE_TOTAL / (2 * (size_t)slots)));
   batch_check_hip(hipHostMalloc((void**)&g.bounce, (size_t)slots * 2 * g.bounce_bytes, hipHostMallocDefault), "hipHostMalloc");
   batch_register_pinned(g.bounce, (size_t)slots * 2 * g.bounce_bytes);
   g.member = new BatchMember[slots];
@@ -141,13 +162,14 @@ static std::vector<BounceOut>& bounce_out_list() {
 
 BatchGroup& batch_current_group() {
   if (tls_batch_group) return *tls_batch_group;
-  if (!tls_solo_group) {   // a thread outside any batch: a group of one that launches on the caller's stream
-    tls_solo_group = new BatchGroup();
-    tls_solo_group->solo = true;
-    batch_group_init(*tls_solo_group, 1);
-    tls_solo_group->member[0].active = true;
+  if (!tls_solo.g) {   // a thread outside any batch: a group of one that launches on the caller's stream
+    BatchGroup* g = new BatchGroup();
+    g->solo = true;
+    batch_group_init(*g, 1, true);
+    g->member[0].active = true;
+    tls_solo.g = g;
   }
-  return *tls_solo_group;
+  return *tls_solo.g;
 }
 
 static void stream_wait(hipStream_t s) {
@@ -260,6 +282,21 @@ static void push_copy(BatchMember& m, uint64_t dst, uint64_t src, size_t n, uint
   }
 }
 
+// A transfer that cannot be batched (a pageable buffer larger than the bounce slot) is issued by the member itself, at
+// once.  Its earlier transfers are still waiting in the member's list for the next rendezvous: issue those first, in
+// order, so that program order holds (e.g. a device-to-device copy followed by the download of the same buffer).
+static void flush_member_direct(BatchGroup& g, BatchMember& m) {
+  for (uint32_t i = 0; i < m.n_copies; ++i) {
+    const BatchCopy& c = m.copies[i];
+    if (c.src == 0)
+      batch_check_hip(hipMemsetAsync(reinterpret_cast<void*>(c.dst), (int)(c.fill & 0xffu), c.bytes, g.stream), "hipMemsetAsync");
+    else
+      batch_check_hip(hipMemcpyAsync(reinterpret_cast<void*>(c.dst), reinterpret_cast<const void*>(c.src), c.bytes,
+                                     hipMemcpyDefault, g.stream), "hipMemcpyAsync");
+  }
+  m.n_copies = 0;
+}
+
 bool batch_copy(void* dst, const void* src, size_t n, int dir) {
   BatchGroup* gp = tls_batch_group;
   if (!gp) return false;                 // outside a batch: the caller's own hipMemcpyAsync
@@ -276,7 +313,8 @@ bool batch_copy(void* dst, const void* src, size_t n, int dir) {
   if (dir == 0 && !pinned_device_address(src, n, &s)) {          // pageable source: through a page-locked slot
     unsigned char* slot = bounce(n);
     if (!slot) {
-        SpinGuard lk(g.lock);
+      flush_member_direct(g, m);
+      SpinGuard lk(g.lock);
       g.direct_copies++;
       return false;
     }
@@ -285,7 +323,8 @@ bool batch_copy(void* dst, const void* src, size_t n, int dir) {
   } else if (dir == 1 && !pinned_device_address(dst, n, &d)) {   // pageable destination: copied out after the wait
     unsigned char* slot = bounce(n);
     if (!slot) {
-        SpinGuard lk(g.lock);
+      flush_member_direct(g, m);
+      SpinGuard lk(g.lock);
       g.direct_copies++;
       return false;
     }
@@ -502,6 +541,20 @@ static void fiber_entry() {
 }
 
 constexpr size_t BATCH_FIBER_STACK = 1u << 20;
+// fiber stacks come from mmap with an inaccessible page below them: running off the end of a stack faults instead of
+// overwriting whatever the heap had put next to a malloc'ed block
+static void* fiber_stack_alloc() {
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  void* p = mmap(nullptr, BATCH_FIBER_STACK + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+  if (p == MAP_FAILED) throw std::bad_alloc();
+  (void)mprotect(p, page, PROT_NONE);
+  return static_cast<char*>(p) + page;
+}
+static void fiber_stack_free(void* stack) {
+  if (!stack) return;
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  (void)munmap(static_cast<char*>(stack) - page, BATCH_FIBER_STACK + page);
+}
 
 // worker w of T runs members w, w + T, w + 2T, ... of every batch as fibers
 static void batch_worker(lmn_batch* b, uint32_t w) {
@@ -525,7 +578,7 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
     uint32_t k = 0;
     for (uint32_t m = w; m < n; m += b->n_threads, ++k) {
       lmn::BatchFiber& f = fibers[k];
-      if (!f.stack) f.stack = malloc(BATCH_FIBER_STACK);
+      if (!f.stack) f.stack = fiber_stack_alloc();
       getcontext(&f.ctx);
       f.ctx.uc_stack.ss_sp = f.stack;
       f.ctx.uc_stack.ss_size = BATCH_FIBER_STACK;
@@ -563,7 +616,7 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
       if (b->pending == 0) b->cv_done.notify_all();
     }
   }
-  for (auto& f : fibers) free(f.stack);
+  for (auto& f : fibers) fiber_stack_free(f.stack);
 }
 
 extern "C" {
@@ -635,9 +688,20 @@ int lmn_batch_prove(lmn_batch* b, uint32_t n, const lmn_table* const* tables, si
       }
   }
   {
-    std::lock_guard<std::mutex> lk(b->m);
+    // Per-context set-up that only SOME members would do (a context that has not proved this shape yet builds its
+    // twiddle tables: uploads and waits the other members do not make) happens here, on the calling thread, before the
+    // members start in lock-step: a batch may use more slots, or a larger shape, than the batches before it.
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->group.stream);   // a failed batch may have left work behind
+    try {
+      for (uint32_t i = 0; i < n; ++i) b->ctx[i]->prepare_for(tables[i], n_tables);
+    } catch (const LmnError& e) {
+      b->last_error = e.what();
+      return (e.code == -100 || (e.code <= -1 && e.code >= -10)) ? e.code : LMN_ERR_INTERNAL;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(b->m);
     b->group.slots = (int)n;
     b->group.state.store((uint64_t)n << 32);
     b->group.failed.store(0);

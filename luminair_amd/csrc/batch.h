@@ -130,7 +130,7 @@ void batch_unregister_pinned(const void* p);
 extern thread_local BatchGroup* tls_batch_group;
 extern thread_local int tls_batch_member;
 BatchGroup& batch_current_group();                       // the thread's group (creates the solo group on first use)
-void batch_group_init(BatchGroup& g, int slots);         // table / bounce memory for `slots` members
+void batch_group_init(BatchGroup& g, int slots, bool solo = false);         // table / bounce memory for `slots` members
 void batch_group_release(BatchGroup& g);
 // a member's slot (header + pack) of the launch it is about to take part in
 unsigned char* batch_launch_begin(BatchGroup& g, const void* fn, void (*do_launch)(BatchGroup&), dim3 grid, dim3 block,

@@ -25,7 +25,8 @@ void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int 
 // only rows [blk_row0, blk_row0 + blk_rows) of the padded table (blk_row0 a multiple of 64); columns out_stride apart
 void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
                                uint64_t out_stride, uint64_t blk_row0, uint64_t blk_rows, const PadRow& pad, uint32_t* bad_flag,
-                               lmn_stream_t s);
+                               lmn_stream_t s,
+                               uint32_t bad_value = 1u /* what a non-canonical word writes to *bad_flag */);
 
 // ---- a4: circle FFT passes.  data = ncols columns of 2^log_n words at stride col_stride.
 // dst may equal src (in place).  launch_fft zero-extends src (2^log_src words) to 2^log_n (LDE).

@@ -67,7 +67,7 @@ constexpr int TR_ROWS = 64;
 // sharded proof); row r of column c lands at cols[c * out_stride + (r - blk_row0)].
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
                            uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic,
-                           uint64_t out_stride, uint64_t blk_row0) {
+                           uint64_t out_stride, uint64_t blk_row0, uint32_t bad_value) {
   LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x stride
   // odd row stride: the column-major read below walks rows at that stride, and an even one (16 words for the 15 columns of
   // Add) maps the 64 rows of a column onto 2 of the 32 LDS banks
@@ -83,7 +83,7 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
       v = rows[gr * (uint64_t)ncols + c];
     else
       v = pad.v[c];
-    if (v >= P31) *bad_flag = 1u;  // the boundary takes raw u32 words: reject non-canonical M31 values
+    if (v >= P31) *bad_flag = bad_value;  // the boundary takes raw u32 words: reject non-canonical M31 values
     tile[r * stride + c] = v;
   }
   __syncthreads();
@@ -95,7 +95,7 @@ LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, i
 
 void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
                                uint64_t out_stride, uint64_t blk_row0, uint64_t blk_rows, const PadRow& pad, uint32_t* bad_flag,
-                               lmn_stream_t s) {
+                               lmn_stream_t s, uint32_t bad_value) {
   uint64_t size = 1ull << log_size;
   if (blk_row0 % TR_ROWS || blk_row0 + blk_rows > size) throw LmnError(-100, "transpose: bad row block");
   unsigned grid = cdiv(blk_rows, TR_ROWS);
@@ -104,7 +104,7 @@ void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols,
   const uint32_t magic = ncols == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)ncols - 1) / (uint64_t)ncols);  // ceil(2^32 / ncols)
   // rows beyond the block are cut off by treating its end as the table's size
   LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, blk_row0 + blk_rows, cols, pad, bad_flag, magic,
-             out_stride, blk_row0);
+             out_stride, blk_row0, bad_value);
 }
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
                           const PadRow& pad, uint32_t* bad_flag, lmn_stream_t s) {

@@ -244,9 +244,9 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
   pin_cap_ = 32u << 20;
   pin_base_ = (char*)lmn_host_alloc_pinned(pin_cap_);
   {
-    const uint32_t zero = 0u;
-    bad_flag_ = (uint32_t*)lmn_dev_malloc(4);
-    lmn_h2d(bad_flag_, &zero, 4, stream_);
+    const uint32_t zero[2] = {0u, 0u};
+    bad_flag_ = (uint32_t*)lmn_dev_malloc(8);   // [0]: prove's non-canonical-word verdict, [1]: trace_lut's range verdict
+    lmn_h2d(bad_flag_, zero, 8, stream_);
     lmn_sync(stream_);
   }
 }
@@ -418,14 +418,14 @@ void Context::trace_lut(uint32_t kind, const int32_t* input, const lmn_view* vie
     if (base > (1ull << 26)) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: LUT larger than 2^26 rows");
   }
   const TraceView tv = trace_view(view, n);
-  // bad_flag_ is zero between calls; the kernel sets it when an input misses every range
-  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, rg, mult, rows + row_offset * 12ull, out, bad_flag_, stream_);
+  // bad_flag_[1] is zero between calls; the kernel sets it when an input misses every range
+  launch_trace_lut(input, tv, n, trace_node(info), lut_col1, rg, mult, rows + row_offset * 12ull, out, bad_flag_ + 1, stream_);
   uint32_t err = 0;
-  lmn_d2h(&err, bad_flag_, 4, stream_);
+  lmn_d2h(&err, bad_flag_ + 1, 4, stream_);
   lmn_sync(stream_);
   if (err) {
     const uint32_t zero = 0u;
-    lmn_h2d(bad_flag_, &zero, 4, stream_);
+    lmn_h2d(bad_flag_ + 1, &zero, 4, stream_);
     lmn_sync(stream_);
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace_lut: an input value lies outside the LUT's range");
   }
@@ -1417,6 +1417,23 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
   return a;
 }
 
+#ifdef LMN_BATCH
+void Context::prepare_for(const lmn_table* tables, size_t n_tables) {
+  LMN_HIP_CHECK(hipSetDevice(device_));
+  if (!tables) return;
+  int max_log = 0;
+  for (size_t t = 0; t < n_tables; ++t) {
+    if (tables[t].n_rows == 0 || tables[t].n_rows > (1ull << 26)) return;
+    int ls = 4;
+    while ((1ull << ls) < tables[t].n_rows) ++ls;
+    max_log = std::max(max_log, ls);
+  }
+  const int max_lde = max_log + 1 + (int)cfg.log_blowup;
+  if (max_lde > MAX_LOG - 2) return;
+  ensure_twiddles(max_lde);
+}
+#endif
+
 // ------------------------------------------------------------------------------------ prove
 std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, const lmn_settings* settings) {
 #ifndef LMN_EMU
@@ -1597,7 +1614,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
 
   // ---- PHASE 1: main trace (prover.rs:70-179)
   DevTree tree1;
-  uint32_t* d_bad = bad_flag_;  // persistent device word (zero between proofs), set by the transposes
+  // Persistent device word the transposes write when a table holds a word that is not a canonical M31.  Unsharded proofs
+  // never reset it: every proof has its own mark (>= 2) and only that value counts, so the accepting and the rejecting
+  // path issue the same launches / copies / waits - what the lock-step batch library needs from its members (a
+  // rejected pie leaves its batch alone and the slot stays usable).  Sharded proofs gather the word across ranks, whose
+  // counters are unrelated: their mark is 1 and the rejecting path clears it.
+  uint32_t* d_bad = bad_flag_;
+  if (++bad_epoch_ < 2u) bad_epoch_ = 2u;
+  const uint32_t bad_mark = shard_.active ? 1u : bad_epoch_;
   const uint32_t* h_bad = nullptr;
   bool any_rows_front = false;
   {
@@ -1620,7 +1644,7 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       PadRow pad{};
       if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
       for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
-      launch_transpose_pad_rows(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, nb, blk0, nb, pad, d_bad, stream_);
+      launch_transpose_pad_rows(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, nb, blk0, nb, pad, d_bad, stream_, bad_mark);
       inst[t].trace_evals = evals;
       inst[t].rows_sharded = rows_front;
       any_rows_front = any_rows_front || rows_front;
@@ -1655,12 +1679,14 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       h_bad = (const uint32_t*)stage_download(d_bad, 4);
     }
     lmn_sync(stream_);
-    uint32_t bad_any = 0;
-    for (uint32_t k = 0; k < n_flags; ++k) bad_any |= h_bad[k];
+    bool bad_any = false;
+    for (uint32_t k = 0; k < n_flags; ++k) bad_any = bad_any || h_bad[k] == bad_mark;
     if (bad_any) {
-      const uint32_t zero = 0u;
-      lmn_h2d(d_bad, &zero, 4, stream_);
-      lmn_sync(stream_);
+      if (shard_.active) {
+        const uint32_t zero = 0u;
+        lmn_h2d(d_bad, &zero, 4, stream_);
+        lmn_sync(stream_);
+      }
       throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace table holds a word that is not a canonical M31 (>= 2^31-1)");
     }
     tree1.merkle.finish_root();

@@ -156,6 +156,9 @@ class Context {
 #ifdef LMN_BATCH
   // lock-step batches (batch.h): every member context issues its work on the group's one stream
   void adopt_stream(lmn_stream_t s);
+  // the set-up `prove` would do for these tables on its first call with such a shape (twiddle tables), done outside
+  // lock-step; malformed tables are left for `prove` to report
+  void prepare_for(const lmn_table* tables, size_t n_tables);
 #endif
 
   // level-2 ops
@@ -299,7 +302,8 @@ class Context {
     return (T*)stage_upload(v.data(), v.size() * sizeof(T));
   }
   void fetch_root_async(DevMerkle& m);   // m.root_pinned valid after the next sync
-  uint32_t* bad_flag_ = nullptr;  // device word set when a trace table holds a non-canonical M31 word
+  uint32_t* bad_flag_ = nullptr;  // two device words: [0] marked when a trace table holds a non-canonical M31 word, [1] trace_lut's
+  uint32_t bad_epoch_ = 1;        // the mark of the current unsharded proof (see Context::prove)
   char* pin_base_ = nullptr;
   size_t pin_cap_ = 0, pin_off_ = 0;
 

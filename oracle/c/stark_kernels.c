@@ -102,6 +102,37 @@ static inline int par_ok(long work) {
   return work >= (per_team > (1L << 18) ? per_team : (1L << 18));
 }
 
+/* ---- M31 over LW lanes: plain loops over fixed-length arrays, written branch-free so that the HOT clones compile
+ * each line to vector instructions (the same shape stwo's SimdBackend gives its 16-lane PackedM31). */
+#define LW 16
+static inline u32 red1(u32 s) { u32 t = s - P; return t < s ? t : s; }           /* s in [0, 2P) -> [0, P): min(s, s - P) unsigned */
+static inline u32 vmadd(u32 a, u32 b) { return red1(a + b); }
+static inline u32 vmsub(u32 a, u32 b) { u32 d = a - b; u32 e = d + P; return e < d ? e : d; } /* a - b wraps iff a < b: then d + P wraps back below d */
+static inline u32 vmmul(u32 a, u32 b) {
+  u64 p = (u64)a * b;
+  return red1((u32)(p & P) + (u32)(p >> 31));
+}
+
+/* out[i] = 1 / v[i] for i < n, n a multiple of LW: LW independent Montgomery chains side by side (element i belongs to
+ * chain i % LW), one inversion per chain by exponentiation, every step a vector line.  tmp: n words. */
+HOT static void batch_inverse_lanes(const u32* v, long n, u32* out, u32* tmp) {
+  u32 acc[LW], inv[LW];
+  for (int l = 0; l < LW; ++l) acc[l] = 1;
+  for (long i = 0; i < n; i += LW)
+    for (int l = 0; l < LW; ++l) { tmp[i + l] = acc[l]; acc[l] = vmmul(acc[l], v[i + l]); }
+  for (int l = 0; l < LW; ++l) inv[l] = 1;
+  { /* inv = acc^(P-2): P - 2 = 0x7ffffffd */
+    u32 b[LW];
+    for (int l = 0; l < LW; ++l) b[l] = acc[l];
+    for (u32 e = P - 2; e; e >>= 1) {
+      if (e & 1) for (int l = 0; l < LW; ++l) inv[l] = vmmul(inv[l], b[l]);
+      for (int l = 0; l < LW; ++l) b[l] = vmmul(b[l], b[l]);
+    }
+  }
+  for (long i = n - LW; i >= 0; i -= LW)
+    for (int l = 0; l < LW; ++l) { u32 x = v[i + l]; out[i + l] = vmmul(inv[l], tmp[i + l]); inv[l] = vmmul(inv[l], x); }
+}
+
 static inline void bfly_fwd(u32* lo, u32* hi, u32 w) {
   u32 x = mmul(*hi, w), a = *lo;
   *lo = madd(a, x);
@@ -229,7 +260,6 @@ static void compress(u32 h[8], const u32 m[16], u32 t, u32 f) {
 }
 /* LW independent hashes side by side (one per SIMD lane): the same compression function written over arrays so
  * that the compiler turns every line into one vector instruction (vprord etc. under AVX-512). */
-#define LW 16
 HOT static void compress_lanes(u32 h[8][LW], u32 m[16][LW], u32 t, u32 f) {
   u32 v[16][LW];
   for (int i = 0; i < 8; ++i)
@@ -304,32 +334,99 @@ void orc_blake2s_rows(const u32* words, long n, int w, u32* out) {
  * cols: k relations x (val, id, mult) pointers, each n words.  out: k secure columns as 4k base
  * columns of n words (running sums, NOT yet prefix-summed); claimed = sum over rows of S_{k-1}.
  * ------------------------------------------------------------------------------------------- */
+/* One chunk of LCH rows: the k denominators of a row are QM31; 1/x = conj-style formula over the CM31 norm
+ * N = A^2 - (2+i) B^2 of x = A + B u, whose own norm (an M31) is what gets inverted - all LCH x k of them together
+ * (stwo batches the inversions of a logup column the same way), the rest lane-wise. */
+#define LCH 1024
+HOT static void logup_chunk(const u32* const* val, const u32* const* id, const u32* const* mult, int k, long r0, long n,
+                            const u32* zs, const u32* alphas, const int* neg, u32* out, u64 loc[4], u32* scratch) {
+  u32* xa = scratch;                 /* k x LCH each: denominator coordinates, CM31 norm, its M31 norm and inverse */
+  u32* xb = xa + (long)k * LCH;
+  u32* xc = xb + (long)k * LCH;
+  u32* xd = xc + (long)k * LCH;
+  u32* na = xd + (long)k * LCH;
+  u32* nb = na + (long)k * LCH;
+  u32* nn = nb + (long)k * LCH;
+  u32* ni = nn + (long)k * LCH;
+  u32* tmp = ni + (long)k * LCH;
+  u32 *sa = tmp + (long)k * LCH, *sb = sa + LCH, *sc = sb + LCH, *sd = sc + LCH;
+  for (int j = 0; j < k; ++j) {
+    const u32 z0 = zs[4 * j], z1 = zs[4 * j + 1], z2 = zs[4 * j + 2], z3 = zs[4 * j + 3];
+    const u32 a0 = alphas[4 * j], a1 = alphas[4 * j + 1], a2 = alphas[4 * j + 2], a3 = alphas[4 * j + 3];
+    const u32* v = val[j] + r0;
+    const u32* idp = id[j] ? id[j] + r0 : NULL;
+    u32 *pa = xa + (long)j * LCH, *pb = xb + (long)j * LCH, *pc = xc + (long)j * LCH, *pd = xd + (long)j * LCH;
+    u32 *qa = na + (long)j * LCH, *qb = nb + (long)j * LCH, *qn = nn + (long)j * LCH;
+    for (int t = 0; t < LCH; ++t) {
+      const u32 w = idp ? idp[t] : 0;
+      const u32 a = vmsub(vmadd(v[t], vmmul(a0, w)), z0), b = vmsub(vmmul(a1, w), z1);
+      const u32 c = vmsub(vmmul(a2, w), z2), d = vmsub(vmmul(a3, w), z3);
+      pa[t] = a; pb[t] = b; pc[t] = c; pd[t] = d;
+      /* A^2 = (a^2 - b^2, 2ab), B^2 = (c^2 - d^2, 2cd), (2+i)(x, y) = (2x - y, x + 2y) */
+      const u32 asq = vmsub(vmmul(a, a), vmmul(b, b)), abb = vmmul(vmadd(a, a), b);
+      const u32 csq = vmsub(vmmul(c, c), vmmul(d, d)), cdd = vmmul(vmadd(c, c), d);
+      const u32 ra = vmsub(vmadd(csq, csq), cdd), rb = vmadd(csq, vmadd(cdd, cdd));
+      const u32 Na = vmsub(asq, ra), Nb = vmsub(abb, rb);
+      qa[t] = Na; qb[t] = Nb;
+      qn[t] = vmadd(vmmul(Na, Na), vmmul(Nb, Nb));
+    }
+  }
+  batch_inverse_lanes(nn, (long)k * LCH, ni, tmp);
+  for (int t = 0; t < LCH; ++t) sa[t] = sb[t] = sc[t] = sd[t] = 0;
+  for (int j = 0; j < k; ++j) {
+    const u32 *pa = xa + (long)j * LCH, *pb = xb + (long)j * LCH, *pc = xc + (long)j * LCH, *pd = xd + (long)j * LCH;
+    const u32 *qa = na + (long)j * LCH, *qb = nb + (long)j * LCH, *qi = ni + (long)j * LCH;
+    const u32* m = mult[j] + r0;
+    const int ng = neg[j];
+    u32* o = out + (long)(4 * j) * n + r0;
+    for (int t = 0; t < LCH; ++t) {
+      /* di = conj(N) / |N|; 1/x = (A di, -B di) */
+      const u32 da = vmmul(qa[t], qi[t]), db = vmmul(vmsub(0, qb[t]), qi[t]);
+      const u32 ia = vmsub(vmmul(pa[t], da), vmmul(pb[t], db)), ib = vmadd(vmmul(pa[t], db), vmmul(pb[t], da));
+      const u32 ic = vmsub(0, vmsub(vmmul(pc[t], da), vmmul(pd[t], db))), idd = vmsub(0, vmadd(vmmul(pc[t], db), vmmul(pd[t], da)));
+      const u32 mm = ng ? vmsub(0, m[t]) : m[t];
+      sa[t] = vmadd(sa[t], vmmul(ia, mm));
+      sb[t] = vmadd(sb[t], vmmul(ib, mm));
+      sc[t] = vmadd(sc[t], vmmul(ic, mm));
+      sd[t] = vmadd(sd[t], vmmul(idd, mm));
+      o[t] = sa[t]; o[n + t] = sb[t]; o[2 * n + t] = sc[t]; o[3 * n + t] = sd[t];
+    }
+  }
+  u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+  for (int t = 0; t < LCH; ++t) { l0 += sa[t]; l1 += sb[t]; l2 += sc[t]; l3 += sd[t]; }
+  loc[0] += l0; loc[1] += l1; loc[2] += l2; loc[3] += l3;
+}
+
 void orc_logup_columns(const u32* const* val, const u32* const* id /* entries may be NULL */,
                        const u32* const* mult, int k, long n, const u32* zs /* 4 per relation */,
                        const u32* alphas /* 4 per relation */, const int* neg, u32* out, u32 claimed[4]) {
   u64 acc[4] = {0, 0, 0, 0};
+  const long nchunks = n / LCH;
 #pragma omp parallel if (par_ok(n * (long)k * 64))
   {
     u64 loc[4] = {0, 0, 0, 0};
+    u32* scratch = (u32*)malloc(sizeof(u32) * ((size_t)k * 9 + 4) * LCH);
 #pragma omp for schedule(static)
-    for (long r = 0; r < n; ++r) {
-      qm S = QZERO;
-      for (int j = 0; j < k; ++j) {
-        const qm Z = {zs[4 * j], zs[4 * j + 1], zs[4 * j + 2], zs[4 * j + 3]};
-        const qm A = {alphas[4 * j], alphas[4 * j + 1], alphas[4 * j + 2], alphas[4 * j + 3]};
-        qm den = qfromm(val[j][r]);
-        if (id[j]) den = qadd(den, qmulm(A, id[j][r]));
-        den = qsub(den, Z);
-        u32 m = mult[j][r];
-        if (neg[j]) m = mneg(m);
-        S = qadd(S, qmulm(qinv(den), m));
-        u32* o = out + (long)(4 * j) * n + r;
-        o[0] = S.a; o[n] = S.b; o[2 * n] = S.c; o[3 * n] = S.d;
-      }
-      loc[0] += S.a; loc[1] += S.b; loc[2] += S.c; loc[3] += S.d;
-    }
+    for (long c = 0; c < nchunks; ++c) logup_chunk(val, id, mult, k, c * LCH, n, zs, alphas, neg, out, loc, scratch);
+    free(scratch);
 #pragma omp critical
     for (int t = 0; t < 4; ++t) acc[t] += loc[t] % P;
+  }
+  for (long r = nchunks * LCH; r < n; ++r) { /* tables below LCH rows: one inversion per row and relation */
+    qm S = QZERO;
+    for (int j = 0; j < k; ++j) {
+      const qm Z = {zs[4 * j], zs[4 * j + 1], zs[4 * j + 2], zs[4 * j + 3]};
+      const qm A = {alphas[4 * j], alphas[4 * j + 1], alphas[4 * j + 2], alphas[4 * j + 3]};
+      qm den = qfromm(val[j][r]);
+      if (id[j]) den = qadd(den, qmulm(A, id[j][r]));
+      den = qsub(den, Z);
+      u32 m = mult[j][r];
+      if (neg[j]) m = mneg(m);
+      S = qadd(S, qmulm(qinv(den), m));
+      u32* o = out + (long)(4 * j) * n + r;
+      o[0] = S.a; o[n] = S.b; o[2 * n] = S.c; o[3 * n] = S.d;
+    }
+    acc[0] += S.a; acc[1] += S.b; acc[2] += S.c; acc[3] += S.d;
   }
   for (int t = 0; t < 4; ++t) claimed[t] = (u32)(acc[t] % P);
 }
@@ -487,29 +584,63 @@ void orc_composition(int kind, int n_cols, int n_rel, const u32* const* rel_val,
 /* ---------------------------------------------------------------------------------------------
  * eval_at_point: sum_j coeff_j * prod_k maps[k]^(bit k of j)  (Appendix A.2 basis; Horner-style fold)
  * ------------------------------------------------------------------------------------------- */
+/* The basis value of coefficient index j factors into a table over the low EV_LB bits of j and a table over the high
+ * bits: f(p) = sum_hi hiT[hi] * (sum_lo c[hi, lo] * loT[lo]).  The inner sums are M31 x QM31 dot products accumulated
+ * lazily in 64 bits (each product folded once to < 2^32, so 2^EV_LB terms stay far below 2^64). */
+#define EV_LB 10
+HOT static void eval_dot(const u32* c, long lo_n, const u32* la, const u32* lb, const u32* lc, const u32* ld, u64 acc[4]) {
+  u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (long k = 0; k < lo_n; ++k) {
+    const u64 v = c[k];
+    const u64 p0 = v * la[k], p1 = v * lb[k], p2 = v * lc[k], p3 = v * ld[k];
+    s0 += (p0 & P) + (p0 >> 31);
+    s1 += (p1 & P) + (p1 >> 31);
+    s2 += (p2 & P) + (p2 >> 31);
+    s3 += (p3 & P) + (p3 >> 31);
+  }
+  acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3;
+}
 void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 4 */, u32 out[4]) {
   const long n = 1L << log_n;
-  qm* acc = (qm*)malloc(sizeof(qm) * (size_t)(n > 1 ? n / 2 : 1));
-  if (log_n == 0) {
-    out[0] = coeffs[0]; out[1] = out[2] = out[3] = 0;
-    free(acc);
-    return;
+  const int lbits = log_n < EV_LB ? log_n : EV_LB;
+  const long lo_n = 1L << lbits, hi_n = n >> lbits;
+  u32* lo = (u32*)malloc(sizeof(u32) * 4 * (size_t)lo_n);
+  qm* hiT = (qm*)malloc(sizeof(qm) * (size_t)hi_n);
+  u32 *la = lo, *lb = lo + lo_n, *lc = lo + 2 * lo_n, *ld = lo + 3 * lo_n;
+  la[0] = 1; lb[0] = lc[0] = ld[0] = 0;
+  for (int k = 0; k < lbits; ++k) {
+    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
+    for (long j = 0; j < (1L << k); ++j) {
+      const qm t = {la[j], lb[j], lc[j], ld[j]};
+      const qm r = qmul(t, m);
+      const long d = j + (1L << k);
+      la[d] = r.a; lb[d] = r.b; lc[d] = r.c; ld[d] = r.d;
+    }
   }
+  hiT[0] = qfromm(1);
+  for (int k = lbits; k < log_n; ++k) {
+    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
+    const long half = 1L << (k - lbits);
+    for (long j = 0; j < half; ++j) hiT[j + half] = qmul(hiT[j], m);
+  }
+  u64 tot[4] = {0, 0, 0, 0};
+#pragma omp parallel if (par_ok(n * 8))
   {
-    const int k = log_n - 1;
-    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
-    const long half = n / 2;
-#pragma omp parallel for schedule(static) if (par_ok(half * 8))
-    for (long i = 0; i < half; ++i) acc[i] = qadd(qfromm(coeffs[i]), qmulm(m, coeffs[half + i]));
+    u64 loc[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static)
+    for (long h = 0; h < hi_n; ++h) {
+      u64 acc[4];
+      eval_dot(coeffs + h * lo_n, lo_n, la, lb, lc, ld, acc);
+      const qm inner = {(u32)(acc[0] % P), (u32)(acc[1] % P), (u32)(acc[2] % P), (u32)(acc[3] % P)};
+      const qm t = qmul(inner, hiT[h]);
+      loc[0] += t.a; loc[1] += t.b; loc[2] += t.c; loc[3] += t.d;
+    }
+#pragma omp critical
+    for (int t = 0; t < 4; ++t) tot[t] += loc[t] % P;
   }
-  for (int k = log_n - 2; k >= 0; --k) {
-    const qm m = {maps[4 * k], maps[4 * k + 1], maps[4 * k + 2], maps[4 * k + 3]};
-    const long half = 1L << k;
-#pragma omp parallel for schedule(static) if (par_ok(half * 8))
-    for (long i = 0; i < half; ++i) acc[i] = qadd(acc[i], qmul(acc[half + i], m));
-  }
-  out[0] = acc[0].a; out[1] = acc[0].b; out[2] = acc[0].c; out[3] = acc[0].d;
-  free(acc);
+  for (int t = 0; t < 4; ++t) out[t] = (u32)(tot[t] % P);
+  free(lo);
+  free(hiT);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -517,23 +648,130 @@ void orc_eval_at_point(const u32* coeffs, int log_n, const u32* maps /* log_n x 
  * [bstart[b], bstart[b+1]) of (col index, a, b, c) line coefficients (already alpha-weighted);
  * point (px, py) as QM31; batch_coeff = alpha^|batch|.  xs/ys: domain points in storage order.
  * ------------------------------------------------------------------------------------------- */
+/* One chunk of QCH rows, all batches.  The denominators are inverted together (stwo's batch inverse of the CM31
+ * denominators: here through their norms, batch_inverse_lanes); the sums over a batch's entries run lane-wise.
+ * sum_e (C_e f_e(s) - (A_e y + B_e)) = sum_e C_e f_e(s) - (SA y + SB) with SA, SB the batch's sums of A_e, B_e. */
+#define QCH 1024
+HOT static void quotients_chunk(const u32* const* cols, long s0, long L, int nbatch, const int* bstart, const int* col_idx,
+                                const u32* lc, const u32* sa /* 4 per batch */, const u32* sb, const u32* pts,
+                                const u32* batch_coeff, const u32* xs, const u32* ys, u32* out, u32* scratch) {
+  u32* dre = scratch;                      /* nbatch x QCH: denominator real / imaginary part, then its norm's inverse */
+  u32* dim = dre + (long)nbatch * QCH;
+  u32* nrm = dim + (long)nbatch * QCH;
+  u32* ninv = nrm + (long)nbatch * QCH;
+  u32* tmp = ninv + (long)nbatch * QCH;
+  u32* ra = tmp + (long)nbatch * QCH;      /* row accumulator, 4 x QCH */
+  u32 *rb = ra + QCH, *rc = rb + QCH, *rd = rc + QCH;
+  u32 *na = rd + QCH, *nb = na + QCH, *nc = nb + QCH, *nd = nc + QCH;   /* numerator, 4 x QCH */
+  const u32* x = xs + s0;
+  const u32* y = ys + s0;
+  for (int b = 0; b < nbatch; ++b) {
+    const u32* p = pts + 8 * b;
+    const u32 prx_a = p[0], prx_b = p[1], pix_a = p[2], pix_b = p[3], pry_a = p[4], pry_b = p[5], piy_a = p[6], piy_b = p[7];
+    u32* re = dre + (long)b * QCH;
+    u32* im = dim + (long)b * QCH;
+    u32* nn = nrm + (long)b * QCH;
+    for (int k = 0; k < QCH; ++k) {
+      /* den = (prx - x) * piy - (pry - y) * pix  in CM31, dx = (prx_a - x, prx_b), dy = (pry_a - y, pry_b) */
+      const u32 dxa = vmsub(prx_a, x[k]), dya = vmsub(pry_a, y[k]);
+      const u32 t1a = vmsub(vmmul(dxa, piy_a), vmmul(prx_b, piy_b)), t1b = vmadd(vmmul(dxa, piy_b), vmmul(prx_b, piy_a));
+      const u32 t2a = vmsub(vmmul(dya, pix_a), vmmul(pry_b, pix_b)), t2b = vmadd(vmmul(dya, pix_b), vmmul(pry_b, pix_a));
+      const u32 a = vmsub(t1a, t2a), bb = vmsub(t1b, t2b);
+      re[k] = a;
+      im[k] = bb;
+      nn[k] = vmadd(vmmul(a, a), vmmul(bb, bb));
+    }
+  }
+  batch_inverse_lanes(nrm, (long)nbatch * QCH, ninv, tmp);
+  for (int k = 0; k < QCH; ++k) ra[k] = rb[k] = rc[k] = rd[k] = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    for (int k = 0; k < QCH; ++k) na[k] = nb[k] = nc[k] = nd[k] = 0;
+    for (int e = bstart[b]; e < bstart[b + 1]; ++e) {
+      const u32 ca = lc[4 * e], cb = lc[4 * e + 1], cc = lc[4 * e + 2], cd = lc[4 * e + 3];
+      const u32* f = cols[col_idx[e]] + s0;
+      for (int k = 0; k < QCH; ++k) {
+        const u32 v = f[k];
+        na[k] = vmadd(na[k], vmmul(ca, v));
+        nb[k] = vmadd(nb[k], vmmul(cb, v));
+        nc[k] = vmadd(nc[k], vmmul(cc, v));
+        nd[k] = vmadd(nd[k], vmmul(cd, v));
+      }
+    }
+    const u32* A = sa + 4 * b;
+    const u32* B = sb + 4 * b;
+    const u32* bc = batch_coeff + 4 * b;
+    const u32* re = dre + (long)b * QCH;
+    const u32* im = dim + (long)b * QCH;
+    const u32* ni = ninv + (long)b * QCH;
+    for (int k = 0; k < QCH; ++k) {
+      const u32 yy = y[k];
+      /* num -= SA * y + SB */
+      const u32 n0 = vmsub(na[k], vmadd(vmmul(A[0], yy), B[0])), n1 = vmsub(nb[k], vmadd(vmmul(A[1], yy), B[1]));
+      const u32 n2 = vmsub(nc[k], vmadd(vmmul(A[2], yy), B[2])), n3 = vmsub(nd[k], vmadd(vmmul(A[3], yy), B[3]));
+      /* 1/den = conj(den) / norm */
+      const u32 ia = vmmul(re[k], ni[k]), ib = vmmul(vmsub(0, im[k]), ni[k]);
+      /* (n0 + n1 i) * inv, (n2 + n3 i) * inv */
+      const u32 q0 = vmsub(vmmul(n0, ia), vmmul(n1, ib)), q1 = vmadd(vmmul(n0, ib), vmmul(n1, ia));
+      const u32 q2 = vmsub(vmmul(n2, ia), vmmul(n3, ib)), q3 = vmadd(vmmul(n2, ib), vmmul(n3, ia));
+      /* row = row * bc + q   (QM31 product with the constant bc = (e + f i) + (g + h i) u, u^2 = 2 + i) */
+      const u32 a_ = ra[k], b_ = rb[k], c_ = rc[k], d_ = rd[k];
+      const u32 e_ = bc[0], f_ = bc[1], g_ = bc[2], h_ = bc[3];
+      /* A*C */
+      const u32 ac_a = vmsub(vmmul(a_, e_), vmmul(b_, f_)), ac_b = vmadd(vmmul(a_, f_), vmmul(b_, e_));
+      /* B*D */
+      const u32 bd_a = vmsub(vmmul(c_, g_), vmmul(d_, h_)), bd_b = vmadd(vmmul(c_, h_), vmmul(d_, g_));
+      /* (2 + i) * BD */
+      const u32 r_a = vmsub(vmadd(bd_a, bd_a), bd_b), r_b = vmadd(bd_a, vmadd(bd_b, bd_b));
+      /* A*D + B*C */
+      const u32 ad_a = vmsub(vmmul(a_, g_), vmmul(b_, h_)), ad_b = vmadd(vmmul(a_, h_), vmmul(b_, g_));
+      const u32 bc_a = vmsub(vmmul(c_, e_), vmmul(d_, f_)), bc_b = vmadd(vmmul(c_, f_), vmmul(d_, e_));
+      ra[k] = vmadd(vmadd(ac_a, r_a), q0);
+      rb[k] = vmadd(vmadd(ac_b, r_b), q1);
+      rc[k] = vmadd(vmadd(ad_a, bc_a), q2);
+      rd[k] = vmadd(vmadd(ad_b, bc_b), q3);
+    }
+  }
+  for (int k = 0; k < QCH; ++k) {
+    out[s0 + k] = ra[k];
+    out[L + s0 + k] = rb[k];
+    out[2 * L + s0 + k] = rc[k];
+    out[3 * L + s0 + k] = rd[k];
+  }
+}
+
 void orc_quotients(const u32* const* cols, long L, int nbatch, const int* bstart, const int* col_idx,
                    const u32* la, const u32* lb, const u32* lc /* 4 words per entry */, const u32* pts /* 8/batch */,
                    const u32* batch_coeff /* 4/batch */, const u32* xs, const u32* ys, u32* out) {
-#pragma omp parallel for schedule(static) if (par_ok(L * 64))
-  for (long s = 0; s < L; ++s) {
+  /* per batch: SA = sum of the entries' a coefficients, SB = sum of the b coefficients */
+  u32* sa = (u32*)calloc((size_t)nbatch * 8, sizeof(u32));
+  u32* sb = sa + (size_t)nbatch * 4;
+  for (int b = 0; b < nbatch; ++b)
+    for (int e = bstart[b]; e < bstart[b + 1]; ++e)
+      for (int t = 0; t < 4; ++t) {
+        sa[4 * b + t] = madd(sa[4 * b + t], la[4 * e + t]);
+        sb[4 * b + t] = madd(sb[4 * b + t], lb[4 * e + t]);
+      }
+  const long nchunks = L / QCH;
+#pragma omp parallel if (par_ok(L * 64))
+  {
+    u32* scratch = (u32*)malloc(sizeof(u32) * ((size_t)nbatch * 5 + 8) * QCH);
+#pragma omp for schedule(static)
+    for (long c = 0; c < nchunks; ++c)
+      quotients_chunk(cols, c * QCH, L, nbatch, bstart, col_idx, lc, sa, sb, pts, batch_coeff, xs, ys, out, scratch);
+    free(scratch);
+  }
+  /* domains below QCH rows (and a ragged tail, which power-of-two domains do not have): one row at a time */
+  for (long s = nchunks * QCH; s < L; ++s) {
     const u32 x = xs[s], y = ys[s];
     qm row = QZERO;
     for (int b = 0; b < nbatch; ++b) {
       qm num = QZERO;
       for (int e = bstart[b]; e < bstart[b + 1]; ++e) {
-        qm A = {la[4 * e], la[4 * e + 1], la[4 * e + 2], la[4 * e + 3]};
-        qm B = {lb[4 * e], lb[4 * e + 1], lb[4 * e + 2], lb[4 * e + 3]};
         qm C = {lc[4 * e], lc[4 * e + 1], lc[4 * e + 2], lc[4 * e + 3]};
-        qm value = qmulm(C, cols[col_idx[e]][s]);
-        qm linear = qadd(qmulm(A, y), B);
-        num = qadd(num, qsub(value, linear));
+        num = qadd(num, qmulm(C, cols[col_idx[e]][s]));
       }
+      qm SA = {sa[4 * b], sa[4 * b + 1], sa[4 * b + 2], sa[4 * b + 3]}, SB = {sb[4 * b], sb[4 * b + 1], sb[4 * b + 2], sb[4 * b + 3]};
+      num = qsub(num, qadd(qmulm(SA, y), SB));
       const u32* p = pts + 8 * b;
       cm prx = {p[0], p[1]}, pix = {p[2], p[3]}, pry = {p[4], p[5]}, piy = {p[6], p[7]};
       cm dx = {msub(prx.a, x), prx.b}, dy = {msub(pry.a, y), pry.b};
@@ -543,6 +781,7 @@ void orc_quotients(const u32* const* cols, long L, int nbatch, const int* bstart
     }
     out[s] = row.a; out[L + s] = row.b; out[2 * L + s] = row.c; out[3 * L + s] = row.d;
   }
+  free(sa);
 }
 
 /* FRI fold of adjacent pairs: dst[i] = [dst[i]*alpha^2 +] (a+b) + alpha*((a-b)*itw[i])  (Appendix A.8) */

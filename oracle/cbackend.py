@@ -41,6 +41,19 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _rows_as_block(rows):
+    """2-D array over a list of equal-length rows: without a copy when the rows are consecutive rows of one array
+    (what `lde` / `interpolate_cols` hand out), else stacked."""
+    base = rows[0].base
+    if isinstance(base, np.ndarray) and base.ndim == 2 and base.dtype == U32 and base.flags["C_CONTIGUOUS"] and \
+            all(r.base is base and r.dtype == U32 for r in rows):
+        stride = base.strides[0]
+        i0 = (rows[0].ctypes.data - base.ctypes.data) // stride
+        if all(r.ctypes.data == base.ctypes.data + (i0 + k) * stride and r.shape == (base.shape[1],) for k, r in enumerate(rows)):
+            return base[i0:i0 + len(rows)]
+    return np.ascontiguousarray(np.stack([np.asarray(r, dtype=U32) for r in rows]))
+
+
 class CKernels:
     name = "c"
 
@@ -175,9 +188,15 @@ class CKernels:
             cpq, nc = air.component_coeffs(comp, ci.flags, powers, n_total, k0)
             cp = np.array([c.v for c in cpq], dtype=U32)
             k0 += nc
-            main_e = self._evaluate(np.stack([np.asarray(tree1.coeffs[i], dtype=U32) for i in range(*ci.main_span)]), e)
-            inter_e = self._evaluate(np.stack([np.asarray(tree2.coeffs[i], dtype=U32) for i in range(*ci.inter_span)]), e)
-            pre_e = [self._evaluate(np.asarray(tree0.coeffs[i], dtype=U32).reshape(1, -1), e)[0] for i in ci.pre_idx]
+            # the evaluation domain of a component is its committed LDE at blow-up 2 (stwo reuses the committed
+            # evaluations when the sizes agree); other blow-ups evaluate the coefficients again
+            def on_eval_domain(tree, idx):
+                if all(len(tree.evals[i]) == E for i in idx):
+                    return _rows_as_block([tree.evals[i] for i in idx])
+                return self._evaluate(np.stack([np.asarray(tree.coeffs[i], dtype=U32) for i in idx]), e)
+            main_e = on_eval_domain(tree1, range(*ci.main_span))
+            inter_e = on_eval_domain(tree2, range(*ci.inter_span))
+            pre_e = [on_eval_domain(tree0, [i])[0] for i in ci.pre_idx]
             prev = np.ascontiguousarray(prev_row_indices(ci.log_size, e), dtype=np.int64)
             zkey = ("zinv", e, ci.log_size)
             if zkey not in self._tw:

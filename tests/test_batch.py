@@ -142,3 +142,62 @@ def test_gpu_batch_rejects_mixed_shapes_and_a_bad_pie_fails_alone(gpu_prover):
         assert bp.prove_batch(good) == [solo.ctx.prove_tables(p) for p in good]
     finally:
         bp.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_grows_across_calls(gpu_prover):
+    """A batch that uses more slots, then a larger shape, than the batches before it: the contexts that prove a shape
+    for the first time build their twiddle tables outside lock-step (before the members start), so members that have
+    the tables and members that do not issue the same launch sequence."""
+    import luminair_amd
+    from luminair_amd.batch import BatchProver
+    solo = luminair_amd.Prover(0, protocol_variant=backend.VARIANT_PINNED)
+    bp = BatchProver(0, 4, protocol_variant=backend.VARIANT_PINNED)
+    try:
+        small = [[(k, r, len(r)) for k, r in syn.config2_graph_faithful(200, 20 + i)] for i in range(4)]
+        big = [[(k, r, len(r)) for k, r in syn.config2_graph_faithful(3000, 30 + i)] for i in range(4)]
+        assert bp.prove_batch(small[:2]) == [solo.ctx.prove_tables(p) for p in small[:2]]      # slots 0-1 only
+        assert bp.prove_batch(small) == [solo.ctx.prove_tables(p) for p in small]              # slots 2-3 are new
+        assert bp.prove_batch(big[:3]) == [solo.ctx.prove_tables(p) for p in big[:3]]          # larger domain on 0-2
+        assert bp.prove_batch(big) == [solo.ctx.prove_tables(p) for p in big]                  # ... and on 3
+        assert bp.prove_batch(small) == [solo.ctx.prove_tables(p) for p in small]
+    finally:
+        bp.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_pie_with_a_non_canonical_word_fails_alone(gpu_prover):
+    """One pie of a batch holds a word >= 2^31 - 1: that pie is rejected (invalid argument), the other proofs are
+    produced, and the slot that saw the bad word proves correctly in the next batch (the verdict word is never reset:
+    each proof has its own mark)."""
+    import luminair_amd
+    from luminair_amd.batch import BatchProver
+    solo = luminair_amd.Prover(0, protocol_variant=backend.VARIANT_PINNED)
+    bp = BatchProver(0, 4, protocol_variant=backend.VARIANT_PINNED)
+    try:
+        good = [[(k, r, len(r)) for k, r in syn.config2_graph_faithful(256, 40 + i)] for i in range(4)]
+        bad = [(k, r.copy(), n) for k, r, n in good[1]]
+        bad[0][1][7, 9] = (1 << 31) - 1
+        lib = bp.lib.lib
+        n = 4
+        pies = [good[0], bad, good[2], good[3]]
+        arrs = (C.POINTER(backend.LmnTable) * n)()
+        keep = []
+        for i, t in enumerate(pies):
+            arr, nt, st, k = backend.Context._marshal_tables(None, t, None)
+            keep.append(k)
+            arrs[i] = C.cast(arr, C.POINTER(backend.LmnTable))
+        proofs, lens, rcs = (C.POINTER(C.c_uint8) * n)(), (C.c_size_t * n)(), (C.c_int * n)()
+        rc = lib.lmn_batch_prove(bp.handle, n, arrs, nt, C.byref(st), proofs, lens, rcs)
+        assert rc == backend.ERR_INVALID_ARGUMENT and list(rcs) == [0, backend.ERR_INVALID_ARGUMENT, 0, 0]
+        for i in (0, 2, 3):
+            assert C.string_at(proofs[i], lens[i]) == solo.ctx.prove_tables(pies[i])
+            lib.lmn_free(proofs[i])
+        for _ in range(2):     # the same slots again, all four pies good
+            assert bp.prove_batch(good) == [solo.ctx.prove_tables(p) for p in good]
+        # the solo prover after a rejected pie
+        with pytest.raises(backend.LuminairBackendError):
+            solo.ctx.prove_tables(bad)
+        assert solo.ctx.prove_tables(good[1]) == bp.prove_batch([good[1]])[0]
+    finally:
+        bp.close()
