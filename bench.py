@@ -164,7 +164,8 @@ def cpu_baseline(sample_log, full_log):
     """The oracle's plain-C restatement (oracle/c/stark_kernels.c, OpenMP, driven by oracle/prover.py) timed on this
     box on the same workload, in its own process (oracle/cpu_baseline.py says why): one cold proof (builds the
     twiddle/domain tables, as the reference does per proof), three warm ones, and the reference's own published
-    32x32 Add shape.  Run twice - on ALL physical cores of the host and on 64 pinned threads (one socket's worth;
+    32x32 Add shape.  kind "port" = the build whose hot loops run 16 M31 lanes per operation (AVX-512 / AVX2 by
+    cpuid: the stand-in for stwo's SimdBackend, BASELINE.md section 3); `port_scalar` = the same source without lanes.  Run twice - on ALL physical cores of the host and on 64 pinned threads (one socket's worth;
     the faster one on a 2-socket EPYC in round 2) - `value` is the better of the two, `cores` the threads it used,
     `by_threads` both.  Bounded: a few seconds of CPU work each."""
     phys = physical_cores()
@@ -175,6 +176,7 @@ def cpu_baseline(sample_log, full_log):
     res = dict(runs[best])
     res["host_physical_cores"] = phys
     res["by_threads"] = {str(t): {"value": r["value"], "sample": r["sample"],
+                                  "port_scalar_value": r.get("port_scalar", {}).get("value"),
                                   "reference_shape_32x32_add_ms": r["reference_shape_32x32_add_ms"]} for t, r in runs.items()}
     return res
 

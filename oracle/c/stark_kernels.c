@@ -90,7 +90,11 @@ static const qm QZERO = {0, 0, 0, 0};
  * compares it with the numpy restatement); only the order of independent butterflies changes.
  * HOT marks the functions compiled for AVX-512 / AVX2 / baseline x86-64 and dispatched by cpuid at load time: the
  * library is built in one container and travels to other hosts. */
+#ifdef ORC_SCALAR /* liboracle_kernels_scalar.so: one scalar instance of every function, vectoriser off (Makefile) */
+#define HOT
+#else
 #define HOT __attribute__((target_clones("arch=skylake-avx512", "avx2", "default")))
+#endif
 #define FFT_G 16
 #define PAR_MIN (1L << 15) /* below this many words an OpenMP team costs more than it saves */
 #include <omp.h>
@@ -826,6 +830,23 @@ void orc_merkle_layer(const u32* prev, const u32* const* cols, int ncols, long s
     }
     memcpy(out + 8 * i, h, 32);
   }
+}
+
+/* `write_trace` (add/witness.rs:33-108): AoS rows -> SoA columns of `size` rows, rows past n_rows = the padding row.
+ * Returns 1 if a word is not a canonical M31. */
+int orc_transpose_pad(const u32* rows, long n_rows, int ncols, long size, const u32* pad, u32* cols) {
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad) if (par_ok(size * (long)ncols))
+  for (long r0 = 0; r0 < size; r0 += 64) {
+    const long r1 = r0 + 64 < size ? r0 + 64 : size;
+    for (int c = 0; c < ncols; ++c)
+      for (long r = r0; r < r1; ++r) {
+        const u32 v = r < n_rows ? rows[r * (long)ncols + c] : pad[c];
+        bad |= v >= P;
+        cols[(long)c * size + r] = v;
+      }
+  }
+  return bad;
 }
 
 /* out[i] = 1/v[i] (Montgomery batch inversion in chunks, chunks in parallel) */

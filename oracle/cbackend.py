@@ -26,11 +26,16 @@ _SO = os.path.join(_HERE, "c", "liboracle_kernels.so")
 U32 = np.uint32
 
 
-def build():
+def build(scalar: bool = False):
+    """Path of the kernel library (built on demand): the 16-lane build, or with scalar=True / ORACLE_KERNELS=scalar
+    the same source compiled without lanes and without the vectoriser (cpu_baseline's "port-scalar")."""
+    so = _SO
+    if scalar or os.environ.get("ORACLE_KERNELS") == "scalar":
+        so = os.path.join(_HERE, "c", "liboracle_kernels_scalar.so")
     src = os.path.join(_HERE, "c", "stark_kernels.c")
-    if not os.path.exists(_SO) or os.path.getmtime(src) > os.path.getmtime(_SO):
-        subprocess.run(["make", "-C", os.path.join(_HERE, "c")], check=True, capture_output=True)
-    return _SO
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.run(["make", "-C", os.path.join(_HERE, "c"), "all"], check=True, capture_output=True)
+    return so
 
 
 def _q4(q: QM31):
@@ -57,11 +62,27 @@ def _rows_as_block(rows):
 class CKernels:
     name = "c"
 
-    def __init__(self, threads: int = 0):
-        self.lib = C.CDLL(build())
+    def __init__(self, threads: int = 0, scalar: bool = False):
+        self.lib = C.CDLL(build(scalar))
         if threads:
             os.environ["OMP_NUM_THREADS"] = str(threads)
         self._tw = {}
+
+    def pad_table(self, comp, rows):
+        """`air.pad_table` (AoS rows -> padded SoA columns) without the 64-bit detour: (n_cols, 2^log_size) uint32."""
+        rows = np.ascontiguousarray(np.asarray(rows).reshape(-1, comp.n_cols))
+        if rows.dtype != U32:
+            if rows.size and int(rows.max()) >= P:
+                raise ValueError("non-canonical M31 word")
+            rows = rows.astype(U32)
+        n = rows.shape[0]
+        if n == 0:
+            raise ValueError("EmptyTrace")  # TraceError::EmptyTrace, add/witness.rs:39-41
+        size = max(1 << (n - 1).bit_length(), 16)
+        out = np.empty((comp.n_cols, size), dtype=U32)
+        pad = np.array(comp.padding, dtype=U32)
+        self.lib.orc_transpose_pad(_ptr(rows), C.c_long(n), C.c_int(comp.n_cols), C.c_long(size), _ptr(pad), _ptr(out))
+        return out
 
     # ---- twiddles (computed by the numpy restatement of the domain; uploaded as uint32 tables)
     def _twiddles(self, log_n, inverse):
@@ -88,7 +109,7 @@ class CKernels:
             j = i
             while j < len(cols) and len(cols[j]) == len(cols[i]):
                 j += 1
-            block = np.ascontiguousarray(np.stack(cols[i:j]), dtype=U32)
+            block = np.array(_rows_as_block(cols[i:j]) if cols[i].dtype == U32 else np.stack(cols[i:j]), dtype=U32, order="C")
             self._fft(block, len(cols[i]).bit_length() - 1, True)
             out.extend(list(block))
             i = j
@@ -173,7 +194,10 @@ class CKernels:
                                    claimed)
         cl = QM31(*claimed)
         shift = cl / QM31(n % P)
-        order = np.ascontiguousarray(coset_order_storage_indices(n.bit_length() - 1), dtype=np.int64)
+        okey = ("order", n)
+        if okey not in self._tw:   # a function of the size alone, like the twiddles
+            self._tw[okey] = np.ascontiguousarray(coset_order_storage_indices(n.bit_length() - 1), dtype=np.int64)
+        order = self._tw[okey]
         last = out[4 * (k - 1):]
         self.lib.orc_logup_prefix(_ptr(last), C.c_long(n), _ptr(order), _q4(shift))
         return [out[i] for i in range(4 * k)], cl
@@ -197,7 +221,10 @@ class CKernels:
             main_e = on_eval_domain(tree1, range(*ci.main_span))
             inter_e = on_eval_domain(tree2, range(*ci.inter_span))
             pre_e = [on_eval_domain(tree0, [i])[0] for i in ci.pre_idx]
-            prev = np.ascontiguousarray(prev_row_indices(ci.log_size, e), dtype=np.int64)
+            pkey = ("prev", ci.log_size, e)
+            if pkey not in self._tw:
+                self._tw[pkey] = np.ascontiguousarray(prev_row_indices(ci.log_size, e), dtype=np.int64)
+            prev = self._tw[pkey]
             zkey = ("zinv", e, ci.log_size)
             if zkey not in self._tw:
                 xs, _ = self._domain(e)

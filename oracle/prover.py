@@ -420,7 +420,7 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
             raise ProvingError("component kind %d has no claim slot in this protocol variant" % kind)
         comp = COMPONENTS[kind]
         try:
-            cols = air.pad_table(comp, rows)
+            cols = K.pad_table(comp, rows) if hasattr(K, "pad_table") else air.pad_table(comp, rows)
         except ValueError as e:
             raise ProvingError("TraceError(EmptyTrace)") from e
         seen[kind] = (comp, cols)

@@ -63,3 +63,14 @@ def test_c_kernels_individually(ck):
     pt = (QM31(*[int(v) for v in rng.integers(0, P, size=4)]), QM31(*[int(v) for v in rng.integers(0, P, size=4)]))
     c = rng.integers(0, P, size=1 << 11, dtype=np.uint64)
     assert ck.eval_at_point(c, pt) == fft.eval_at_point(c, pt)
+
+
+def test_scalar_build_of_the_c_oracle_gives_the_same_bytes(ck, kat_bytes):
+    """liboracle_kernels_scalar.so (no lanes, vectoriser off: cpu_baseline's "port-scalar") against the 16-lane build,
+    at sizes where the chunked batch inversions and the row-at-a-time tails both run."""
+    from oracle.cbackend import CKernels
+    ks = CKernels(scalar=True)
+    assert ks.lib._name.endswith("liboracle_kernels_scalar.so")
+    assert to_bincode(prove(syn.simple_example(), kernels=ks)) == kat_bytes
+    for tabs, variant in ((syn.chain_graph(3000, 3), ProtocolVariant.KAT), (syn.sqrt_rem_graph(700, 4), ProtocolVariant.PINNED)):
+        assert to_bincode(prove(tabs, variant=variant, kernels=ks)) == to_bincode(prove(tabs, variant=variant, kernels=ck))
