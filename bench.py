@@ -25,11 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
-# ALU ceilings measured on MI355X with both VALU issue ports in use (tools/microbench_reconcile.hip `prio` / `bfly`,
-# profiles/r3_valu_coissue.txt); informational only
-BLAKE2S_PEAK_GCOMP = 63.8    # G compressions/s chip-wide: 1024 SIMDs x 2.235 GHz x 0.425 instr/clk x 64 lanes / 976 instr
-BUTTERFLY_PEAK_G = 4800.0    # G M31 butterflies/s chip-wide: 0.035 butterflies/clk/SIMD x 2.08 GHz x 1024 SIMDs x 64 lanes
+from luminair_amd.roofline import HBM_PEAK_GBS  # noqa: E402  (ceilings and the `roofline` objects: luminair_amd/roofline.py)
 
 
 def parse_args(argv=None):
@@ -342,8 +338,10 @@ def main(argv=None):
     # rank's ~3.4 busy CPUs, the library's waits sleep between polls from the start (LMN_SPIN_US=0: 1.7 CPUs per rank, - 1 %
     # proofs/s where CPUs are plentiful).  Set before the library is loaded; an explicit LMN_SPIN_US wins.
     budget = cpu_budget()
-    if world > 1 and budget < 4 * world:
-        os.environ.setdefault("LMN_SPIN_US", "0")
+    spin_set_by_bench = False
+    if world > 1 and budget < 4 * world and "LMN_SPIN_US" not in os.environ:
+        os.environ["LMN_SPIN_US"] = "0"
+        spin_set_by_bench = True
     import numpy as np
     import torch
     import luminair_amd
@@ -468,68 +466,23 @@ def main(argv=None):
     # roofline per kernel family, from HIP events recorded by the library on the prover's own stream
     # around every transform / tree of the solo proof above (lmn_timings).  `traffic` comes from the
     # committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
-    # applied: 2*FETCH_SIZE + WRITE_SIZE), per launch like `achieved`.
+    # applied: 2*FETCH_SIZE + WRITE_SIZE), per launch like `achieved`.  The objects are built in luminair_amd/roofline.py.
+    from luminair_amd import roofline as rf
     tm = prover.timings()
-    pmc = {}
-    pmc_source = None
-    try:
-        for cand in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
-            pth = os.path.join(ROOT, "profiles", cand)
-            if os.path.exists(pth):
-                with open(pth) as f:
-                    pmc = json.load(f)["kernels"]
-                pmc_source = "profiles/" + cand
-                break
-    except Exception:
-        pass
-    fams = {
-        "k_fft_fx": (tm["fft_ms"], tm["fft_bytes"], tm["fft_launches"],
-                         ["k_fft_staged<false>", "k_fft_staged<true>", "k_fft_interp_extend", "k_fft_fx", "k_fft_interp_extend_fx"]),
-        "k_merkle_fused": (tm["merkle_fused_ms"], tm["merkle_fused_bytes"], tm["merkle_fused_launches"],
-                           ["k_merkle_fused", "k_merkle_fused<0>", "k_merkle_fused<1>", "k_merkle_fused<2>", "k_merkle_fused<3>"]),
-    }
-    alu = {
-        "k_fft_fx": (tm["fft_butterflies"], BUTTERFLY_PEAK_G, "G butterflies/s"),
-        "k_merkle_fused": (tm["merkle_fused_compressions"], BLAKE2S_PEAK_GCOMP, "G Blake2s compressions/s"),
-    }
-
-    def roof(name):
-        ms, nbytes, launches, pmc_names = fams[name]
-        launches = max(launches, 1)
-        achieved = nbytes / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
-        traffic = None
-        got = [v for k, v in pmc.items() if any(k == n or k.startswith(n + "<") for n in pmc_names)]
-        if got:
-            tot_l = sum(g["launches"] for g in got)
-            traffic = sum(g["hbm_bytes_per_launch_corrected"] * g["launches"] for g in got) / max(tot_l, 1)
-        ops, alu_peak, alu_unit = alu[name]
-        alu_achieved = ops / (1e-3 * ms) / 1e9 if ms > 0 else 0.0
-        # what the kernel is bound by: the ceiling it sits closer to.  `achieved` / `peak` / `frac` stay the HBM figures
-        # of the contract (algorithmic bytes per launch / HIP-event time); `alu_ceiling` carries the VALU side and
-        # `traffic_vs_algorithmic` the counter-measured HBM bytes against the algorithmic ones
-        valu_bound = alu_achieved / alu_peak > achieved / HBM_PEAK_GBS
-        return {"bound": "valu" if valu_bound else "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_vs_algorithmic": (traffic / (nbytes / launches)) if traffic and nbytes else None,
-                "traffic_source": (pmc_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)")
-                if traffic is not None and pmc_source else None,
-                "launches_per_proof": launches,
-                "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": nbytes / launches,
-                "alu_ceiling": {"achieved": alu_achieved, "peak_measured": alu_peak, "unit": alu_unit,
-                                "frac": alu_achieved / alu_peak}}
-
-    dom = max(fams, key=lambda k: fams[k][0])
-    roofline = roof(dom)
-    roofline_other = [roof(k) for k in fams if k != dom]
-
-    # whole-proof figure against SURVEY.md §8d's minimum-traffic model of the WHOLE proof (48*C*N + 1500*N bytes, C = 27
-    # columns: every pass of every stage counted once - not the per-pass Merkle formula `roofline` uses for its launches)
-    model_bytes = (48 * 27 + 1500) * float(1 << args.log_rows)
-    whole = {"byte_model": "SURVEY.md §8(d) whole-proof minimum-traffic model: 48*C*N + 1500*N bytes, C = 27, N = 2^%d "
-                           "(all stages; differs from the per-launch Merkle bytes behind `roofline`)" % args.log_rows,
-             "model_bytes_per_proof": model_bytes, "achieved": model_bytes / (1e-3 * ms_per_proof) / 1e9 * world,
-             "peak": HBM_PEAK_GBS * world, "unit": "GB/s"}
-    whole["frac"] = whole["achieved"] / whole["peak"]
+    # the committed counter summary is of the 2^20-row workload on the GPU: no `traffic` for anything else
+    pmc, pmc_source = rf.load_pmc(ROOT) if (args.log_rows == 20 and not emu) else ({}, None)
+    fams = {name: tm[rf.KERNEL_FAMILIES[name][0] + "_ms"] for name in rf.KERNEL_FAMILIES}
+    dom = max(fams, key=lambda k: fams[k])
+    roofline = rf.kernel_roofline(dom, tm, pmc, pmc_source)
+    roofline_other = [rf.kernel_roofline(k, tm, pmc, pmc_source) for k in fams if k != dom]
+    counter_total = None
+    if pmc:
+        try:
+            counter_total = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in pmc.values()) / max(
+                1, next(v["launches"] for k, v in pmc.items() if k.startswith("k_transpose_pad")))
+        except (KeyError, StopIteration):
+            counter_total = None
+    whole = rf.whole_proof(args.log_rows, ms_per_proof, world, counter_total)
 
     def sub_result(name, fn):
         try:
@@ -614,6 +567,8 @@ def main(argv=None):
                    "proofs_in_flight_per_gpu": inflight, "ranks_in_process_group": ranks_seen,
                    "collective_backend": ("nccl (RCCL)" if has_cuda else "gloo") if use_dist else None,
                    "host_cpu_budget": round(budget, 1), "host_wait_spin_us": os.environ.get("LMN_SPIN_US", "1200 (default)"),
+                   "host_wait_policy_set_by_bench": spin_set_by_bench,   # True: fewer than 4 CPUs per rank, waits sleep between polls
+                   "ms_per_step_is": "per batch of %d proofs (rounds 1-3: per proof; compare `ms_per_proof` / `short_region`)" % inflight,
                    "proof_bytes": len(out["proof"])},
         "prove_latency_ms": latency_ms,
         "prove_latency_p95_ms": latency_p95_ms,
