@@ -91,6 +91,92 @@ def cpu_budget():
     return n
 
 
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _format_cpulist(cpus):
+    cpus, out, i = sorted(cpus), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append("%d" % cpus[i] if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def gpu_local_cpus(pci_bdf, sysfs="/sys/bus/pci/devices"):
+    """(NUMA node, CPUs local to it) of the PCI device `pci_bdf` ("0000:c1:00.0"), from sysfs - the data
+    `rocm-smi --showtoponuma` prints; (None, empty set) when sysfs does not say."""
+    base = os.path.join(sysfs, pci_bdf)
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        node = None
+    try:
+        cpus = _parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except (OSError, ValueError):
+        cpus = set()
+    return (node if node is not None and node >= 0 else None), cpus
+
+
+def rank_cpu_slice(local_cpus, allowed, ranks_sharing, index):
+    """CPUs for one of `ranks_sharing` ranks whose GPUs sit on the same NUMA node: an equal contiguous share of the
+    node's CPUs this process may use (whole cores stay together when SMT siblings are numbered n and n + N/2 only by
+    luck - the share is by CPU number).  Empty when there is nothing to slice."""
+    cpus = sorted(set(local_cpus) & set(allowed))
+    if not cpus or ranks_sharing < 1:
+        return set()
+    per = len(cpus) // ranks_sharing
+    if per < 2:                       # fewer than 2 CPUs per rank: leave the scheduler alone
+        return set()
+    return set(cpus[index * per:(index + 1) * per])
+
+
+def pin_rank_to_gpu_numa_node(local_rank, world):
+    """N > 1: keep this rank's threads (8 proof drivers + their pollers; ~3.4 busy CPUs at full rate) on the CPUs of its
+    GPU's NUMA node, an equal share per rank of that node - the host work of a proof touches page-locked staging memory
+    the GPU reads.  Returns what was done, for the bench line.  LMN_BENCH_AFFINITY=0 switches it off."""
+    info = {"pinned": False}
+    if world < 2 or os.environ.get("LMN_BENCH_AFFINITY", "1") == "0":
+        info["reason"] = "off" if world > 1 else "single rank"
+        return info
+    try:
+        import torch
+        allowed = os.sched_getaffinity(0)
+        n_gpus = torch.cuda.device_count()
+        nodes = {}
+        for g in range(n_gpus):
+            pr = torch.cuda.get_device_properties(g)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            nodes[g] = gpu_local_cpus(bdf) + (bdf,)
+        if local_rank not in nodes:
+            info["reason"] = "no such GPU"
+            return info
+        node, cpus, bdf = nodes[local_rank]
+        info.update({"gpu_pci": bdf, "numa_node": node})
+        if not cpus:
+            info["reason"] = "sysfs has no local_cpulist for the GPU"
+            return info
+        sharing = sorted(g for g in range(min(world, n_gpus)) if nodes[g][1] == cpus)
+        mine = rank_cpu_slice(cpus, allowed, len(sharing), sharing.index(local_rank))
+        if not mine:
+            info["reason"] = "fewer than 2 usable CPUs per rank on the GPU's node"
+            return info
+        os.sched_setaffinity(0, mine)
+        info.update({"pinned": True, "cpus": _format_cpulist(mine), "ranks_on_node": len(sharing)})
+    except Exception as e:  # noqa: BLE001 - affinity is an optimisation, never a reason to fail the run
+        info["reason"] = "%s: %s" % (type(e).__name__, e)
+    return info
+
+
 def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -324,7 +410,9 @@ def main(argv=None):
     # RCCL prints a version banner on STDOUT when a communicator is created unless told otherwise; the contract is
     # ONE JSON line on stdout
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":   # leave a real debug level alone
-        os.environ["NCCL_DEBUG"] = "NONE"
+        # warnings only, into a per-process file (stdout carries ONE JSON line): dumped to stderr if a multi-GPU step fails
+        os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/lmn_bench_rccl.%h.%p.log")
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
@@ -337,6 +425,7 @@ def main(argv=None):
     # 2 CPUs loses 10 - 20 %, profiles/r4_host_cpu_wait_policy.jsonl): when the node's CPU budget is below what the default needs - a
     # rank's ~3.4 busy CPUs, the library's waits sleep between polls from the start (LMN_SPIN_US=0: 1.7 CPUs per rank, - 1 %
     # proofs/s where CPUs are plentiful).  Set before the library is loaded; an explicit LMN_SPIN_US wins.
+    affinity = pin_rank_to_gpu_numa_node(local_rank, world) if args.emu_library is None else {"pinned": False, "reason": "emulation"}
     budget = cpu_budget()
     spin_set_by_bench = False
     if world > 1 and budget < 4 * world and "LMN_SPIN_US" not in os.environ:
@@ -445,6 +534,11 @@ def main(argv=None):
     # CPU-limited container (tools/host_cpu_per_proof.py; the library's waits back off to sleeps under load)
     host_cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     agg = aggregate(elapsed, world, args.steps, reduce_max, inflight)
+    per_rank = [{"rank": rank, "proofs_per_s": args.steps * inflight / elapsed, "affinity": affinity}]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     ms_per_proof = 1e3 / (agg["value"] / world)        # per-GPU time per proof at this throughput
     # the rounds 1-3 form of the driver's command: 20 single proofs after 5, a 30 ms region that starts and ends drained
     short_elapsed = timed_region(step_one, 20, 5, barrier, device_sync)
@@ -566,6 +660,9 @@ def main(argv=None):
                    "parallelism": "proof-sharded x%d" % world,
                    "proofs_in_flight_per_gpu": inflight, "ranks_in_process_group": ranks_seen,
                    "collective_backend": ("nccl (RCCL)" if has_cuda else "gloo") if use_dist else None,
+                   "per_rank_proofs_per_s": {"min": min(r["proofs_per_s"] for r in per_rank), "max": max(r["proofs_per_s"] for r in per_rank),
+                                             "all": [round(r["proofs_per_s"], 1) for r in per_rank]},
+                   "cpu_affinity": [r["affinity"] for r in per_rank],
                    "host_cpu_budget": round(budget, 1), "host_wait_spin_us": os.environ.get("LMN_SPIN_US", "1200 (default)"),
                    "host_wait_policy_set_by_bench": spin_set_by_bench,   # True: fewer than 4 CPUs per rank, waits sleep between polls
                    "ms_per_step_is": "per batch of %d proofs (rounds 1-3: per proof; compare `ms_per_proof` / `short_region`)" % inflight,
@@ -670,12 +767,23 @@ def main(argv=None):
         # line is printed even if the multi-GPU transport misbehaves on this node.
         import threading
 
+        def dump_rccl_logs():
+            import glob
+            for pth in sorted(glob.glob("/tmp/lmn_bench_rccl.*.log")):
+                try:
+                    txt = open(pth).read().strip()
+                except OSError:
+                    continue
+                if txt:
+                    sys.stderr.write("---- RCCL warnings (%s)\n%s\n" % (pth, txt[-4000:]))
+
         def give_up():
             # a multi-GPU transport that hangs on this node is an infrastructure problem, not a rejected proof: the
             # headline (independent proofs, measured above) is still printed and the exit status stays 0; the line
             # says what happened in `warnings`
+            dump_rccl_logs()
             if rank == 0:
-                line["sharded_proof"] = {"error": "timed out (watchdog)"}
+                line.setdefault("sharded_proof", {})["error"] = "timed out (watchdog)"
                 line["errors"] = errors
                 line["warnings"] = ["sharded_proof: no result within %s s (watchdog)"
                                     % os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "300")]
@@ -742,6 +850,7 @@ def main(argv=None):
                 if "bytes differ" in str(e) or rejected:      # a valid proof request rejected, or different bytes
                     raise
                 line.setdefault("warnings", []).append("sharded_proof: %s: %s" % (type(e).__name__, e))
+                dump_rccl_logs()
                 return {"error": "%s: %s" % (type(e).__name__, e)}
         line["sharded_proof"] = {}
         for name, stabs, what, variant, luts, n_sh in sharded_workloads():

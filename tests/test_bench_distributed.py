@@ -139,3 +139,42 @@ def test_throughput_never_puts_two_threads_into_one_context():
         raise AssertionError("a failing context must fail the sub-result")
     except RuntimeError as e:
         assert "ConstraintsNotSatisfied" in str(e)
+
+
+def test_bench_gpus_8_over_gloo_with_the_emulation_build():
+    """The 8-rank launch the driver's node will see first, end to end on CPU (gloo, emulation build): 8 ranks in the
+    process group, per-rank throughput and affinity records in the line, the sharded sub-result over all 8 ranks."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    r, line = _run_bench(["--gpus", "8", "--emu-library", emu, "--log-rows", "5", "--steps", "2", "--warmup", "1"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["config"]["ranks_in_process_group"] == 8 and line["errors"] == []
+    pr = line["config"]["per_rank_proofs_per_s"]
+    assert len(pr["all"]) == 8 and 0 < pr["min"] <= pr["max"]
+    assert line["value"] <= 8 * pr["max"] * 1.0001                 # the headline is the max-over-ranks time, never better than the ranks
+    assert len(line["config"]["cpu_affinity"]) == 8 and all(a["pinned"] is False for a in line["config"]["cpu_affinity"])
+    assert line["sharded_proof"]["config_2a"]["bytes_identical_to_unsharded_proof"] is True
+    assert "cpu_baseline" not in line                              # not in emulation runs; on GPU runs rank 0 times it after its GPU work
+
+
+def test_rank_affinity_follows_the_gpus_numa_node(tmp_path):
+    """pin_rank_to_gpu_numa_node's building blocks on a fake sysfs: 8 GPUs on two NUMA nodes, 4 ranks per node, each
+    rank an equal share of its node's CPUs; a cpuset that leaves a rank fewer than 2 CPUs pins nothing."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    for g in range(8):
+        d = tmp_path / ("0000:%02x:00.0" % (0x10 + g))
+        d.mkdir()
+        (d / "numa_node").write_text("%d\n" % (g // 4))
+        (d / "local_cpulist").write_text("0-63,128-191\n" if g < 4 else "64-127,192-255\n")
+    node, cpus = bench.gpu_local_cpus("0000:15:00.0", str(tmp_path))
+    assert node == 1 and len(cpus) == 128 and 64 in cpus and 255 in cpus
+    assert bench.gpu_local_cpus("0000:99:00.0", str(tmp_path)) == (None, set())
+    allowed = set(range(256))
+    shares = [bench.rank_cpu_slice(cpus, allowed, 4, i) for i in range(4)]
+    assert all(len(s) == 32 for s in shares) and set().union(*shares) == cpus
+    assert all(not (shares[i] & shares[j]) for i in range(4) for j in range(i))
+    assert bench.rank_cpu_slice(cpus, {64, 65, 66}, 4, 0) == set()          # container cpuset too small: no pinning
+    assert bench._format_cpulist(shares[0]) == "64-95" and bench._parse_cpulist("64-95") == shares[0]
+    assert bench.pin_rank_to_gpu_numa_node(0, 1)["pinned"] is False         # one rank: nothing to separate
