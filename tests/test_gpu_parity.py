@@ -516,7 +516,7 @@ print(want_small, want_big)
 
 def test_gpu_twiddle_sets_are_shared_and_outlive_their_builder(gpu_prover, root):
     """The twiddle tables are one set per device, shared by the contexts of the process and replaced by a larger set when a
-    context needs one (prover.cpp `ensure_twiddles`).  In a fresh process: a context keeps proving with the set it holds
+    context needs one (context.cpp `ensure_twiddles`).  In a fresh process: a context keeps proving with the set it holds
     after the context that built it is gone, moves to a larger set built by someone else, a set is rebuilt after all of its
     holders are gone - and every context yields the bytes this process's prover gives for the same tables."""
     import subprocess

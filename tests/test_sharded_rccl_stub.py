@@ -1,5 +1,5 @@
 """`lmn_ctx_set_shard_rccl` with MORE THAN ONE RANK on a machine without GPUs: the emulation build carries the library's
-built-in RCCL transport (prover.cpp RcclApi / RcclTransport), LMN_RCCL_LIB points it at tests/emu/libstub_rccl.so - the
+built-in RCCL transport (shard.cpp RcclApi / RcclTransport), LMN_RCCL_LIB points it at tests/emu/libstub_rccl.so - the
 NCCL entry points over POSIX shared memory - and world 2 / 4 / 8 rank processes prove the sharded test pies.  What this
 executes before the driver's multi-GPU node does: `lmn_rccl_unique_id` on rank 0 and its hand-over, one communicator per
 rank (`ncclCommInitRank` returns when every rank has joined), grouped all-gathers of coordinate columns, the grouped

@@ -11,7 +11,7 @@ CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-f
 while [ $# -ge 2 ]; do
   $CC $2 -c kernels.hip -o /tmp/kernels_$1.o
   OBJS="/tmp/kernels_$1.o"
-  for src in fft_fixed.hip prover.cpp verifier.cpp capi.cpp level2.cpp; do
+  for src in fft_fixed.hip components.cpp context.cpp trace_gen.cpp commit.cpp oods.cpp decommit.cpp quotients.cpp prove.cpp shard.cpp ops.cpp verifier.cpp capi.cpp level2.cpp; do
     base=${src%.*}
     if [ "${ALLSRC:-0}" = 1 ]; then $CC $2 -c $src -o /tmp/${base}_$1.o; OBJS="$OBJS /tmp/${base}_$1.o"; else OBJS="$OBJS $base.o"; fi
   done
