@@ -1,5 +1,5 @@
 // Compile-time-specialised circle-FFT passes (fft_fixed.hip) for the tile shapes the prover's committed columns
-// actually have; the generic k_fft_staged in kernels.hip covers every other shape.
+// actually have; the generic k_fft_staged in kernels_fft.hip covers every other shape.
 #pragma once
 #include "kernels.h"
 

@@ -1,7 +1,7 @@
 // Fixed-shape circle-FFT passes for gfx950 (stwo PolyOps::interpolate / evaluate behind
 // /root/reference/crates/prover/src/prover.rs:56-59,179,298 and the composition commit behind :312).
 //
-// The generic k_fft_staged (kernels.hip) takes its tile geometry at run time; every address, LDS index and twiddle index is
+// The generic k_fft_staged (kernels_fft.hip) takes its tile geometry at run time; every address, LDS index and twiddle index is
 // then computed with vector instructions and the emitted code spends ~19 VALU instructions per butterfly for 12 of
 // arithmetic.  The shapes the prover's committed columns actually have are few - the contiguous 12-layer low pass and the
 // strided 16-word-run passes of 5..10 layers - so they are instantiated here with everything but the tile's position
@@ -199,7 +199,7 @@ LMN_D uint32_t m_rot(uint32_t x, uint32_t e) {
 }
 
 // Tile shape: 2^RBITS rows x 2^CB contiguous words; the RBITS layers are split into stages of at most 4 (balanced, as
-// split_stages in kernels.hip).  LO0: the pass starts at layer 0 of a contiguous tile (CB = 0).
+// split_stages in kernels_fft.hip).  LO0: the pass starts at layer 0 of a contiguous tile (CB = 0).
 template <int RBITS_, int CB_, bool LO0_>
 struct FxShape {
   static constexpr int RBITS = RBITS_, CB = CB_, TB = RBITS_ + CB_;
@@ -353,7 +353,7 @@ k_fft_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_
   }
 }
 
-// k_fft_interp_extend (kernels.hip) with a fixed tile: layers [12, n) of the inverse transform on 2^n points, then the
+// k_fft_interp_extend (kernels_fft.hip) with a fixed tile: layers [12, n) of the inverse transform on 2^n points, then the
 // same layers of both halves of the forward transform onto 2^(n+1) points from the coefficient tile kept in LDS.
 template <int RBITS>
 LMN_KERNEL LMN_BOUNDS((FxShape<RBITS, 4, false>::NT))

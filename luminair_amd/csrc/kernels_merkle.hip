@@ -1,0 +1,697 @@
+// gfx950 kernels, part 3: Blake2s Merkle trees in fused subtree launches, the device-resident channel of the FRI commit
+// loop, the single-block FRI tail and the decommitment gather.
+#include "kernels_common.h"
+
+namespace lmn {
+
+// =============================================================================================
+// a4  Blake2s Merkle layer: one lane per node; a wave reads 64 consecutive rows of each column.
+// =============================================================================================
+LMN_KERNEL k_merkle_layer(const uint32_t* __restrict__ prev, const uint32_t* const* __restrict__ cols, int ncols,
+                          uint32_t size, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size) return;
+  const int npre = prev ? 16 : 0;
+  const int nwords = npre + ncols;
+  const int nblocks = (nwords + 15) / 16;
+  uint32_t h[8];
+  b2_init(h);
+  for (int b = 0; b < nblocks; ++b) {
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int w = b * 16 + k;
+      uint32_t v = 0u;
+      if (w < npre)
+        v = prev[(uint64_t)i * 16 + w];
+      else if (w < nwords)
+        v = cols[w - npre][i];
+      m[k] = v;
+    }
+    bool last = b + 1 == nblocks;
+    b2_compress(h, m, last ? (uint32_t)(4 * nwords) : (uint32_t)(64 * (b + 1)), last ? 0xffffffffu : 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[(uint64_t)i * 8 + k] = h[k];
+}
+
+void launch_merkle_layer(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out,
+                         lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle layer with no input");
+  LMN_LAUNCH(k_merkle_layer, dim3(cdiv(size, TPB)), dim3(TPB), 0, s, prev, cols, ncols, size, out);
+}
+
+// Fused Merkle subtree.  Every lane owns 2^sub consecutive start-level nodes and reduces them to one
+// subtree root in registers (post-order, private LDS slots as the merge stack: all 64 lanes of a
+// wave stay busy on every compression); the block's subtree roots then climb further levels
+// through LDS.  All levels are written to HBM (decommitment needs them).
+// Start-level columns are described as up to MERKLE_MAX_SEG runs of contiguous columns
+// (column c of a run lives at base + c*size), so no per-column pointer loads are needed.
+LMN_D const uint32_t* merkle_col_ptr(const MerkleSegs& sg, int c, uint64_t size) {
+  // c is compile-time after unrolling; the comparisons are wave-uniform scalar work
+  int n0 = sg.n[0], n1 = n0 + sg.n[1], n2 = n1 + sg.n[2];
+  if (c < n0) return sg.base[0] + (uint64_t)c * size;
+  if (c < n1) return sg.base[1] + (uint64_t)(c - n0) * size;
+  if (c < n2) return sg.base[2] + (uint64_t)(c - n1) * size;
+  return sg.base[3] + (uint64_t)(c - n2) * size;
+}
+
+// First 16 message words of start-level node i: the two child hashes when the level has a `prev`
+// layer, else its first 16 columns (zero padded).  Split from the hashing so that callers can issue the
+// loads of the next node before compressing the current one.
+LMN_D void merkle_load_first(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                             uint32_t i, uint32_t m[16]) {
+  if (prev) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
+    uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+    m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+    m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = k < ncols ? merkle_col_ptr(sg, k, size)[i] : 0u;
+  }
+}
+
+// Hash of start-level node i given its first 16 message words (merkle_load_first).
+LMN_D void merkle_hash_from(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16], uint32_t h[8]) {
+  b2_init(h);
+  const uint32_t total = (prev ? 64u : 0u) + 4u * (uint32_t)ncols;
+  int c0 = prev ? 0 : 16;  // first column not yet consumed
+  if (c0 >= ncols) {
+    b2_compress(h, m, total, 0xffffffffu);
+    return;
+  }
+  b2_compress(h, m, 64u, 0u);
+  uint32_t done = 64u;
+  while (c0 < ncols) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int c = c0 + k;
+      m[k] = c < ncols ? merkle_col_ptr(sg, c, size)[i] : 0u;
+    }
+    c0 += 16;
+    bool last = c0 >= ncols;
+    done += 64u;
+    b2_compress(h, m, last ? total : done, last ? 0xffffffffu : 0u);
+  }
+}
+
+LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                             uint32_t i, uint32_t h[8]) {
+  uint32_t m[16];
+  merkle_load_first(prev, sg, ncols, size, i, m);
+  merkle_hash_from(prev, sg, ncols, size, i, m, h);
+}
+
+// MerkleFold::below: raw words of leaves 2i (m[0..7]) and 2i+1 (m[8..15]) of the level under the start level
+LMN_D void merkle_load_below(const uint32_t* __restrict__ below, int below_ncols, uint32_t size, uint32_t i, uint32_t m[16]) {
+  const uint64_t L = 2ull * size;
+  const uint32_t* __restrict__ bp = below + 2ull * i;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < below_ncols) {
+      m[k] = bp[(uint64_t)k * L];
+      m[8 + k] = bp[(uint64_t)k * L + 1];
+    } else {
+      m[k] = 0u;
+      m[8 + k] = 0u;
+    }
+  }
+}
+// start node i = H(H(leaf 2i) || H(leaf 2i+1) || own columns) from the raw leaf words of merkle_load_below
+LMN_D void merkle_hash_below(const MerkleSegs& sg, int ncols, uint32_t size, int below_ncols, uint32_t i, const uint32_t m[16],
+                             uint32_t h[8]) {
+  uint32_t ml[16], mr[16], hl[8], hr[8];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    ml[k] = k < 8 ? m[k] : 0u;
+    mr[k] = k < 8 ? m[8 + k] : 0u;
+  }
+  b2_compress_fresh(hl, ml, 4u * (uint32_t)below_ncols);
+  b2_compress_fresh(hr, mr, 4u * (uint32_t)below_ncols);
+  uint32_t m2[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    m2[k] = hl[k];
+    m2[8 + k] = hr[k];
+  }
+  // merkle_hash_from only asks whether the node HAS children; their hashes are in m2
+  merkle_hash_from(reinterpret_cast<const uint32_t*>(sg.base[0]), sg, ncols, size, i, m2, h);
+}
+
+LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
+  uint4* o4 = reinterpret_cast<uint4*>(o);
+  o4[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  o4[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// Quad-cooperative Blake2s of one 64-byte final block (a Merkle parent): lane q of a quad owns column q
+// of the 4x4 state (a, b, c, d = rows), so the four G functions of a half-round run on four lanes; the
+// diagonal step rotates rows b, c, d by 1, 2, 3 lanes with DPP quad_perm.  Message words are fetched from
+// LDS by per-lane sigma offsets.  ~400 issue slots instead of ~1000: single-hash latency 0.93 us vs 2.0 us
+// on MI355X (tools/microbench4.hip) - used where a level is too narrow to fill lanes anyway.
+// Returns words q and 4+q of the digest.  Must be executed by all four lanes of the quad.
+// WS = 0: the 16 message words are contiguous at msg; WS > 0: the two child hashes live in a word-major node array
+// (word k of node j at base[k * WS + j]): message word w = msg[(w & 7) * WS + (w >> 3)] with msg = base + 2 * parent.
+template <uint32_t WS = 0u>
+LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint32_t& o_hi, uint32_t t0 = 64u) {
+#define LMN_B2_QW(w) (WS ? msg[((w) & 7u) * WS + ((w) >> 3)] : msg[(w)])
+#ifdef LMN_EMU
+  // CPU emulation (tests only): a cross-lane rendezvous per DPP move would be a block-wide fiber switch;
+  // every lane hashes the block alone and keeps its two words.  The DPP path is checked on the GPU.
+  uint32_t h[8], m[16];
+  for (uint32_t k = 0; k < 16; ++k) m[k] = LMN_B2_QW(k);
+  b2_compress_fresh(h, m, t0);
+  o_lo = h[q];
+  o_hi = h[4 + q];
+  return;
+#endif
+  const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+  const uint32_t h_lo = q == 0 ? (0x6A09E667u ^ 0x01010020u) : iv_lo;
+  uint32_t a = h_lo, b = iv_hi, c = iv_lo, d = iv_hi ^ (q == 0 ? t0 : q == 2 ? 0xffffffffu : 0u);
+  const uint32_t sh8 = 8u * q;
+#define LMN_B2_QUAD_ROUND(...)                                            \
+  {                                                                       \
+    const uint64_t S = LMN_B2_SIGMA_PACK(__VA_ARGS__);                    \
+    const uint32_t lo = (uint32_t)(S >> sh8), hi = (uint32_t)(S >> (32u + sh8)); \
+    const uint32_t x0 = LMN_B2_QW(lo & 15u), y0 = LMN_B2_QW((lo >> 4) & 15u); \
+    const uint32_t x1 = LMN_B2_QW(hi & 15u), y1 = LMN_B2_QW((hi >> 4) & 15u); \
+    LMN_B2_G(a, b, c, d, x0, y0)                                          \
+    b = lmn_quad_perm(b, 0x39);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x93);                                           \
+    LMN_B2_G(a, b, c, d, x1, y1)                                          \
+    b = lmn_quad_perm(b, 0x93);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x39);                                           \
+  }
+  LMN_B2_QUAD_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  LMN_B2_QUAD_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_QUAD_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_QUAD_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_QUAD_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_QUAD_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_QUAD_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_QUAD_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_QUAD_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_QUAD_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef LMN_B2_QUAD_ROUND
+  o_lo = h_lo ^ a ^ c;
+  o_hi = iv_hi ^ b ^ d;
+#undef LMN_B2_QW
+}
+
+// One level of an in-LDS Merkle climb.  The block's nodes live WORD-MAJOR in sh (word k of node j at sh[k * BLOCK + j]:
+// lanes that walk nodes touch consecutive banks - the node-major form, 8 or 16 words per lane, put a whole wave on two
+// banks): the children of this block's `n_par` parents are nodes 0 .. 2 * n_par - 1, parent j replaces node j and is
+// written to out[(node0 + j)*8 ..].  Levels with at most 128 parents (two quad-waves per SIMD of the CU) use four lanes
+// per hash, which is faster there; wider levels are throughput-bound inside the CU and keep one lane per hash.
+// Block-uniform arguments; ends WITHOUT a barrier.
+template <int BLOCK>
+LMN_D void merkle_lds_level(uint32_t* sh, uint32_t* __restrict__ out, uint32_t node0, uint32_t n_par) {
+  __syncthreads();
+  if (n_par * 4u <= (uint32_t)BLOCK && n_par <= 128u) {
+    const uint32_t g = threadIdx.x >> 2, q = threadIdx.x & 3u;
+    const bool on = g < n_par;
+    uint32_t o_lo = 0u, o_hi = 0u;
+    const bool wave_on = ((threadIdx.x & ~63u) >> 2) < n_par;  // wave-uniform
+    if (wave_on) b2_quad_parent<(uint32_t)BLOCK>(sh + 2u * g, q, o_lo, o_hi);
+    __syncthreads();
+    if (on) {
+      sh[q * BLOCK + g] = o_lo;
+      sh[(4u + q) * BLOCK + g] = o_hi;
+      uint32_t* o = out + (uint64_t)(node0 + g) * 8;
+      o[q] = o_lo;
+      o[4u + q] = o_hi;
+    }
+  } else {
+    const bool on = threadIdx.x < n_par;
+    uint32_t cur[8];
+    if (on) {
+      uint32_t m[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        m[k] = sh[k * BLOCK + 2u * threadIdx.x];
+        m[8 + k] = sh[k * BLOCK + 2u * threadIdx.x + 1u];
+      }
+      b2_compress_fresh(cur, m, 64u);
+      store_hash(out + (uint64_t)(node0 + threadIdx.x) * 8, cur);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[k * BLOCK + threadIdx.x] = cur[k];
+    }
+  }
+}
+
+// LDS climb shared by the Merkle kernels: `lvl_size` hashes of the whole level exist, this block's share
+// sits in sh[idx*8..]; levels first..last are produced.
+template <int BLOCK>
+LMN_D void merkle_lds_climb(uint32_t* sh, const MerkleLevels& outs, int first, int last, uint32_t lvl_size) {
+  for (int l = first; l <= last; ++l) {
+    lvl_size >>= 1;
+    const uint32_t active = (uint32_t)BLOCK >> (l - first + 1);
+    const uint32_t node0 = blockIdx.x * active;
+    const uint32_t n_par = node0 >= lvl_size ? 0u : (lvl_size - node0 < active ? lvl_size - node0 : active);
+    merkle_lds_level<BLOCK>(sh, outs.p[l], node0, n_par);
+  }
+}
+
+// MODE 1: leaf level of a single-size tree (no child layer, one contiguous run of <= 16 columns: one
+// compression per leaf); MODE 2: pure inner level (children only); MODE 0: anything else.  The special modes
+// drop the run selection and the multi-block loop from the hot loop.
+// ZT: the caller keeps the message words this mode never loads at zero (set once, outside its leaf loop), so they are not
+// rewritten for every leaf
+template <int MODE, bool ZT = false>
+LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16], const MerkleFold& fold = MerkleFold{}) {
+  if (MODE == 3) {
+    // leaf i of a FRI layer = fold of the pair (2i, 2i+1) of the previous layer (same arithmetic as k_fold)
+    const uint64_t L = 2ull * size;
+    const uint32_t* __restrict__ sp = fold.src + 2ull * i;
+    const QM31 a{sp[0], sp[L], sp[2 * L], sp[3 * L]};
+    const QM31 b{sp[1], sp[L + 1], sp[2 * L + 1], sp[3 * L + 1]};
+    const QM31 alpha = *fold.alpha;
+    QM31 r = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), fold.itw[i])));
+    if (fold.src2) {   // block-uniform: a quotient column joins this layer (k_fold with accumulate = 1)
+      const uint32_t* __restrict__ sq = fold.src2 + 2ull * i;
+      const QM31 c{sq[0], sq[L], sq[2 * L], sq[3 * L]};
+      const QM31 d{sq[1], sq[L + 1], sq[2 * L + 1], sq[3 * L + 1]};
+      const QM31 rc = q_add(q_add(c, d), q_mul(alpha, q_mul_m(q_sub(c, d), fold.itw2[i])));
+      r = q_add(q_mul(r, q_mul(alpha, alpha)), rc);
+    }
+    uint32_t* __restrict__ o = fold.dst + i;
+    o[0] = r.a;
+    o[(uint64_t)size] = r.b;
+    o[2ull * size] = r.c;
+    o[3ull * size] = r.d;
+    m[0] = r.a;
+    m[1] = r.b;
+    m[2] = r.c;
+    m[3] = r.d;
+    if (!ZT) {
+#pragma unroll
+      for (int k = 4; k < 16; ++k) m[k] = 0u;
+    }
+  } else if (MODE == 1) {
+    const uint32_t* __restrict__ base = sg.base[0] + i;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < ncols)
+        m[k] = base[(uint64_t)k * size];
+      else if (!ZT)
+        m[k] = 0u;
+    }
+  } else if (MODE == 2) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(prev) + (uint64_t)i * 4;
+    uint4 a = p4[0], b = p4[1], c = p4[2], d = p4[3];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+    m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+    m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+  } else if (MODE == 4) {
+    merkle_load_below(fold.below, fold.below_ncols, size, i, m);
+  } else {
+    merkle_load_first(prev, sg, ncols, size, i, m);
+  }
+}
+template <int MODE>
+LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                            uint32_t i, uint32_t m[16], uint32_t h[8], const MerkleFold& fold = MerkleFold{}) {
+  if (MODE == 4) {
+    merkle_hash_below(sg, ncols, size, fold.below_ncols, i, m, h);
+  } else if (MODE == 3) {
+    b2_compress_fresh(h, m, 16u);
+  } else if (MODE == 1) {
+    b2_compress_fresh(h, m, 4u * (uint32_t)ncols);
+  } else if (MODE == 2) {
+    b2_compress_fresh(h, m, 64u);
+  } else {
+    merkle_hash_from(prev, sg, ncols, size, i, m, h);
+  }
+}
+
+template <int MODE>
+LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
+                          MerkleLevels outs, int sub, int nfused, MerkleFold fold) {
+  // Wave-cooperative subtree: in batch j lane l hashes start node W0 + 64*j + l (coalesced column
+  // loads and hash stores).  Siblings sit in neighbouring lanes, so after every second batch the
+  // lanes swap one hash with lane^1 and ALL 64 lanes compress one level-1 parent (even lanes for the
+  // older batch, odd lanes for the newer one); after every fourth batch the same with lane^2, etc.
+  // Each lane keeps its pending hash per level in private LDS slots (word 8 = node index).
+  LMN_SHARED uint32_t stack[MERKLE_MAX_SUB * 8 * TPB];  // [level][word][thread]
+  uint32_t* sh = stack;  // the climb buffer reuses the stack storage once the batch loop is over
+  const uint32_t per = 1u << sub;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t W0 = (t >> 6) * (64u << sub);
+  uint32_t cur[8];
+  uint32_t cur_idx = 0;
+  // software pipeline: the next batch's loads are in flight while this batch is compressed (only ~2 waves share a SIMD
+  // here, too few to hide HBM latency by occupancy alone).  Two message buffers alternate (the loop body handles an even and
+  // an odd batch), so the prefetched words are hashed where they were loaded - no 16-register copy per leaf.
+  uint32_t mA[16], mB[16];
+  constexpr bool ZT = MODE == 1 || MODE == 3;   // the words beyond a leaf's columns stay zero for the whole kernel
+  if (ZT) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mA[k] = mB[k] = 0u;
+  }
+  merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, W0 + lane, mA, fold);
+  auto leaf = [&](uint32_t j, uint32_t (&mc)[16], uint32_t (&mn)[16]) {
+    const uint32_t node = W0 + 64u * j + lane;
+    cur_idx = node;
+    if (j + 1 < per) merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, node + 64u, mn, fold);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur, fold);
+    if (outs.p[0]) store_hash(outs.p[0] + (uint64_t)node * 8, cur);
+  };
+  for (uint32_t j = 0; j < per; j += 2) {
+    leaf(j, mA, mB);
+    if (per == 1) break;                       // sub = 0: one leaf per lane, nothing to merge in registers
+#pragma unroll
+    for (int k = 0; k < 8; ++k) stack[k * TPB + threadIdx.x] = cur[k];   // level-0 slot: the even batch waits for its sibling
+    leaf(j + 1, mB, mA);
+    uint32_t jj = j + 1;
+    int lvl = 0;
+    while (jj & 1u) {
+      const bool b = ((lane >> lvl) & 1u) != 0u;
+      uint32_t m[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t st = stack[(lvl * 8 + k) * TPB + threadIdx.x];
+        const uint32_t recv = lmn_shfl_xor(b ? st : cur[k], 1 << lvl);
+        m[k] = b ? recv : st;
+        m[8 + k] = b ? cur[k] : recv;
+      }
+      // the pending (older) node of this lane sits exactly 64 nodes before the newer one at every level
+      cur_idx = (b ? cur_idx : cur_idx - 64u) >> 1;
+      b2_compress_fresh(cur, m, 64u);
+      jj >>= 1;
+      ++lvl;
+      if (outs.p[lvl]) store_hash(outs.p[lvl] + (uint64_t)cur_idx * 8, cur);
+    }
+    if (lvl < sub) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) stack[(lvl * 8 + k) * TPB + threadIdx.x] = cur[k];
+    }
+  }
+  __syncthreads();  // every lane is done with its stack slots before they are overwritten
+  {
+    const uint32_t local = cur_idx - blockIdx.x * TPB;  // this block owns level-`sub` nodes [b*TPB, (b+1)*TPB)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[k * TPB + local] = cur[k];   // word-major (merkle_lds_level)
+  }
+  merkle_lds_climb<TPB>(sh, outs, sub + 1, nfused, size >> sub);
+}
+
+LMN_D void chan_draw_words(DevChannel* ch, uint32_t out[8]) {
+  uint32_t m[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = ch->digest[k];
+  m[8] = ch->n_sent;
+#pragma unroll
+  for (int k = 9; k < 16; ++k) m[k] = 0u;
+  b2_init(out);
+  // KAT encoding: digest || u64 counter zero-padded to 32 bytes (64-byte message);
+  // LMN_PV_DRAW_CTR_U32: digest || u32 counter || 0x00 (37-byte message)
+  b2_compress(out, m, ch->variant == 0u ? 64u : 37u, 0xffffffffu);
+  ch->n_sent += 1u;
+}
+
+// digest <- H(digest || root); alpha <- draw_felt(); executed by ONE lane
+LMN_D void chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy) {
+  uint32_t m[16], h[8];
+  for (int k = 0; k < 8; ++k) {
+    m[k] = ch->digest[k];
+    m[8 + k] = root[k];
+    root_copy[k] = root[k];
+  }
+  b2_compress_fresh(h, m, 64u);
+  for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
+  ch->n_sent = 0u;
+  for (;;) {
+    uint32_t w[8];
+    chan_draw_words(ch, w);
+    bool ok = true;
+    for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
+    if (!ok) continue;
+    QM31 a;
+    a.a = w[0] >= P31 ? w[0] - P31 : w[0];
+    a.b = w[1] >= P31 ? w[1] - P31 : w[1];
+    a.c = w[2] >= P31 ? w[2] - P31 : w[2];
+    a.d = w[3] >= P31 ? w[3] - P31 : w[3];
+    *out_alpha = a;
+    break;
+  }
+}
+
+// Block-cooperative form of chan_mix_root_draw for kernels that already hold the root in LDS: called by ALL
+// threads of the block (block-uniform control flow); the hashing runs on the first quad with the
+// quad-cooperative Blake2s (0.9 us per hash instead of 2 us).  `scratch`: 28 words of LDS that do not
+// overlap the root's 8 words.  Ends with a barrier and returns the drawn alpha to every thread.
+LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32_t root_stride, uint32_t* scratch,
+                                    QM31* out_alpha, uint32_t* root_copy) {
+  uint32_t* msg = scratch;       // 16 words: digest || root, then digest || counter
+  uint32_t* wbuf = scratch + 16;  // 8 words: drawn words
+  const uint32_t tid = threadIdx.x, q = tid & 3u;
+  const uint32_t t_draw = ch->variant == 0u ? 64u : 37u;
+  __syncthreads();
+  if (tid < 8u) {
+    msg[tid] = ch->digest[tid];
+    const uint32_t r = root[tid * root_stride];   // word k of the root at root[k * root_stride] (word-major node array)
+    msg[8u + tid] = r;
+    root_copy[tid] = r;
+  }
+  __syncthreads();
+  uint32_t lo = 0u, hi = 0u;
+  if (tid < 64u) b2_quad_parent(msg, q, lo, hi);
+  __syncthreads();
+  if (tid < 4u) {
+    msg[q] = lo;
+    msg[4u + q] = hi;
+    ch->digest[q] = lo;
+    ch->digest[4u + q] = hi;
+  }
+  for (uint32_t n_sent = 0;; ++n_sent) {
+    if (tid >= 8u && tid < 16u) msg[tid] = tid == 8u ? n_sent : 0u;
+    __syncthreads();
+    if (tid < 64u) b2_quad_parent(msg, q, lo, hi, t_draw);
+    if (tid < 4u) {
+      wbuf[q] = lo;
+      wbuf[4u + q] = hi;
+    }
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ok = ok && (wbuf[k] < 2u * P31);
+    if (ok) {  // block-uniform
+      if (tid == 0u) {
+        QM31 a;
+        a.a = wbuf[0] >= P31 ? wbuf[0] - P31 : wbuf[0];
+        a.b = wbuf[1] >= P31 ? wbuf[1] - P31 : wbuf[1];
+        a.c = wbuf[2] >= P31 ? wbuf[2] - P31 : wbuf[2];
+        a.d = wbuf[3] >= P31 ? wbuf[3] - P31 : wbuf[3];
+        *out_alpha = a;
+        ch->n_sent = n_sent + 1u;
+        scratch[24] = a.a;
+        scratch[25] = a.b;
+        scratch[26] = a.c;
+        scratch[27] = a.d;
+      }
+      break;
+    }
+    __syncthreads();  // everyone has read wbuf before the next draw overwrites it
+  }
+  __syncthreads();
+  return QM31{scratch[24], scratch[25], scratch[26], scratch[27]};
+}
+
+// Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
+constexpr int MERKLE_SMALL_BLOCK = 1024;
+template <int MODE>
+LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
+                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  const uint32_t i = threadIdx.x;
+  uint32_t cur[8];
+  if (i < size) {
+    uint32_t m[16];
+    merkle_load_mode<MODE>(prev, sg, ncols, size, i, m);
+    merkle_hash_mode<MODE>(prev, sg, ncols, size, i, m, cur);
+    store_hash(outs.p[0] + (uint64_t)i * 8, cur);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
+  }
+  LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
+  merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
+  // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
+  if (ch != nullptr && (size >> nfused) == 1u)
+    chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
+}
+
+void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold) {
+  if (LMN_ABLATED(1u)) return;
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (nfused > MERKLE_MAX_FUSED || sub > MERKLE_MAX_SUB || sub > nfused || nfused - sub > 8 ||
+      size % ((uint32_t)TPB << sub) != 0)
+    throw LmnError(-100, "merkle_fused: bad arguments");
+  const dim3 g(cdiv(size >> sub, TPB)), b(TPB);
+  const MerkleFold none{};
+  // a null p[l] (l < sub only: the levels a lane keeps in registers) is a level the caller does not want written
+  for (int l = sub; l <= nfused; ++l)
+    if (!outs.p[l]) throw LmnError(-100, "merkle_fused: only the per-lane levels may be left unwritten");
+  if (fold && fold->below) {
+    if (prev || fold->src || ncols < 1 || fold->below_ncols < 1 || fold->below_ncols > 8)
+      throw LmnError(-100, "merkle_fused: a start level over its own leaf level has columns, no stored children and <= 8 leaf columns");
+    LMN_LAUNCH(k_merkle_fused<4>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+  } else if (fold) {
+    if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
+    LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+  } else if (!prev && ncols <= 16 && sg.n[0] == ncols)
+    LMN_LAUNCH(k_merkle_fused<1>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+  else if (prev && ncols == 0)
+    LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+  else
+    LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+}
+
+void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
+                         const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
+                         lmn_stream_t s) {
+  if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
+  if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
+  const dim3 g(1), b(MERKLE_SMALL_BLOCK);
+  if (!prev && ncols <= 16 && sg.n[0] == ncols)
+    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+  else if (prev && ncols == 0)
+    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+  else
+    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+}
+
+// =============================================================================================
+// Device-resident Fiat-Shamir steps for the FRI commit loop (no host round trip per layer)
+// =============================================================================================
+LMN_KERNEL k_chan_mix_root_draw(DevChannel* ch, const uint32_t* __restrict__ root, QM31* out_alpha,
+                                uint32_t* root_copy) {
+  LMN_SERIAL_KERNEL();
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  chan_mix_root_draw(ch, root, out_alpha, root_copy);
+}
+
+void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
+                               lmn_stream_t s) {
+  LMN_LAUNCH(k_chan_mix_root_draw, dim3(1), dim3(64), 0, s, ch, root, out_alpha, root_copy);
+}
+
+// =============================================================================================
+// FRI tail: all layers of size <= 1024 in ONE single-block launch: per layer Merkle-commit the
+// line evaluation (LDS tree), mix the root into the device-resident channel, draw the folding
+// alpha, fold.  Every layer's evaluations and tree levels still go to HBM for decommitment.
+// =============================================================================================
+LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, int n_layers, int first_log,
+                      QM31* alphas_out, uint32_t* roots_out) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  const uint32_t i = threadIdx.x;
+  for (int li = 0; li < n_layers; ++li) {
+    const FriTailLayer ly = layers[li];
+    const int L = first_log - li;
+    const uint32_t size = 1u << L;
+    uint32_t cur[8];
+    if (i < size) {
+      uint32_t m[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = 0u;
+      m[0] = ly.vals[i];
+      m[1] = ly.vals[size + i];
+      m[2] = ly.vals[2 * size + i];
+      m[3] = ly.vals[3 * size + i];
+      b2_compress_fresh(cur, m, 16u);
+      store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
+    }
+    for (int l = L - 1; l >= 0; --l) merkle_lds_level<MERKLE_SMALL_BLOCK>(sh, ly.merkle[l], 0u, 1u << l);
+    const QM31 alpha = chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, &alphas_out[li], roots_out + li * 8);
+    const uint32_t n = size >> 1;
+    if (i < n) {
+      QM31 a{ly.vals[2 * i], ly.vals[size + 2 * i], ly.vals[2 * size + 2 * i], ly.vals[3 * size + 2 * i]};
+      QM31 b{ly.vals[2 * i + 1], ly.vals[size + 2 * i + 1], ly.vals[2 * size + 2 * i + 1],
+             ly.vals[3 * size + 2 * i + 1]};
+      QM31 f0 = q_add(a, b);
+      QM31 f1 = q_mul_m(q_sub(a, b), ly.itw[i]);
+      QM31 r = q_add(f0, q_mul(alpha, f1));
+      ly.next[i] = r.a;
+      ly.next[n + i] = r.b;
+      ly.next[2 * n + i] = r.c;
+      ly.next[3 * n + i] = r.d;
+    }
+    __syncthreads();
+  }
+}
+
+void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
+                     uint32_t* roots_out, lmn_stream_t s) {
+  if (first_log > 10 || n_layers < 1 || n_layers > first_log) throw LmnError(-100, "fri_tail: bad arguments");
+  LMN_LAUNCH(k_fri_tail, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, ch, layers, n_layers, first_log, alphas_out,
+             roots_out);
+}
+
+// =============================================================================================
+// gather
+// =============================================================================================
+LMN_KERNEL k_gather(const uint32_t* __restrict__ arena, const GatherEntry* __restrict__ entries, uint32_t n,
+                    const MerkleRecompute* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ out) {
+  LMN_SERIAL_KERNEL();
+  uint32_t e = blockIdx.x;
+  if (e < n) {
+    GatherEntry g = entries[e];
+    for (uint32_t k = threadIdx.x; k < g.len; k += blockDim.x) out[g.dst_off + k] = arena[g.src_off + k];
+    return;
+  }
+  e -= n;
+  if (e >= n_jobs) return;
+  // A tree node the fused launch kept in registers only: lane q of a quad hashes start node (node << depth) + q, the
+  // quad reduces the 2^depth hashes pairwise (every quad of the block does the same; block-uniform control flow).
+  const MerkleRecompute j = jobs[e];
+  const uint32_t q = threadIdx.x & 3u;
+  uint32_t h[8];
+  const uint32_t i0 = (j.node << j.depth) + (q & ((1u << j.depth) - 1u));
+  if (j.below) {
+    uint32_t mb[16];
+    merkle_load_below(j.below, j.below_ncols, j.size, i0, mb);
+    merkle_hash_below(j.sg, j.ncols, j.size, j.below_ncols, i0, mb, h);
+  } else {
+    merkle_hash_start(j.prev, j.sg, j.ncols, j.size, i0, h);
+  }
+  for (int s = 0; s < j.depth; ++s) {
+    const bool hi = ((q >> s) & 1u) != 0u;
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t other = lmn_shfl_xor(h[k], 1 << s);
+      m[k] = hi ? other : h[k];
+      m[8 + k] = hi ? h[k] : other;
+    }
+    b2_compress_fresh(h, m, 64u);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[j.dst_off + k] = h[k];
+  }
+}
+
+void launch_gather(const uint32_t* arena, const GatherEntry* entries, uint32_t n_entries, const MerkleRecompute* jobs,
+                   uint32_t n_jobs, uint32_t* out, lmn_stream_t s) {
+  if (n_entries + n_jobs == 0) return;
+  LMN_LAUNCH(k_gather, dim3(n_entries + n_jobs), dim3(64), 0, s, arena, entries, n_entries, jobs, n_jobs, out);
+}
+
+}  // namespace lmn

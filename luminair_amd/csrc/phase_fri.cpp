@@ -1,0 +1,230 @@
+// prove(), inside stwo::prover::prove: the FRI commit phase.  The layer loop runs on the device
+// without host round trips (device-resident channel; the host replays and cross-checks it), folds are computed inside
+// the next layer's leaf hashing where nothing else needs the values first; then the last layer's polynomial.
+#include "prove_run.h"
+
+namespace lmn {
+
+void Context::run_fri_commit(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  // ---- FRI commit
+  auto secure_cols = [&](const uint32_t* vals, int lg, bool s, std::vector<ColRef>& out) { secure_columns(vals, lg, s, g, out); };
+  auto sharded_log = [&](int lg) { return r.sharded_log(lg); };
+  {
+    StageTimer st(this, log, stream_, C_FRI);
+    for (auto& q : quots) secure_cols(q.vals, q.log, q.sharded, first_cols);
+    // The FRI commit loop runs without host round trips: a device-resident copy of the channel
+    // mixes each layer root and draws the folding alpha; the host replays the same steps afterwards.
+    int ls0 = quots[0].log;
+    const int last_size_log = (int)cfg.log_last_layer + lb;
+    const int max_layers = ls0 + 1;
+    DevChannel hc{};
+    memcpy(hc.digest, channel.digest().w, 32);
+    hc.n_sent = 0;
+    hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
+    DevChannel* d_ch = (DevChannel*)stage_upload(&hc, sizeof hc);
+    QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
+    uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);
+    int n_roots = 0;
+    build_merkle(first_merkle, first_cols, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, sharded_log(ls0));
+    ++n_roots;
+    // fold of a (whole or row-block) source into a (whole or row-block) destination one size smaller; a sharded
+    // source folds its own pairs only: into its own block of a sharded destination, or into its rows of a whole
+    // one (all-gathered by the caller afterwards).  Line domain of log L: x-coordinates of CanonicCoset(L+1)'s half coset.
+    auto fold = [&](bool circle, uint32_t* dst, bool dst_s, const uint32_t* src, int src_log, bool src_s, const QM31* alpha,
+                    int accumulate) {
+      const uint32_t* itw = circle ? itwY_[src_log] : itwX_[src_log + 1];
+      if (!src_s) {
+        if (circle)
+          launch_fold_circle_into_line(dst, src, 1u << src_log, itw, alpha, accumulate, stream_);
+        else
+          launch_fold_line(dst, src, 1u << src_log, itw, alpha, stream_);
+        return;
+      }
+      const uint32_t src_len = 1u << (src_log - g);
+      const uint32_t off = shard_.rank << (src_log - 1 - g);  // first folded row (= first twiddle) of this block
+      uint32_t* d = dst_s ? dst : dst + off;
+      const uint64_t dstride = dst_s ? 0 : (1ull << (src_log - 1));
+      if (circle)
+        launch_fold_circle_into_line(d, src, src_len, itw + off, alpha, accumulate, stream_, dstride);
+      else
+        launch_fold_line(d, src, src_len, itw + off, alpha, stream_, dstride);
+    };
+    auto layer_alloc = [&](int lg, bool s) { return arena_.alloc_words(s ? (4ull << (lg - g)) : (4ull << lg)); };
+    int layer_log = ls0 - 1;
+    bool lay_sh = sharded_log(layer_log);
+    uint32_t* layer = layer_alloc(layer_log, lay_sh);
+    // Unsharded proofs leave the fold that produces a layer PENDING, so that the layer's own leaf hashing can
+    // compute it (MerkleFold): one launch and one pass over the layer less.  It is materialised by the plain fold
+    // kernel instead whenever something else needs the values first (a quotient column that joins the layer, the
+    // single-block FRI tail, a layer too small for the fused kernel).
+    struct PendingFold {
+      bool on = false, circle = false;
+      const uint32_t* src = nullptr;
+      int src_log = 0;
+      const QM31* alpha = nullptr;
+      const uint32_t* join = nullptr;   // a quotient column of the source's size that joins the layer (circle fold, accumulated)
+    } pend;
+    auto materialise = [&](uint32_t* dst) {
+      if (!pend.on) return;
+      fold(pend.circle, dst, false, pend.src, pend.src_log, false, pend.alpha, 0);
+      if (pend.join) fold(true, dst, false, pend.join, pend.src_log, false, pend.alpha, 1);
+      pend.on = false;
+    };
+    static const bool fuse_folds = getenv("LMN_NO_FOLD_FUSION") == nullptr;
+    if (!sh && fuse_folds) {
+      pend = {true, true, quots[0].vals, ls0, d_alphas + (n_roots - 1)};
+    } else {
+      fold(true, layer, lay_sh, quots[0].vals, ls0, quots[0].sharded, d_alphas + (n_roots - 1), 0);
+      if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
+    }
+    size_t qi = 1;
+    while (layer_log > last_size_log) {
+      if (pend.on && layer_log <= 10) materialise(layer);
+      if (!lay_sh && layer_log <= 10 && qi == quots.size()) {
+        // all remaining layers fit one block: commit + fold them in a single launch
+        int n_tail = layer_log - last_size_log;
+        std::vector<FriTailLayer> tl(n_tail);
+        for (int li = 0; li < n_tail; ++li) {
+          int L = layer_log - li;
+          FriLayer fl;
+          fl.log = L;
+          fl.vals = layer;
+          fl.sharded = false;
+          fl.merkle.max_log = L;
+          fl.merkle.layers.assign(L + 1, nullptr);
+          for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
+          uint32_t* next = arena_.alloc_words(4ull << (L - 1));
+          tl[li].vals = layer;
+          tl[li].next = next;
+          tl[li].itw = itwX_[L + 1];
+          for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
+          inner.push_back(fl);
+          layer = next;
+        }
+        FriTailLayer* d_tl = upload_vec(tl);
+        {
+          StageTimer t(this, log, stream_, C_MERKLE);
+          launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+        }
+        for (int li = 0; li < n_tail; ++li) timings.merkle_compressions += (2ull << (layer_log - li));
+        n_roots += n_tail;
+        layer_log = last_size_log;
+        break;
+      }
+      FriLayer fl;
+      fl.log = layer_log;
+      fl.vals = layer;
+      fl.sharded = lay_sh;
+      std::vector<ColRef> lc;
+      secure_cols(layer, layer_log, lay_sh, lc);
+      if (pend.on) {
+        MerkleFold mf{pend.src, pend.circle ? itwY_[pend.src_log] : itwX_[pend.src_log + 1], pend.alpha, layer};
+        if (pend.join) {
+          mf.src2 = pend.join;
+          mf.itw2 = itwY_[pend.src_log];
+        }
+        build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, false, &mf);
+        pend.on = false;
+      } else {
+        build_merkle(fl.merkle, lc, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, lay_sh);
+      }
+      ++n_roots;
+      const QM31* d_alpha = d_alphas + (n_roots - 1);
+      const int next_log = layer_log - 1;
+      const bool next_sh = sharded_log(next_log);
+      uint32_t* next = layer_alloc(next_log, next_sh);
+      const bool joins = qi < quots.size() && quots[qi].log - 1 == next_log;
+      const bool fuse_joins = getenv("LMN_NO_JOIN_FUSION") == nullptr;   // (read per proof: the tests toggle it)
+      if (!sh && fuse_folds && next_log > 10 && (!joins || (fuse_joins && !quots[qi].sharded))) {
+        pend = {true, false, layer, layer_log, d_alpha, joins ? quots[qi].vals : nullptr};
+        if (joins) ++qi;   // (quotient sizes are distinct: at most one column joins a layer)
+      } else {
+        fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
+      }
+      inner.push_back(fl);
+      while (qi < quots.size() && quots[qi].log - 1 == next_log) {
+        fold(true, next, next_sh, quots[qi].vals, quots[qi].log, quots[qi].sharded, d_alpha, 1);
+        ++qi;
+      }
+      // a quotient column of this size is sharded exactly when the layer is, so one test covers both sources
+      if (lay_sh && !next_sh) gather_columns(next, 1ull << next_log, 4, (1ull << next_log) >> g);
+      layer = next;
+      layer_log = next_log;
+      lay_sh = next_sh;
+    }
+    materialise(layer);  // a last layer larger than the fused threshold (log_last_layer > 9) is still pending
+    hm.mark("fri enqueued");
+    // one sync: roots + alphas back, then replay the transcript on the host channel
+    const uint32_t* h_roots = (const uint32_t*)stage_download(d_roots, (size_t)n_roots * 32);
+    const QM31* h_alphas = (const QM31*)stage_download(d_alphas, (size_t)n_roots * sizeof(QM31));
+    if (qi != quots.size()) throw LmnError(LMN_ERR_INTERNAL, "FRI: unconsumed columns");
+    last_log = layer_log;
+    const uint32_t* raw = (const uint32_t*)stage_download(layer, (size_t)16 << last_log);
+    lmn_sync(stream_);
+    {
+      uint32_t n = 1u << last_log;
+      for (uint32_t i = 0; i < n; ++i) last_vals.push_back({raw[i], raw[n + i], raw[2 * n + i], raw[3 * n + i]});
+    }
+    for (int r = 0; r < n_roots; ++r) {
+      Hash32 root;
+      memcpy(root.w, &h_roots[(size_t)r * 8], 32);
+      if (r == 0)
+        first_merkle.root = root;
+      else
+        inner[r - 1].merkle.root = root;
+      channel.mix_root(root);
+      QM31 a = channel.draw_felt();
+      if (!q_eq(a, h_alphas[r])) throw LmnError(LMN_ERR_INTERNAL, "device/host transcript divergence in FRI");
+    }
+  }
+  hm.mark("fri synced+replayed");
+  // last layer: interpolate the line evaluation (bit-reversed over LineDomain(half_odds(last_log)))
+  {
+    std::vector<std::vector<QM31>> chunks{last_vals};
+    int dlog = last_log;
+    // x-coordinates of the current line domain in bit-reversed order
+    auto line_xs = [&](int lg) {
+      std::vector<uint32_t> xs(1u << lg);
+      uint32_t init = 1u << (31 - (lg + 2)), step = lg >= 1 ? (1u << (31 - lg)) : 0u;
+      for (uint32_t i = 0; i < (1u << lg); ++i) xs[i] = pt_of_index(init + bit_reverse(i, lg) * step).x;
+      return xs;
+    };
+    while (dlog > 0) {
+      std::vector<uint32_t> xs = line_xs(dlog);
+      std::vector<std::vector<QM31>> nc;
+      for (auto& ch : chunks) {
+        std::vector<QM31> f0, f1;
+        for (size_t i = 0; i < ch.size() / 2; ++i) {
+          QM31 a = ch[2 * i], b = ch[2 * i + 1];
+          f0.push_back(q_add(a, b));
+          f1.push_back(q_mul_m(q_sub(a, b), m_inv(xs[2 * i])));
+        }
+        nc.push_back(f0);
+        nc.push_back(f1);
+      }
+      chunks.swap(nc);
+      // after halving, the remaining domain is the doubled line domain
+      dlog -= 1;
+    }
+    uint32_t n = 1u << last_log;
+    uint32_t ninv = m_inv(n % P31);
+    std::vector<QM31> coeffs(n);
+    for (uint32_t idx = 0; idx < n; ++idx) {
+      uint32_t j = 0;
+      for (int k = 0; k < last_log; ++k) j |= ((idx >> (last_log - 1 - k)) & 1u) << k;
+      coeffs[j] = q_mul_m(chunks[idx][0], ninv);
+    }
+    uint32_t bound = 1u << cfg.log_last_layer;
+    for (uint32_t j = bound; j < n; ++j)
+      if (!q_is_zero(coeffs[j]) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_INTERNAL, "FRI: invalid last-layer degree");
+    coeffs.resize(bound);
+    proof.last_layer_coeffs = coeffs;
+    proof.last_layer_log_size = cfg.log_last_layer;
+    channel.mix_felts(coeffs);
+  }
+
+  hm.mark("last layer");
+}
+
+}  // namespace lmn

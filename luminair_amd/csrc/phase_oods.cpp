@@ -1,0 +1,141 @@
+// prove(), inside stwo::prover::prove: the OODS point and the sampled values of every committed polynomial (with the
+// prover's own check of the composition identity), then the FRI quotient columns, one per LDE size.
+#include "prove_run.h"
+
+namespace lmn {
+
+void Context::run_oods(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  // ---- OODS point + mask points
+  QM31 tt = channel.draw_felt();
+  QM31 t2 = q_sqr(tt);
+  QM31 tinv = q_inv(q_add_m(t2, 1u));
+  oods = QPt{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
+  points.assign(1, oods);
+  std::map<int, int> prev_point_of_log;
+  for (auto& ci : inst) {
+    if (prev_point_of_log.count(ci.log_size)) continue;
+    Pt stp = pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu);  // -step
+    prev_point_of_log[ci.log_size] = (int)points.size();
+    points.push_back(qpt_add_m(oods, stp));
+  }
+  // sample point indices per tree/column, in sampled_values order
+  spoints.assign(4, {});
+  spoints[0].assign(tree0.cols.size(), {0});
+  spoints[1].assign(tree1.cols.size(), {0});
+  spoints[2].assign(tree2.cols.size(), {0});
+  spoints[3].assign(4, {0});
+  for (auto& ci : inst) {
+    int nic = 4 * ci.spec->n_rel;
+    for (int c = nic - 4; c < nic; ++c) spoints[2][ci.inter_start + c] = {prev_point_of_log[ci.log_size], 0};
+  }
+  sampled.assign(4, {});
+  {
+    StageTimer st(this, log, stream_, C_OODS);
+    std::vector<EvalJob> jobs;
+    for (int t = 0; t < 4; ++t)
+      for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+        for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p, trees[t]->cols[c].owner});
+    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true);
+    size_t k = 0;
+    for (int t = 0; t < 4; ++t) {
+      sampled[t].resize(trees[t]->cols.size());
+      for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+        for (size_t p = 0; p < spoints[t][c].size(); ++p) sampled[t][c].push_back(vals[k++]);
+    }
+  }
+  proof.sampled_values = sampled;
+  hm.mark("sync4: oods values on host");
+  {
+    std::vector<QM31> flat;
+    for (auto& t : sampled)
+      for (auto& c : t)
+        for (auto& v : c) flat.push_back(v);
+    channel.mix_felts(flat);
+  }
+  // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
+  {
+    QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
+    QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha, cfg.protocol_variant);
+    if (!q_eq(lhs, rhs) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
+  }
+}
+
+void Context::run_quotients(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  // ---- FRI quotients, one secure column per LDE size (descending)
+  quot_alpha = channel.draw_felt();
+  hm.mark("sampled mixed, oods check, alpha drawn");
+  // sharding of the FRI part: a quotient column / FRI layer of more than 2^fri_T rows is split into row blocks
+  // (pair folds stay inside a block: rows 2i and 2i+1 are adjacent in bit-reversed order); smaller ones are
+  // all-gathered once and finished identically on every rank
+  sh = shard_.active;
+  g = sh ? shard_.g : 0;
+  fri_T = std::max(shard_.fri_min_log, (int)cfg.log_last_layer + lb);
+  auto sharded_log = [&](int lg) { return r.sharded_log(lg); };
+  struct FlatCol {
+    const uint32_t* lde;  // all rows, or this rank's block of them (sharded proof)
+    int lde_log;
+    std::vector<std::pair<int, QM31>> samples;  // (point index, value)
+  };
+  std::vector<FlatCol> flat;
+  for (int t = 0; t < 4; ++t)
+    for (size_t c = 0; c < trees[t]->cols.size(); ++c) {
+      FlatCol f{trees[t]->cols[c].lde, trees[t]->cols[c].log_size + lb, {}};
+      for (size_t p = 0; p < spoints[t][c].size(); ++p) f.samples.push_back({spoints[t][c][p], sampled[t][c][p]});
+      flat.push_back(f);
+    }
+  std::set<int, std::greater<int>> size_set;
+  for (auto& f : flat) size_set.insert(f.lde_log);
+  sizes.assign(size_set.begin(), size_set.end());
+  {
+    StageTimer st(this, log, stream_, C_QUOT);
+    for (int ls : sizes) {
+      std::vector<const FlatCol*> cols;
+      for (auto& f : flat)
+        if (f.lde_log == ls) cols.push_back(&f);
+      std::vector<const uint32_t*> ptrs;
+      std::vector<std::vector<std::pair<int, QM31>>> smp;
+      for (auto* c : cols) {
+        ptrs.push_back(c->lde);
+        smp.push_back(c->samples);
+      }
+      QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha, !sh);
+      uint32_t* vals = a.out;
+      const bool qs = sharded_log(ls);
+      const uint64_t L = 1ull << ls, Lb = L >> g;
+      if (sh) {
+        a.row0 = shard_.rank << (ls - g);
+        a.log_rows = ls - g;
+        if (qs) {
+          vals = arena_.alloc_words(4 * Lb);
+          a.out = vals;
+          a.out_stride = Lb;
+        } else {
+          vals = arena_.alloc_words(4 * L);
+          a.out = vals + a.row0;
+          a.out_stride = L;
+        }
+      }
+      // unsharded proofs with two LDE sizes: the second (smaller) size is computed on the second stream, next to the
+      // leaf hashing of the first size's quotient columns; build_merkle_levels waits for it before level `ls`
+      const bool overlap = have_stream2_ && !sh && sizes.size() == 2 && ls == sizes[1];
+      if (overlap) {
+        lmn_event_record(ev_fork_, stream_);            // everything enqueued so far (incl. the entry-table upload)
+        lmn_stream_wait_event(stream2_, ev_fork_);
+        launch_quotients(a, stream2_);
+        lmn_event_record(ev_join_, stream2_);
+        wait_before_level_ev_ = ev_join_;
+        wait_before_level_ = ls;
+      } else {
+        launch_quotients(a, stream_);
+      }
+      if (sh && !qs) gather_columns(vals, L, 4, Lb);
+      quots.push_back({ls, vals, qs});
+    }
+  }
+
+  hm.mark("quotients enqueued");
+}
+
+}  // namespace lmn

@@ -1,0 +1,100 @@
+// State of one proof while Context::prove walks its phases (prove.cpp drives; the phases live in phase_*.cpp).
+// The phases read and write it through LMN_RUN_ALIASES, so their bodies read like the single function they were
+// carved out of.  Not part of any boundary.
+#pragma once
+#include "prover_internal.h"
+
+namespace lmn {
+
+struct TableInfo {
+  const ComponentSpec* spec;
+  uint64_t n_rows;
+  int log_size;
+  const uint32_t* rows;
+  bool on_device;
+};
+// one FRI quotient column (the columns of one LDE size accumulated)
+struct Quot {
+  int log;
+  uint32_t* vals;  // 4 x 2^log, or 4 x 2^(log-g) (this rank's rows) when sharded
+  bool sharded;
+};
+// one committed inner FRI layer
+struct FriLayer {
+  int log;
+  uint32_t* vals;  // 4 x 2^log (line evaluation), or this rank's 4 x 2^(log-g) rows when sharded
+  bool sharded;
+  DevMerkle merkle;
+};
+
+struct ProofRun {
+  explicit ProofRun(uint32_t protocol_flags) : channel(protocol_flags) {}
+  // inputs (borrowed)
+  const lmn_table* tables = nullptr;
+  size_t n_tables = 0;
+  const lmn_settings* settings = nullptr;
+  // set-up
+  int lb = 0, n_slots = 0, comp_log = 0;
+  HostMarks hm;
+  EventLog* log = nullptr;
+  std::vector<TableInfo> infos;
+  Channel channel;
+  Proof proof;
+  std::unique_ptr<StageTimer> total_guard;
+  // commitments: preprocessed, main trace, interaction trace, composition
+  DevTree tree0, tree1, tree2, tree3;
+  DevTree* trees[4] = {&tree0, &tree1, &tree2, &tree3};
+  std::vector<Instance> inst;
+  std::vector<uint32_t*> pre_evals;  // tree-0 columns on their trace domain (logup denominators)
+  RelElems elems;
+  QM31 comp_alpha{};
+  // OODS
+  QPt oods{};
+  std::vector<QPt> points;
+  std::vector<std::vector<std::vector<int>>> spoints;     // sample point indices per tree / column, sampled_values order
+  std::vector<std::vector<std::vector<QM31>>> sampled;
+  // FRI
+  QM31 quot_alpha{};
+  bool sh = false;   // sharded proof
+  int g = 0;         // log2 ranks
+  int fri_T = 0;     // quotient columns / layers of more than 2^fri_T rows are split into row blocks
+  std::vector<int> sizes;   // LDE log sizes present, descending
+  std::vector<Quot> quots;
+  DevMerkle first_merkle;
+  std::vector<ColRef> first_cols;
+  std::vector<FriLayer> inner;
+  std::vector<QM31> last_vals;
+  int last_log = 0;
+  std::vector<uint32_t> queries;
+  std::map<int, std::vector<uint32_t>> pos_by_log;
+  bool sharded_log(int lg) const { return sh && lg > fri_T; }
+  ProofRun(const ProofRun&) = delete;
+  ProofRun& operator=(const ProofRun&) = delete;
+};
+
+// the four coordinate columns of a secure column as tree columns
+inline void secure_columns(const uint32_t* vals, int lg, bool s, int g, std::vector<ColRef>& out) {
+  const uint64_t stride = s ? (1ull << (lg - g)) : (1ull << lg);
+  for (int k = 0; k < 4; ++k) out.push_back({vals + (uint64_t)k * stride, lg, s});
+}
+
+#define LMN_RUN_ALIASES(r)                                                                                              \
+  HostMarks& hm = (r).hm; EventLog* const log = (r).log; const int lb = (r).lb, n_slots = (r).n_slots; int& comp_log = (r).comp_log; \
+  std::vector<TableInfo>& infos = (r).infos; Channel& channel = (r).channel; Proof& proof = (r).proof;                  \
+  DevTree &tree0 = (r).tree0, &tree1 = (r).tree1, &tree2 = (r).tree2, &tree3 = (r).tree3; DevTree* (&trees)[4] = (r).trees; \
+  std::vector<Instance>& inst = (r).inst; std::vector<uint32_t*>& pre_evals = (r).pre_evals; RelElems& elems = (r).elems; \
+  QM31& comp_alpha = (r).comp_alpha; QPt& oods = (r).oods; std::vector<QPt>& points = (r).points;                       \
+  std::vector<std::vector<std::vector<int>>>& spoints = (r).spoints;                                                    \
+  std::vector<std::vector<std::vector<QM31>>>& sampled = (r).sampled; QM31& quot_alpha = (r).quot_alpha;                \
+  bool& sh = (r).sh; int &g = (r).g, &fri_T = (r).fri_T; std::vector<int>& sizes = (r).sizes;                           \
+  std::vector<Quot>& quots = (r).quots; DevMerkle& first_merkle = (r).first_merkle;                                     \
+  std::vector<ColRef>& first_cols = (r).first_cols; std::vector<FriLayer>& inner = (r).inner;                           \
+  std::vector<QM31>& last_vals = (r).last_vals; int& last_log = (r).last_log; std::vector<uint32_t>& queries = (r).queries; \
+  std::map<int, std::vector<uint32_t>>& pos_by_log = (r).pos_by_log;                                                    \
+  (void)hm; (void)log; (void)lb; (void)n_slots; (void)comp_log; (void)infos; (void)channel; (void)proof; (void)tree0;   \
+  (void)tree1; (void)tree2; (void)tree3; (void)trees; (void)inst; (void)pre_evals; (void)elems; (void)comp_alpha;       \
+  (void)oods; (void)points; (void)spoints; (void)sampled; (void)quot_alpha; (void)sh; (void)g; (void)fri_T; (void)sizes; \
+  (void)quots; (void)first_merkle; (void)first_cols; (void)inner; (void)last_vals; (void)last_log; (void)queries;       \
+  (void)pos_by_log
+
+}  // namespace lmn

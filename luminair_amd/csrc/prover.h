@@ -148,6 +148,8 @@ struct DevTree {
 
 struct StageTimer;
 
+struct ProofRun;   // state of one proof across the phases of Context::prove (prove_run.h)
+
 class Context {
  public:
   Context(int device, const lmn_config& cfg);
@@ -233,6 +235,19 @@ class Context {
   std::string last_error;
 
  private:
+  // the phases of prove(), in transcript order (prove.cpp, phase_*.cpp)
+  void run_setup(ProofRun& r);
+  void run_preprocessed(ProofRun& r);
+  void run_main_trace(ProofRun& r);
+  void run_interaction(ProofRun& r);
+  void run_composition(ProofRun& r);
+  void run_oods(ProofRun& r);
+  void run_quotients(ProofRun& r);
+  void run_fri_commit(ProofRun& r);
+  void run_queries(ProofRun& r);
+  void run_decommit(ProofRun& r);
+  std::vector<uint8_t> run_finish(ProofRun& r);
+
   void ensure_twiddles(int max_domain_log);
   TwPtrs tw(int domain_log) const;
   TwPtrs itw(int domain_log) const;

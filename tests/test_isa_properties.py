@@ -27,7 +27,9 @@ def _emit_asm(tmp_path_factory, name):
 
 @pytest.fixture(scope="module")
 def device_asm(tmp_path_factory):
-    return _emit_asm(tmp_path_factory, "kernels")
+    # the kernel translation units (kernels.hip until round 5) as one listing
+    return "\n".join(_emit_asm(tmp_path_factory, n) for n in
+                     ("kernels_trace", "kernels_fft", "kernels_merkle", "kernels_logup", "kernels_quotient"))
 
 
 @pytest.fixture(scope="module")
@@ -108,7 +110,7 @@ def test_blake2s_half_rounds_are_issued_in_priority_phases(device_asm):
 
 def test_butterfly_layers_are_issued_in_priority_phases(device_asm):
     """k_fft_staged<false>: the multiplication phase of a layer of 8 butterflies = 8 v_mad_u64_u32 + 8 v_alignbit_b32 at
-    priority 3, then the plain phase, then 8 v_min_u32 at priority 3 (kernels.hip m_mul_phased / radix_butterflies)."""
+    priority 3, then the plain phase, then 8 v_min_u32 at priority 3 (kernels_fft.hip m_mul_phased / radix_butterflies)."""
     ks = _kernels(device_asm)
     for part in ("k_fft_stagedILb0E", "k_fft_stagedILb1E", "k_fft_interp_extend"):
         name, = _find(ks, part)
