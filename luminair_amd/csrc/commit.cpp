@@ -350,7 +350,7 @@ Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint3
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
 // shard set, only this rank's aligned block of rows of every LDE is evaluated (launch_fft_block: the top
 // log2(world) layers collapse to a world-point combination at fixed row, the rest runs inside the block).
-void Context::lde_and_merkle(DevTree& tree) {
+void Context::lde_and_merkle(DevTree& tree, bool fetch_root) {
   const int lb = (int)cfg.log_blowup;
   const bool sh = shard_.active;
   const int g = sh ? shard_.g : 0;
@@ -389,7 +389,7 @@ void Context::lde_and_merkle(DevTree& tree) {
   for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb, c.sharded});
   std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
   build_merkle(tree.merkle, sorted, nullptr, nullptr, nullptr, sh);
-  fetch_root_async(tree.merkle);
+  if (fetch_root) fetch_root_async(tree.merkle);   // (device-resident transcript: the root travels with the DevReport)
 }
 
 }  // namespace lmn

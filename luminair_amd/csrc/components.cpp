@@ -67,22 +67,27 @@ ConstraintLayout constraint_layout(const ComponentSpec& sp, uint32_t flags) {
   return L;
 }
 
+int relation_draw_sets(uint32_t protocol_flags, int sets_out[5]) {
+  int n = 0;
+  sets_out[n++] = ELEMS_NODE;
+  sets_out[n++] = ELEMS_SIN;  // the KAT era drew a single LUT relation; HEAD: sin, exp2, log2, range_check
+  if (protocol_flags & LMN_PV_LUT_DRAWS4) {
+    sets_out[n++] = ELEMS_EXP2;
+    sets_out[n++] = ELEMS_LOG2;
+    sets_out[n++] = ELEMS_RANGE_CHECK;
+  }
+  return n;
+}
+
 RelElems draw_relation_elements(Channel& channel, uint32_t protocol_flags) {
   RelElems e;
-  auto draw = [&](int set) {
+  int sets[5];
+  const int n = relation_draw_sets(protocol_flags, sets);
+  for (int i = 0; i < n; ++i) {
     std::vector<QM31> d = channel.draw_felts(2);
-    if (set >= 0) {
-      e.z[set] = d[0];
-      e.alpha[set] = d[1];
-      e.drawn[set] = true;
-    }
-  };
-  draw(ELEMS_NODE);
-  draw(ELEMS_SIN);  // the KAT era drew a single LUT relation; HEAD: sin, exp2, log2, range_check
-  if (protocol_flags & LMN_PV_LUT_DRAWS4) {
-    draw(ELEMS_EXP2);
-    draw(ELEMS_LOG2);
-    draw(ELEMS_RANGE_CHECK);
+    e.z[sets[i]] = d[0];
+    e.alpha[sets[i]] = d[1];
+    e.drawn[sets[i]] = true;
   }
   return e;
 }

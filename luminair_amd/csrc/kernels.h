@@ -83,6 +83,54 @@ struct DevChannel {
 void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_alpha, uint32_t* root_copy,
                                lmn_stream_t s);
 
+// ---- device-resident Fiat-Shamir of the commitment phases (phase_trace / _logup / _composition / _oods.cpp): the host
+// enqueues a whole proof up to the sampled values without waiting; these single-workgroup kernels do the transcript steps
+// in between on a DevChannel and leave what the next kernels need in device memory.  The host replays the same steps on
+// its own Channel once the values have arrived and cross-checks every draw.
+constexpr int CHAN_N_ELEMS = 5;              // relation element sets (prover.h ELEMS_*)
+struct DevElems {                            // z / alpha of every set, written by k_chan_root_elems (or uploaded by the host)
+  QM31 z[CHAN_N_ELEMS], alpha[CHAN_N_ELEMS];
+};
+// Everything the host needs back from the device-resident steps, in one place: ONE download at the proof's first wait
+struct DevReport {
+  DevElems elems;
+  QM31 comp_alpha, t;
+  QM31 claimed[17];
+  uint32_t roots[3][8];                      // main, interaction, composition tree
+  uint32_t bad;                              // copy of the transposes' non-canonical-word verdict
+  uint32_t pad[3];
+};
+struct ChanElemSets {
+  int n;
+  int set[CHAN_N_ELEMS];
+};
+// mix_root(root); then one draw_felts(2) per entry of set_of_draw (a negative entry draws and discards)
+void launch_chan_root_elems(DevChannel* ch, const uint32_t* root, const uint32_t* bad_word, const int* set_of_draw,
+                            int n_draws, DevReport* rep, lmn_stream_t s);
+// mix_felts([claimed_i]) per component, mix_root(root), draw_felt() = the composition randomness alpha; then the
+// coefficient of every kernel constraint slot of every component: sign * alpha^(n_total - 1 - (k0 + proto_index)), 0 for a
+// slot the protocol lacks (Context's constraint_layout) - 16 per component at coeff_out + 16 * i
+constexpr int CHAN_MAX_INST = 17;
+struct ChanCoeffPlan {
+  int n_inst, n_total;
+  const QM31* claimed[CHAN_MAX_INST];        // device [claimed, shift] of each component, struct order
+  int16_t k0[CHAN_MAX_INST];
+  int8_t n_kernel[CHAN_MAX_INST];
+  int8_t proto_index[CHAN_MAX_INST][16];
+  uint16_t neg[CHAN_MAX_INST];               // bit k: the protocol's constraint is minus kernel slot k
+};
+void launch_chan_claims_root_alpha(DevChannel* ch, const ChanCoeffPlan& plan, const uint32_t* root, DevReport* rep,
+                                   QM31* coeff_out, lmn_stream_t s);
+// mix_root(root), t = draw_felt(), the OODS point ((1 - t^2) / (1 + t^2), 2t / (1 + t^2)), the points oods + step_i
+// (i >= 1; step_0 unused) and per point the mappings y, x, pi(x), pi^2(x), ... that launch_eval_tables expands
+constexpr int CHAN_MAX_POINTS = 24;
+struct ChanOodsPlan {
+  int n_points, n_maps;
+  uint32_t step_x[CHAN_MAX_POINTS], step_y[CHAN_MAX_POINTS];
+};
+void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep,
+                           QM31* maps_out /* n_points x n_maps */, lmn_stream_t s);
+
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.
 constexpr int MERKLE_MAX_SEG = 4;
@@ -222,7 +270,9 @@ struct LogupArgs {
   const uint32_t* id[LOGUP_MAX_REL];    // tensor-id column, nullptr for width-1 relations
   const uint32_t* mult[LOGUP_MAX_REL];  // multiplicity column
   int neg[LOGUP_MAX_REL];      // numerator is -mult
-  QM31 z[LOGUP_MAX_REL], alpha[LOGUP_MAX_REL];  // element set of each relation
+  QM31 z[LOGUP_MAX_REL], alpha[LOGUP_MAX_REL];  // element set of each relation (used when d_elems is null)
+  const DevElems* d_elems;     // device-resident draws (k_chan_root_elems): relation j uses set es[j]
+  int es[LOGUP_MAX_REL];
   uint32_t* inter;             // interaction eval columns (4k columns, stride n)
   QM31* last_tmp;              // S_{k-1} per row (AoS), n entries
   uint32_t* partials;          // per-block partial sums, 4 words each
@@ -254,10 +304,13 @@ struct CompositionArgs {
   int accumulate;              // out += instead of out =
   QM31 z, alpha;               // NodeElements
   QM31 z2, alpha2;             // the component's LUT element set (range check / sin / exp2 / log2)
+  const DevElems* d_elems;     // when set: the four values above are read from here (sets 0 and es2) instead
+  int es2;
   const uint32_t* pre;         // preprocessed columns on the eval domain (lookup components)
   const uint32_t* pre2;
   const QM31* claimed_shift;   // device: [claimed, shift]
   QM31 coeff[16];              // alpha^(N-1-k) for this component's constraints, in order
+  const QM31* d_coeff;         // when set: the 16 coefficients are read from device memory (k_chan_claims_root_alpha) instead
   uint32_t zinv[2];            // 1/Z for rows with (s >> log_size) == 0 / 1
 };
 void launch_composition(const CompositionArgs& a, lmn_stream_t s);

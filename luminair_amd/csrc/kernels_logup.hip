@@ -19,8 +19,10 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       QM31 d = q_from_m(a.val[j][r]);
-      if (a.id[j]) d = q_add(d, q_mul_m(a.alpha[j], a.id[j][r]));
-      d = q_sub(d, a.z[j]);
+      // relation elements: kernel arguments, or the device-resident draws (a.d_elems is launch-uniform)
+      const QM31 ez = a.d_elems ? a.d_elems->z[a.es[j]] : a.z[j];
+      if (a.id[j]) d = q_add(d, q_mul_m(a.d_elems ? a.d_elems->alpha[a.es[j]] : a.alpha[j], a.id[j][r]));
+      d = q_sub(d, ez);
       den[j] = d;
       pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
     }

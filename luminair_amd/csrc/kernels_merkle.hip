@@ -591,6 +591,148 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 }
 
 // =============================================================================================
+// Device-resident Fiat-Shamir of the commitment phases (kernels.h): single-lane transcript steps - two to four dependent
+// compressions each - between the big kernels of a proof, instead of a host round trip (30 - 45 us of idle GPU each)
+// =============================================================================================
+// digest <- H(digest || w[0..n)), n <= 8 words (one block)
+LMN_D void chan_mix_words(DevChannel* ch, const uint32_t* w, int n) {
+  uint32_t m[16], h[8];
+  for (int k = 0; k < 8; ++k) m[k] = ch->digest[k];
+  for (int k = 0; k < 8; ++k) m[8 + k] = k < n ? w[k] : 0u;
+  b2_compress_fresh(h, m, 32u + 4u * (uint32_t)n);
+  for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
+  ch->n_sent = 0u;
+}
+// Channel::draw_base_felts: 8 M31 from one hash, redrawn while a word is >= 2P
+LMN_D void chan_draw_base_felts(DevChannel* ch, uint32_t f[8]) {
+  for (;;) {
+    uint32_t w[8];
+    chan_draw_words(ch, w);
+    bool ok = true;
+    for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
+    if (!ok) continue;
+    for (int k = 0; k < 8; ++k) f[k] = w[k] >= P31 ? w[k] - P31 : w[k];
+    return;
+  }
+}
+
+LMN_KERNEL k_chan_root_elems(DevChannel* ch, const uint32_t* __restrict__ root, const uint32_t* __restrict__ bad_word,
+                             ChanElemSets sets, DevReport* rep) {
+  LMN_SERIAL_KERNEL();
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  DevElems* out = &rep->elems;
+  rep->bad = *bad_word;
+  uint32_t r[8];
+  for (int k = 0; k < 8; ++k) r[k] = rep->roots[0][k] = root[k];
+  chan_mix_words(ch, r, 8);
+  for (int i = 0; i < sets.n; ++i) {
+    uint32_t f[8];
+    chan_draw_base_felts(ch, f);
+    const int e = sets.set[i];
+    if (e >= 0) {
+      out->z[e] = QM31{f[0], f[1], f[2], f[3]};
+      out->alpha[e] = QM31{f[4], f[5], f[6], f[7]};
+    }
+  }
+}
+void launch_chan_root_elems(DevChannel* ch, const uint32_t* root, const uint32_t* bad_word, const int* set_of_draw,
+                            int n_draws, DevReport* rep, lmn_stream_t s) {
+  if (n_draws < 1 || n_draws > CHAN_N_ELEMS) throw LmnError(-100, "chan_root_elems: bad draw count");
+  ChanElemSets sets{};
+  sets.n = n_draws;
+  for (int i = 0; i < n_draws; ++i) sets.set[i] = set_of_draw[i];
+  LMN_LAUNCH(k_chan_root_elems, dim3(1), dim3(64), 0, s, ch, root, bad_word, sets, rep);
+}
+
+LMN_KERNEL k_chan_claims_root_alpha(DevChannel* ch, ChanCoeffPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
+                                    QM31* coeff_out) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED uint32_t sh_alpha[4];
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < plan.n_inst; ++i) {
+      const QM31 c = plan.claimed[i][0];
+      rep->claimed[i] = c;
+      const uint32_t w[4] = {c.a, c.b, c.c, c.d};
+      chan_mix_words(ch, w, 4);
+    }
+    uint32_t r[8];
+    for (int k = 0; k < 8; ++k) r[k] = rep->roots[1][k] = root[k];
+    chan_mix_words(ch, r, 8);
+    uint32_t f[8];
+    chan_draw_base_felts(ch, f);
+    rep->comp_alpha = QM31{f[0], f[1], f[2], f[3]};
+    for (int k = 0; k < 4; ++k) sh_alpha[k] = f[k];
+  }
+  __syncthreads();
+  const QM31 alpha{sh_alpha[0], sh_alpha[1], sh_alpha[2], sh_alpha[3]};
+  // one lane per (component, kernel slot): alpha^e by square-and-multiply
+  for (int idx = (int)threadIdx.x; idx < plan.n_inst * 16; idx += (int)blockDim.x) {
+    const int i = idx >> 4, k = idx & 15;
+    QM31 c = q_zero();
+    if (k < plan.n_kernel[i] && plan.proto_index[i][k] >= 0) {
+      uint32_t e = (uint32_t)(plan.n_total - 1 - ((int)plan.k0[i] + (int)plan.proto_index[i][k]));
+      QM31 b = alpha;
+      c = q_one();
+      while (e) {
+        if (e & 1u) c = q_mul(c, b);
+        b = q_mul(b, b);
+        e >>= 1;
+      }
+      if ((plan.neg[i] >> k) & 1u) c = q_neg(c);
+    }
+    coeff_out[idx] = c;
+  }
+}
+void launch_chan_claims_root_alpha(DevChannel* ch, const ChanCoeffPlan& plan, const uint32_t* root, DevReport* rep,
+                                   QM31* coeff_out, lmn_stream_t s) {
+  if (plan.n_inst < 1 || plan.n_inst > CHAN_MAX_INST) throw LmnError(-100, "chan_claims_root_alpha: bad component count");
+  LMN_LAUNCH(k_chan_claims_root_alpha, dim3(1), dim3(TPB), 0, s, ch, plan, root, rep, coeff_out);
+}
+
+LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
+                            QM31* maps_out) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED uint32_t sh_pt[8];
+  if (threadIdx.x == 0) {
+    uint32_t r[8];
+    for (int k = 0; k < 8; ++k) r[k] = rep->roots[2][k] = root[k];
+    chan_mix_words(ch, r, 8);
+    uint32_t f[8];
+    chan_draw_base_felts(ch, f);
+    const QM31 tt{f[0], f[1], f[2], f[3]};
+    rep->t = tt;
+    const QM31 t2 = q_sqr(tt);
+    const QM31 tinv = q_inv(q_add_m(t2, 1u));
+    const QM31 x = q_mul(q_sub(q_one(), t2), tinv), y = q_mul(q_add(tt, tt), tinv);
+    sh_pt[0] = x.a; sh_pt[1] = x.b; sh_pt[2] = x.c; sh_pt[3] = x.d;
+    sh_pt[4] = y.a; sh_pt[5] = y.b; sh_pt[6] = y.c; sh_pt[7] = y.d;
+  }
+  __syncthreads();
+  const QM31 ox{sh_pt[0], sh_pt[1], sh_pt[2], sh_pt[3]}, oy{sh_pt[4], sh_pt[5], sh_pt[6], sh_pt[7]};
+  for (int p = (int)threadIdx.x; p < plan.n_points; p += (int)blockDim.x) {
+    QM31 px = ox, py = oy;
+    if (p > 0) {   // secure point + base point (host.h qpt_add_m)
+      const uint32_t bx = plan.step_x[p], by = plan.step_y[p];
+      px = q_sub(q_mul_m(ox, bx), q_mul_m(oy, by));
+      py = q_add(q_mul_m(ox, by), q_mul_m(oy, bx));
+    }
+    QM31* mp = maps_out + (size_t)p * plan.n_maps;
+    mp[0] = py;
+    mp[1] = px;
+    QM31 cur = px;
+    for (int k = 2; k < plan.n_maps; ++k) {
+      cur = q_sub_m(q_add(q_sqr(cur), q_sqr(cur)), 1u);
+      mp[k] = cur;
+    }
+  }
+}
+void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep, QM31* maps_out,
+                           lmn_stream_t s) {
+  if (plan.n_points < 1 || plan.n_points > CHAN_MAX_POINTS || plan.n_maps < 2) throw LmnError(-100, "chan_root_oods: bad plan");
+  LMN_LAUNCH(k_chan_root_oods, dim3(1), dim3(64), 0, s, ch, plan, root, rep, maps_out);
+}
+
+// =============================================================================================
 // FRI tail: all layers of size <= 1024 in ONE single-block launch: per layer Merkle-commit the
 // line evaluation (LDS tree), mix the root into the device-resident channel, draw the folding
 // alpha, fold.  Every layer's evaluations and tree levels still go to HBM for decommitment.

@@ -59,17 +59,20 @@ LMN_D QM31 load_secure(const uint32_t* __restrict__ base, uint64_t stride, uint3
 // those get promoted to LDS and cost occupancy).  rc[j]: 0 = NodeElements (z, alpha); 1 = width-1
 // LUT relation val - z2 (range check); 2 = width-2 LUT relation val + alpha2*id - z2 (sin/exp2/log2).
 // neg: numerator is -mult.
+struct CompElems {
+  QM31 z, alpha, z2, alpha2;
+};
 template <int NREL>
-LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const uint32_t (&mult)[NREL],
+LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const CompElems& ce, const uint32_t (&mult)[NREL],
                              const uint32_t (&val)[NREL], const uint32_t (&id)[NREL], const int (&rc)[NREL], bool neg,
                              uint32_t s, uint32_t t, uint64_t E) {
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
     QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * a.stride, a.stride, t);
-    QM31 den = rc[j] == 1   ? q_sub(q_from_m(val[j]), a.z2)
-               : rc[j] == 2 ? q_sub(q_add_m(q_mul_m(a.alpha2, id[j]), val[j]), a.z2)
-                            : q_sub(q_add_m(q_mul_m(a.alpha, id[j]), val[j]), a.z);
+    QM31 den = rc[j] == 1   ? q_sub(q_from_m(val[j]), ce.z2)
+               : rc[j] == 2 ? q_sub(q_add_m(q_mul_m(ce.alpha2, id[j]), val[j]), ce.z2)
+                            : q_sub(q_add_m(q_mul_m(ce.alpha, id[j]), val[j]), ce.z);
     QM31 diff;
     if (j < NREL - 1) {
       diff = q_sub(cur, prev);
@@ -89,7 +92,10 @@ LMN_KERNEL k_composition(CompositionArgs a) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // row inside the block handled by this launch
   if (t >= a.n_rows) return;
   const uint32_t s = a.row0 + t;                             // storage index on the whole eval domain
-  ConsAcc ca{qacc_zero(), a.coeff, 0};
+  // coefficients and relation elements: kernel arguments, or what the device-resident channel left in memory
+  ConsAcc ca{qacc_zero(), a.d_coeff ? a.d_coeff : a.coeff, 0};
+  const CompElems ce = a.d_elems ? CompElems{a.d_elems->z[0], a.d_elems->alpha[0], a.d_elems->z[a.es2], a.d_elems->alpha[a.es2]}
+                                 : CompElems{a.z, a.alpha, a.z2, a.alpha2};
   const uint32_t* __restrict__ mn = a.main + t;
   const uint64_t cstride = a.stride;
 #define LMN_COL(k) mn[(uint64_t)(k) * cstride]
@@ -116,7 +122,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, out}, ri[3] = {lhs_id, rhs_id, node};
     const int rc[3] = {0, 0, 0};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<3>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 2 || KIND == 7) {
     // Recip / Sqrt (13 cols; the eval_fixed_* forms are unpinned natural identities)
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -134,7 +140,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     const int rc[2] = {0, 0};
-    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<2>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 8) {
     // Rem (16 cols): lhs = rhs*quotient + rem (unpinned form); the out relation carries `rem`
     const uint32_t node = LMN_COL(0), lhs_id = LMN_COL(1), rhs_id = LMN_COL(2), idx = LMN_COL(3), is_last = LMN_COL(4);
@@ -150,7 +156,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {lhs, rhs, rem}, ri[3] = {lhs_id, rhs_id, node};
     const int rc[3] = {0, 0, 0};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<3>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 13) {
     // LessThan (22 cols; less_than/component.rs:48-185): 9 local constraints, 3 node relations +
     // 4 range-check relations on the 8-bit limbs of diff
@@ -172,18 +178,18 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     const uint32_t rm[7] = {m0, m1, m2, md, md, md, md}, rv[7] = {lhs, rhs, out, l0, l1, l2, l3};
     const uint32_t ri[7] = {lhs_id, rhs_id, node, 0u, 0u, 0u, 0u};
     const int rc[7] = {0, 0, 0, 1, 1, 1, 1};
-    logup_constraints<7>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<7>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 14) {
     // RangeCheckLookup: multiplicity column + preprocessed LUT column, relation (-multiplicity, [lut])
     const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {0u};
     const int rc[1] = {1};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, t, E);
+    logup_constraints<1>(ca, a, ce, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 4) {
     // SinLookup / Exp2Lookup / Log2Lookup (lookups/sin/component.rs:40-59): multiplicity column + the two
     // preprocessed LUT columns, relation (-multiplicity, [lut_0, lut_1])
     const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {a.pre2[t]};
     const int rc[1] = {2};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, true, s, t, E);
+    logup_constraints<1>(ca, a, ce, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 3) {
     // Sin / Exp2 / Log2 (12 cols; sin/component.rs:50-122): the function value is enforced by the LUT
     // relation (lookup_mult, [input, out]) only
@@ -198,7 +204,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[3] = {m0, m1, m2}, rv[3] = {inp, out, inp}, ri[3] = {in_id, node, out};
     const int rc[3] = {0, 0, 2};
-    logup_constraints<3>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<3>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 5 || KIND == 6 || KIND == 16) {
     // SumReduce (14 cols) / MaxReduce (15) / Contiguous (11): shared id/idx prefix, 2 relations
     const uint32_t node = LMN_COL(0), in_id = LMN_COL(1), idx = LMN_COL(2), is_last = LMN_COL(3);
@@ -226,7 +232,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[2] = {m0, m1}, rv[2] = {inp, out}, ri[2] = {in_id, node};
     const int rc[2] = {0, 0};
-    logup_constraints<2>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<2>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else {
     const uint32_t node = LMN_COL(0), idx = LMN_COL(1), is_last = LMN_COL(2), n_node = LMN_COL(3), n_idx = LMN_COL(4);
     const uint32_t val = LMN_COL(5), mult = LMN_COL(6);
@@ -236,7 +242,7 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     ca.add_m(m_mul(not_last, m_sub(m_sub(n_idx, idx), 1u)));
     const uint32_t rm[1] = {mult}, rv[1] = {val}, ri[1] = {node};
     const int rc[1] = {0};
-    logup_constraints<1>(ca, a, rm, rv, ri, rc, false, s, t, E);
+    logup_constraints<1>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   }
 #undef LMN_COL
   QM31 r = q_mul_m(qacc_reduce(ca.acc), a.zinv[(s >> a.log_size) & 1u]);

@@ -6,15 +6,15 @@ namespace lmn {
 
 // ------------------------------------------------------------------------------------ OODS evaluation
 std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points,
-                                          int max_log, bool split) {
-  const int np = (int)points.size();
+                                          int max_log, bool split, const QM31* d_maps_in, int n_points) {
+  const int np = d_maps_in ? n_points : (int)points.size();
   const uint32_t lo_n = 1u << EVAL_LB;
   const int hi_bits = max_log > EVAL_LB ? max_log - EVAL_LB : 0;
   const uint32_t hi_n = 1u << hi_bits;
   const int nmaps = std::max(max_log, EVAL_LB);
   // mappings per point: y, x, pi(x), pi^2(x), ...  (tables themselves are expanded on the device)
-  std::vector<QM31> maps((size_t)np * nmaps);
-  for (int p = 0; p < np; ++p) {
+  std::vector<QM31> maps(d_maps_in ? 0 : (size_t)np * nmaps);
+  for (int p = 0; p < np && !d_maps_in; ++p) {
     QM31* mp = &maps[(size_t)p * nmaps];
     mp[0] = points[p].y;
     mp[1] = points[p].x;
@@ -26,7 +26,7 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
   }
   int max_chunks = eval_num_chunks(max_log);
   EvalJob* d_jobs = upload_vec(jobs);
-  QM31* d_maps = upload_vec(maps);
+  const QM31* d_maps = d_maps_in ? d_maps_in : upload_vec(maps);
   QM31* d_lo = (QM31*)arena_.alloc_bytes((size_t)np * lo_n * sizeof(QM31));
   QM31* d_hi = (QM31*)arena_.alloc_bytes((size_t)np * hi_n * sizeof(QM31));
   QM31* d_part = (QM31*)arena_.alloc_bytes(jobs.size() * (size_t)max_chunks * sizeof(QM31));

@@ -7,12 +7,16 @@ namespace lmn {
 void Context::run_composition(ProofRun& r) {
   LMN_RUN_ALIASES(r);
   // ---- stwo::prover::prove (prover.rs:312): composition polynomial
-  comp_alpha = channel.draw_felt();
+  // (device-resident transcript: the randomness was drawn and every coefficient laid out by k_chan_claims_root_alpha)
   int n_total = 0;
   for (auto& ci : inst) n_total += constraint_layout(*ci.spec, cfg.protocol_variant).n_protocol;
-  std::vector<QM31> powers(n_total);
-  powers[0] = q_one();
-  for (int k = 1; k < n_total; ++k) powers[k] = q_mul(powers[k - 1], comp_alpha);
+  std::vector<QM31> powers(std::max(n_total, 1));
+  if (!r.dev_fs) {
+    comp_alpha = channel.draw_felt();
+    powers[0] = q_one();
+    for (int k = 1; k < n_total; ++k) powers[k] = q_mul(powers[k - 1], comp_alpha);
+  }
+  size_t inst_index = 0;
   {
     StageTimer st(this, log, stream_, C_COMPOSITION);
     std::map<int, uint32_t*> sub;  // eval log -> 4 x 2^e accumulation buffer
@@ -67,10 +71,19 @@ void Context::run_composition(ProofRun& r) {
       a.pre2 = ci.pre_idx[1] >= 0 ? tree0.cols[ci.pre_idx[1]].lde : nullptr;
       a.claimed_shift = ci.d_claimed_shift;
       const ConstraintLayout L = constraint_layout(*ci.spec, cfg.protocol_variant);
-      for (int k = 0; k < L.n_kernel; ++k) {
-        a.coeff[k] = L.proto_index[k] < 0 ? q_zero() : powers[n_total - 1 - (k0 + L.proto_index[k])];
-        if (L.neg[k]) a.coeff[k] = q_neg(a.coeff[k]);
+      if (r.dev_fs) {
+        a.d_coeff = r.d_coeff + 16 * inst_index;
+        a.d_elems = &r.d_report->elems;
+        a.es2 = ELEMS_NODE;
+        for (int j = 0; j < ci.spec->n_rel; ++j)
+          if (ci.spec->rel_elems[j] != ELEMS_NODE) a.es2 = ci.spec->rel_elems[j];
+      } else {
+        for (int k = 0; k < L.n_kernel; ++k) {
+          a.coeff[k] = L.proto_index[k] < 0 ? q_zero() : powers[n_total - 1 - (k0 + L.proto_index[k])];
+          if (L.neg[k]) a.coeff[k] = q_neg(a.coeff[k]);
+        }
       }
+      ++inst_index;
       k0 += L.n_protocol;
       for (int b = 0; b < 2; ++b) {
         Pt p = domain_point(e, (uint32_t)b << ci.log_size);
@@ -118,6 +131,11 @@ void Context::run_composition(ProofRun& r) {
   }
   {
     StageTimer st(this, log, stream_, C_COMP_COMMIT);
+    if (r.dev_fs) {
+      lde_and_merkle(tree3, false);   // no wait: run_oods goes on with k_chan_root_oods
+      hm.mark("composition enqueued (device transcript)");
+      return;
+    }
     lde_and_merkle(tree3);
     lmn_sync(stream_);
     tree3.merkle.finish_root();

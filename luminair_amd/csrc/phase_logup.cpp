@@ -7,7 +7,8 @@ namespace lmn {
 void Context::run_interaction(ProofRun& r) {
   LMN_RUN_ALIASES(r);
   // ---- PHASE 2: interaction trace (prover.rs:186-298)
-  elems = draw_relation_elements(channel, cfg.protocol_variant);
+  if (!r.dev_fs) elems = draw_relation_elements(channel, cfg.protocol_variant);   // else: drawn on the device, `drawn` set in run_main_trace
+  const DevElems* d_elems = r.dev_fs ? &r.d_report->elems : nullptr;
   {
     StageTimer st(this, log, stream_, C_LOGUP);
     int off = 0;
@@ -83,6 +84,8 @@ void Context::run_interaction(ProofRun& r) {
         a.neg[j] = sp->rel_neg[j];
         a.z[j] = elems.z[es];
         a.alpha[j] = elems.alpha[es];
+        a.es[j] = es;
+        a.d_elems = d_elems;
       }
       a.inter = ievals;
       a.last_tmp = (QM31*)arena_.alloc_bytes(n * sizeof(QM31));
@@ -110,6 +113,31 @@ void Context::run_interaction(ProofRun& r) {
     // commit the interaction tree first (it does not depend on the transcript), then fetch the
     // claimed sums and the root with a single synchronisation
     StageTimer st(this, log, stream_, C_INTER_COMMIT);
+    if (r.dev_fs) {
+      // no wait: the device mixes the claimed sums and the root, draws the composition randomness and lays out every
+      // component's constraint coefficients (k_chan_claims_root_alpha)
+      lde_and_merkle(tree2, false);
+      ChanCoeffPlan plan{};
+      if (inst.size() > (size_t)CHAN_MAX_INST) throw LmnError(LMN_ERR_INTERNAL, "more components than claim slots");
+      plan.n_inst = (int)inst.size();
+      int k0 = 0;
+      for (size_t i = 0; i < inst.size(); ++i) {
+        const ConstraintLayout L = constraint_layout(*inst[i].spec, cfg.protocol_variant);
+        plan.claimed[i] = inst[i].d_claimed_shift;
+        plan.k0[i] = (int16_t)k0;
+        plan.n_kernel[i] = (int8_t)L.n_kernel;
+        for (int k = 0; k < 16; ++k) plan.proto_index[i][k] = (int8_t)(k < L.n_kernel ? L.proto_index[k] : -1);
+        uint16_t neg = 0;
+        for (int k = 0; k < L.n_kernel; ++k) neg |= (uint16_t)(L.neg[k] ? 1u << k : 0u);
+        plan.neg[i] = neg;
+        k0 += L.n_protocol;
+      }
+      plan.n_total = k0;
+      r.d_coeff = (QM31*)arena_.alloc_bytes(inst.size() * 16 * sizeof(QM31));
+      launch_chan_claims_root_alpha(r.d_chan, plan, tree2.merkle.layers[0], r.d_report, r.d_coeff, stream_);
+      hm.mark("interaction trace enqueued (device transcript)");
+      return;
+    }
     lde_and_merkle(tree2);
     std::vector<const QM31*> cs(inst.size());
     for (size_t i = 0; i < inst.size(); ++i)

@@ -4,20 +4,76 @@
 
 namespace lmn {
 
+// The host's first wait of a proof with the device-resident transcript is over: replay the steps the k_chan_* kernels
+// made - root 1, relation draws, claimed sums, root 2, composition randomness, root 3, OODS draw - on the host channel
+// from what came back in the DevReport, and insist that every draw agrees.
+void Context::replay_device_transcript(ProofRun& r, const std::function<void(QM31)>& set_points) {
+  LMN_RUN_ALIASES(r);
+  const DevReport& rep = *r.h_report;
+  if (rep.bad == r.bad_mark)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace table holds a word that is not a canonical M31 (>= 2^31-1)");
+  auto diverged = [](const char* what) {
+    return LmnError(LMN_ERR_INTERNAL, std::string("device/host transcript divergence at ") + what);
+  };
+  memcpy(tree1.merkle.root.w, rep.roots[0], 32);
+  memcpy(tree2.merkle.root.w, rep.roots[1], 32);
+  memcpy(tree3.merkle.root.w, rep.roots[2], 32);
+  channel.mix_root(tree1.merkle.root);
+  hm.mark("replay: root1 mixed");
+  elems = draw_relation_elements(channel, cfg.protocol_variant);
+  for (int e = 0; e < N_ELEMS; ++e)
+    if (elems.drawn[e] && (!q_eq(elems.z[e], rep.elems.z[e]) || !q_eq(elems.alpha[e], rep.elems.alpha[e])))
+      throw diverged("the relation elements");
+  for (size_t i = 0; i < inst.size(); ++i) {
+    inst[i].claimed = rep.claimed[i];
+    proof.interaction_claim[inst[i].spec->kind] = {true, rep.claimed[i]};
+  }
+  for (int k = 0; k < n_slots; ++k)
+    if (proof.interaction_claim[k].first) channel.mix_felts({proof.interaction_claim[k].second});
+  channel.mix_root(tree2.merkle.root);
+  comp_alpha = channel.draw_felt();
+  if (!q_eq(comp_alpha, rep.comp_alpha)) throw diverged("the composition randomness");
+  channel.mix_root(tree3.merkle.root);
+  for (auto* t : trees) proof.commitments.push_back(t->merkle.root);
+  const QM31 tt = channel.draw_felt();
+  if (!q_eq(tt, rep.t)) throw diverged("the OODS point");
+  set_points(tt);
+  hm.mark("replay: transcript up to the OODS point");
+}
+
 void Context::run_oods(ProofRun& r) {
   LMN_RUN_ALIASES(r);
-  // ---- OODS point + mask points
-  QM31 tt = channel.draw_felt();
-  QM31 t2 = q_sqr(tt);
-  QM31 tinv = q_inv(q_add_m(t2, 1u));
-  oods = QPt{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
-  points.assign(1, oods);
+  // ---- OODS point + mask points: point 0 = the OODS point, then per trace size the point one trace step before it
   std::map<int, int> prev_point_of_log;
+  std::vector<Pt> neg_step{Pt{1u, 0u}};
   for (auto& ci : inst) {
     if (prev_point_of_log.count(ci.log_size)) continue;
-    Pt stp = pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu);  // -step
-    prev_point_of_log[ci.log_size] = (int)points.size();
-    points.push_back(qpt_add_m(oods, stp));
+    prev_point_of_log[ci.log_size] = (int)neg_step.size();
+    neg_step.push_back(pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu));  // -step
+  }
+  auto set_points = [&](QM31 tt) {
+    QM31 t2 = q_sqr(tt);
+    QM31 tinv = q_inv(q_add_m(t2, 1u));
+    oods = QPt{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
+    points.assign(1, oods);
+    for (size_t p = 1; p < neg_step.size(); ++p) points.push_back(qpt_add_m(oods, neg_step[p]));
+  };
+  if (r.dev_fs) {
+    // the device draws the point and expands the mappings (k_chan_root_oods); everything the device-resident steps
+    // produced comes back in one download, valid after the wait inside eval_at_points below
+    if (neg_step.size() > (size_t)CHAN_MAX_POINTS) throw LmnError(LMN_ERR_INTERNAL, "more sample points than the device transcript plans for");
+    ChanOodsPlan plan{};
+    plan.n_points = (int)neg_step.size();
+    plan.n_maps = std::max(comp_log, EVAL_LB);
+    for (size_t p = 0; p < neg_step.size(); ++p) {
+      plan.step_x[p] = neg_step[p].x;
+      plan.step_y[p] = neg_step[p].y;
+    }
+    r.d_maps = (QM31*)arena_.alloc_bytes((size_t)plan.n_points * plan.n_maps * sizeof(QM31));
+    launch_chan_root_oods(r.d_chan, plan, tree3.merkle.layers[0], r.d_report, r.d_maps, stream_);
+    r.h_report = (const DevReport*)stage_download(r.d_report, sizeof(DevReport));
+  } else {
+    set_points(channel.draw_felt());
   }
   // sample point indices per tree/column, in sampled_values order
   spoints.assign(4, {});
@@ -36,7 +92,8 @@ void Context::run_oods(ProofRun& r) {
     for (int t = 0; t < 4; ++t)
       for (size_t c = 0; c < trees[t]->cols.size(); ++c)
         for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p, trees[t]->cols[c].owner});
-    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true);
+    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true, r.dev_fs ? r.d_maps : nullptr, (int)neg_step.size());
+    if (r.dev_fs) replay_device_transcript(r, set_points);
     size_t k = 0;
     for (int t = 0; t < 4; ++t) {
       sampled[t].resize(trees[t]->cols.size());

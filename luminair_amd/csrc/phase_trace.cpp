@@ -134,6 +134,25 @@ void Context::run_main_trace(ProofRun& r) {
     }
     for (int k = 0; k < n_slots; ++k)  // LuminairClaim::mix_into (crates/air/src/lib.rs:52-104)
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
+    r.bad_mark = bad_mark;
+    if (r.dev_fs) {
+      // no wait: the device mixes the root and draws the relation elements (k_chan_root_elems); the host replays the
+      // step in run_oods, where the non-canonical-word verdict is read as well
+      lde_and_merkle(tree1, false);
+      DevChannel hc{};
+      memcpy(hc.digest, channel.digest().w, 32);
+      hc.n_sent = 0;
+      hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;
+      r.d_chan = (DevChannel*)stage_upload(&hc, sizeof hc);
+      r.d_report = (DevReport*)arena_.alloc_bytes(sizeof(DevReport));
+      int sets[CHAN_N_ELEMS];
+      const int n_draws = relation_draw_sets(cfg.protocol_variant, sets);
+      launch_chan_root_elems(r.d_chan, tree1.merkle.layers[0], d_bad, sets, n_draws, r.d_report, stream_);
+      for (int i = 0; i < n_draws; ++i)
+        if (sets[i] >= 0) elems.drawn[sets[i]] = true;
+      hm.mark("main trace enqueued (device transcript)");
+      return;
+    }
     lde_and_merkle(tree1);
     uint32_t n_flags = 1;
     if (any_rows_front) {   // every rank has only looked at its own rows: the ranks must agree on the verdict

@@ -48,6 +48,16 @@ struct ProofRun {
   std::vector<uint32_t*> pre_evals;  // tree-0 columns on their trace domain (logup denominators)
   RelElems elems;
   QM31 comp_alpha{};
+  // Device-resident Fiat-Shamir of the commitment phases (unsharded proofs): the host enqueues everything up to the
+  // sampled values without waiting; the k_chan_* kernels do the transcript steps in between and report back through
+  // `d_report`, which the host reads at its first wait (run_oods) to replay and cross-check the same steps.
+  bool dev_fs = false;
+  DevChannel* d_chan = nullptr;
+  DevReport* d_report = nullptr;
+  const DevReport* h_report = nullptr;   // page-locked copy, valid after the wait in run_oods
+  QM31* d_coeff = nullptr;               // 16 constraint-slot coefficients per component
+  QM31* d_maps = nullptr;                // point mappings for launch_eval_tables
+  uint32_t bad_mark = 0;                 // this proof's mark of the non-canonical-word verdict
   // OODS
   QPt oods{};
   std::vector<QPt> points;

@@ -1,6 +1,7 @@
 // Device-resident prover context and the `prove` orchestration that replaces
 // /root/reference/crates/prover/src/prover.rs:28-319 on MI355X.
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -39,6 +40,8 @@ struct RelElems {
 };
 class Channel;
 RelElems draw_relation_elements(Channel& channel, uint32_t protocol_flags);
+// the element set each draw_felts(2) of LuminairInteractionElements::draw fills, in draw order; returns the number of draws
+int relation_draw_sets(uint32_t protocol_flags, int sets_out[5]);
 inline int claim_slots(uint32_t protocol_flags) { return (protocol_flags & LMN_PV_CLAIM17) ? 17 : 8; }
 
 // Constraint slots of a component under the protocol's constraint-form bits (LMN_PV_*_SLOT(S) / _NEG, luminair_hip.h).
@@ -242,6 +245,7 @@ class Context {
   void run_interaction(ProofRun& r);
   void run_composition(ProofRun& r);
   void run_oods(ProofRun& r);
+  void replay_device_transcript(ProofRun& r, const std::function<void(QM31)>& set_points);
   void run_quotients(ProofRun& r);
   void run_fri_commit(ProofRun& r);
   void run_queries(ProofRun& r);
@@ -281,7 +285,7 @@ class Context {
   bool shard_a2a_columns(int log_size) const;   // stage A / B for columns of this size
   bool shard_rows_front(int log_size) const;    // row-parallel transposes and logup fractions for tables of this size
   // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
-  void lde_and_merkle(DevTree& tree);
+  void lde_and_merkle(DevTree& tree, bool fetch_root = true);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its
   // row block, the subtree roots are all-gathered and the top log2(world) levels are hashed on every rank.
   // `fold` (unsharded FRI layers of more than 2^10 rows only): the leaf level computes the layer as the fold of the
@@ -302,8 +306,9 @@ class Context {
                                   const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);
   // split: a sharded proof evaluates 1/world of every polynomial's coefficient chunks per rank and all-gathers the
   // partial sums (16 B per sample and rank)
+  // d_maps (device, n_points x max(max_log, EVAL_LB) mappings, written by k_chan_root_oods) replaces `points` when given
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log,
-                                   bool split = false);
+                                   bool split = false, const QM31* d_maps = nullptr, int n_points = 0);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
   void begin_op();

@@ -247,6 +247,10 @@ def format_report(res: PinResult, top: int = 6) -> str:
             lines.append("  %-16s = %s" % (B.PV_NAMES[b], "correlated (see list)" if v is None else int(v)))
         for b in res.undetermined:
             lines.append("  %-16s   undetermined (verdict does not depend on it)" % B.PV_NAMES[b])
+        if B.PV_POW_PREFIXED in res.undetermined:
+            lines.append("  note: the proof-of-work form is decided by ONE check worth pow_bits bits (5 by default): a nonce found "
+                         "under one form passes the other with probability 2^-pow_bits, as it did here.  Run the tool on a second "
+                         "proof, or with --tables (the prover's own nonce differs between the two forms).")
         lines.append("accepting protocol_variant values: %s" % ", ".join("0x%04x %s" % (f, flag_names(f) or ["KAT"]) for f in res.accepted))
         if res.unique:
             f = res.accepted[0]

@@ -437,3 +437,40 @@ def test_emu_rows_in_lmn_host_alloc_memory(emu_ctx):
     assert emu_lib.lib.lmn_host_alloc(64, None) == bk.ERR_INVALID_ARGUMENT
     assert emu_lib.lib.lmn_host_register(None, 64) == bk.ERR_INVALID_ARGUMENT
     assert emu_lib.lib.lmn_host_unregister(None) == bk.ERR_INVALID_ARGUMENT
+
+
+def test_emu_device_and_host_transcript_give_the_same_bytes_and_errors(root, monkeypatch):
+    """The commitment phases' Fiat-Shamir steps run on the device by default (k_chan_* kernels, no host wait before the
+    sampled values) and on the host under LMN_HOST_FS=1: same proof bytes for a multi-component pie with LUT relations
+    and a non-default constraint form, same rejection of a non-canonical word and of an unsatisfied constraint."""
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    cfg = lib.default_config()
+    cfg.protocol_variant = backend.VARIANT_PINNED | backend.PV_MUL_ONE_SLOT | backend.PV_RECIP_NEG
+    ctx = backend.Context(0, cfg, lib)
+    cases = [(syn.chain_graph(300, 3) + [], None)]
+    tabs, luts = syn.activation_graph(40, 3)
+    cases.append((tabs, luts))
+    for tabs, luts in cases:
+        t = [(k, r, len(r)) for k, r in tabs]
+        monkeypatch.delenv("LMN_HOST_FS", raising=False)
+        dev = ctx.prove_tables(t, luts)
+        monkeypatch.setenv("LMN_HOST_FS", "1")
+        assert ctx.prove_tables(t, luts) == dev
+    tabs = syn.chain_graph(300, 3)
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("LMN_HOST_FS", env)
+        else:
+            monkeypatch.delenv("LMN_HOST_FS", raising=False)
+        bad = [(k, r.copy(), len(r)) for k, r in tabs]
+        bad[0][1][5, 9] = 0x7fffffff
+        with pytest.raises(backend.LuminairBackendError) as e:
+            ctx.prove_tables(bad)
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+        wrong = [(k, r.copy(), len(r)) for k, r in tabs]
+        wrong[0][1][7, 11] = (int(wrong[0][1][7, 11]) + 1) % 0x7fffffff          # out != lhs + rhs
+        with pytest.raises(backend.LuminairBackendError) as e:
+            ctx.prove_tables(wrong)
+        assert e.value.code == backend.ERR_CONSTRAINTS
+        assert ctx.prove_tables([(k, r, len(r)) for k, r in tabs])               # the context stays usable
+    ctx.close()
