@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import luminair_amd
-from luminair_amd import synthetic as syn
+from luminair_amd import backend, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
@@ -792,3 +792,26 @@ def test_gpu_prover_pool_prove_many(hip_lib_path):
     want = [pool.provers[0].prove(p).to_bincode() for p in pies]
     assert [p.to_bincode() for p in pool.prove_many(pies)] == want
     pool.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [
+    backend.PV_MIX_U64_HASHED | backend.PV_POW_PREFIXED | backend.PV_MUL_ONE_SLOT | backend.PV_RECIP_NEG,
+    backend.PV_DRAW_CTR_U32 | backend.PV_RECIP_TWO_SLOTS,
+    backend.VARIANT_PINNED | backend.PV_SQRT_TWO_SLOTS | backend.PV_SQRT_NEG | backend.PV_REM_NEG | backend.PV_MUL_ONE_SLOT,
+])
+def test_gpu_protocol_flag_combinations_equal_oracle(hip_lib_path, c_oracle, flags):
+    """Round 5: `protocol_variant` is a set of independent flags (encodings, proof-of-work form, slot count and sign of the
+    un-vendored eval_fixed_* helpers).  Combinations away from KAT / PINNED: GPU bytes == C oracle bytes at 2^14 rows, the
+    product verifier accepts them under the same flags and rejects them under a neighbouring combination."""
+    from oracle.channel import ProtocolVariant
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    tabs = syn.sqrt_rem_graph(1 << 14, 4) if flags & backend.PV_CLAIM17 else syn.chain_graph(1 << 14, 5)
+    p = luminair_amd.Prover(0, protocol_variant=flags)
+    got = p.prove(luminair_amd.LuminairPie.from_tables(tabs)).to_bincode()
+    assert got == to_bincode(prove(tabs, variant=ProtocolVariant(flags), kernels=c_oracle))
+    luminair_amd.verify(luminair_amd.LuminairProof(got), protocol_variant=flags)
+    with pytest.raises(luminair_amd.LuminairError):
+        luminair_amd.verify(luminair_amd.LuminairProof(got), protocol_variant=flags ^ backend.PV_MIX_U64_HASHED)
+    p.ctx.close()
