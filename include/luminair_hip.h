@@ -108,7 +108,7 @@ uint32_t lmn_abi_version(void);
 /* Replaces PcsConfig::default() (prover.rs:36) + DEFAULT_FP_SCALE (crates/air/src/lib.rs:23-24). */
 typedef struct lmn_config {
   uint32_t pow_bits;         /* default 5 */
-  uint32_t log_blowup;       /* default 1 (only 1 is supported: eval domain == LDE domain) */
+  uint32_t log_blowup;       /* default 1 (= blow-up 2, PcsConfig::default()); 1..3 accepted, sharded proofs: 1 only */
   uint32_t log_last_layer;   /* default 0 */
   uint32_t n_queries;        /* default 3 */
   uint32_t fp_scale;         /* default 12 */

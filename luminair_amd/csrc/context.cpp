@@ -33,7 +33,7 @@ void* Arena::alloc_bytes(size_t bytes) {
 
 Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
   // validate before acquiring anything: a throwing constructor does not run the destructor
-  if (cfg.log_blowup != 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "only log_blowup = 1 is supported");
+  if (cfg.log_blowup < 1 || cfg.log_blowup > 3) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "log_blowup must be 1, 2 or 3");
   if (cfg.n_queries == 0 || cfg.n_queries > 1024) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad n_queries");
   if (cfg.log_last_layer > 10) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad log_last_layer");
   if (cfg.pow_bits > 40) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad pow_bits");

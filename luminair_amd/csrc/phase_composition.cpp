@@ -33,6 +33,25 @@ void Context::run_composition(ProofRun& r) {
       a.eval_log = e;
       a.main = tree1.cols[ci.main_start].lde;
       a.inter = tree2.cols[ci.inter_start].lde;
+      const uint32_t* pre_e[2] = {ci.pre_idx[0] >= 0 ? tree0.cols[ci.pre_idx[0]].lde : nullptr,
+                                  ci.pre_idx[1] >= 0 ? tree0.cols[ci.pre_idx[1]].lde : nullptr};
+      if (lb != 1) {
+        // The constraints are evaluated on the domain of log size log_size + 1 (max_constraint_log_degree_bound,
+        // add/component.rs:33-35).  At blow-up 2 that IS the committed LDE; at larger blow-ups it is not (canonic cosets of
+        // different sizes are disjoint), so the component's columns are evaluated there from their coefficients.
+        auto on_eval_domain = [&](const uint32_t* coeffs, int ncols) {
+          uint32_t* ev = arena_.alloc_words((size_t)ncols * E);
+          StageTimer t(this, log, stream_, C_FFT);
+          timings.fft_launches += launch_fft(ev, E, coeffs, 1ull << ci.log_size, ci.log_size, ncols, e, tw(e), stream_);
+          timings.fft_bytes += (uint64_t)ncols * (4ull << ci.log_size) + (uint64_t)ncols * 4ull * E;
+          timings.fft_butterflies += (uint64_t)ncols * (E / 2) * (uint64_t)e;
+          return (const uint32_t*)ev;
+        };
+        a.main = on_eval_domain(tree1.cols[ci.main_start].coeffs, ci.spec->n_cols);
+        a.inter = on_eval_domain(tree2.cols[ci.inter_start].coeffs, 4 * ci.spec->n_rel);
+        for (int k = 0; k < 2; ++k)
+          if (ci.pre_idx[k] >= 0) pre_e[k] = on_eval_domain(tree0.cols[ci.pre_idx[k]].coeffs, 1);
+      }
       a.row0 = shard_.rank << (e - sg);
       a.n_rows = (uint32_t)(E >> sg);
       a.stride = E >> sg;
@@ -67,8 +86,8 @@ void Context::run_composition(ProofRun& r) {
           a.z2 = elems.z[ci.spec->rel_elems[j]];
           a.alpha2 = elems.alpha[ci.spec->rel_elems[j]];
         }
-      a.pre = ci.pre_idx[0] >= 0 ? tree0.cols[ci.pre_idx[0]].lde : nullptr;
-      a.pre2 = ci.pre_idx[1] >= 0 ? tree0.cols[ci.pre_idx[1]].lde : nullptr;
+      a.pre = pre_e[0];
+      a.pre2 = pre_e[1];
       a.claimed_shift = ci.d_claimed_shift;
       const ConstraintLayout L = constraint_layout(*ci.spec, cfg.protocol_variant);
       if (r.dev_fs) {

@@ -53,6 +53,8 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   } cut_scope{merkle_cut_};
   merkle_cut_ = !shard_.active && getenv("LMN_MERKLE_FULL") == nullptr;
 
+  if (shard_.active && cfg.log_blowup != 1)
+    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "sharded proofs support log_blowup = 1 only");
   // Device-resident Fiat-Shamir of the commitment phases: unsharded proofs (a sharded proof exchanges data at the same
   // points anyway); LMN_HOST_FS=1 keeps the transcript on the host (round 1-4 behaviour, for A/B measurements)
   r.dev_fs = !shard_.active && getenv("LMN_HOST_FS") == nullptr;
@@ -105,6 +107,7 @@ void Context::run_setup(ProofRun& r) {
     words += (uint64_t)sp->n_pre * ((2ull << ls) + row_split(2ull << ls));  // preprocessed columns: evals + coeffs + lde
     words += (4ull << ls) * 2;                                 // logup temps
     words += (4ull << (ls + 1)) * 3;                           // per-size composition scratch
+    if (lb != 1) words += (uint64_t)(sp->n_cols + 4 * sp->n_rel + sp->n_pre) << (ls + 1);   // columns on the constraint domain
     if (shard_.active) words += (4ull << (ls + 1)) + 4096;     // halo rows of the last logup column group
     if (shard_rows_front(ls))                                  // received row blocks, gathered logup sums, scan output, coefficients
       words += (uint64_t)(sp->n_cols + 8 * sp->n_rel + 16) << ls;

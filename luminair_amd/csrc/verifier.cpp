@@ -270,7 +270,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     st.index = index;
     memcpy(st.digest, ch.digest().w, 32);
   };
-  if (expect.log_blowup != 1 || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
+  if (expect.log_blowup < 1 || expect.log_blowup > 3 || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
       expect.pow_bits > 40)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad expected PCS config");
   const int n_slots = claim_slots(variant);

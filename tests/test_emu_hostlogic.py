@@ -474,3 +474,35 @@ def test_emu_device_and_host_transcript_give_the_same_bytes_and_errors(root, mon
         assert e.value.code == backend.ERR_CONSTRAINTS
         assert ctx.prove_tables([(k, r, len(r)) for k, r in tabs])               # the context stays usable
     ctx.close()
+
+
+@pytest.mark.parametrize("log_blowup,tabs,luts,flags", [
+    (2, syn.chain_graph(300, 3), None, 0),
+    (2, syn.config3_mixed(9, 8, 8, 8), None, 0),                          # mixed-size trees
+    (3, syn.chain_graph(100, 4), None, backend.PV_MIX_U64_HASHED | backend.PV_MUL_ONE_SLOT),
+    (2,) + syn.activation_graph(40, 3) + (backend.VARIANT_PINNED,),       # preprocessed LUT columns on the constraint domain
+])
+def test_emu_larger_blowups_match_oracle(root, log_blowup, tabs, luts, flags):
+    """Blow-up 4 and 8 (round 5; the reference itself only uses PcsConfig::default() = blow-up 2): the committed LDE is then no
+    longer the constraint evaluation domain, so the composition phase evaluates the columns there from their coefficients;
+    LDE sizes, FRI layer count and query domain follow log_blowup.  Byte-equal to the oracle, accepted by the product
+    verifier under the same config only; sharded proofs refuse it."""
+    from oracle.channel import ProtocolVariant
+    from oracle.prover import PcsConfig
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    cfg = lib.default_config()
+    cfg.log_blowup, cfg.protocol_variant = log_blowup, flags
+    ctx = backend.Context(0, cfg, lib)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs], luts)
+    ctx.close()
+    want = to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs], PcsConfig(log_blowup=log_blowup),
+                                   variant=ProtocolVariant(flags), luts=luts))
+    assert got == want
+    lib.verify(got, flags, config=cfg)
+    with pytest.raises(backend.LuminairBackendError):
+        lib.verify(got, flags)                                  # the default verifier expects blow-up 2
+    bad = lib.default_config()
+    bad.log_blowup = 4
+    with pytest.raises(backend.LuminairBackendError) as e:
+        backend.Context(0, bad, lib)
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT

@@ -815,3 +815,19 @@ def test_gpu_protocol_flag_combinations_equal_oracle(hip_lib_path, c_oracle, fla
     with pytest.raises(luminair_amd.LuminairError):
         luminair_amd.verify(luminair_amd.LuminairProof(got), protocol_variant=flags ^ backend.PV_MIX_U64_HASHED)
     p.ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_blowup,tabs", [(2, syn.config3_mixed(16, 15, 15, 8)), (3, syn.chain_graph(1 << 14, 3)),
+                                            (2, syn.config2_add_only(1 << 18, 6))])
+def test_gpu_larger_blowups_match_oracle(hip_lib_path, c_oracle, log_blowup, tabs):
+    """Blow-up 4 / 8 on the MI355X (the reference only uses blow-up 2): the composition phase evaluates the columns on the
+    constraint domain from their coefficients; byte-equal to the C oracle, verified under the same config."""
+    from oracle.proof import to_bincode
+    from oracle.prover import PcsConfig, prove
+    p = luminair_amd.Prover(0, log_blowup=log_blowup)
+    got = p.ctx.prove_tables([(k, r, len(r)) for k, r in tabs])
+    want = to_bincode(prove([(k, r.astype(np.uint64)) for k, r in tabs], PcsConfig(log_blowup=log_blowup), kernels=c_oracle))
+    assert got == want
+    backend.default_library().verify(got, backend.VARIANT_KAT, config=p.ctx.config)
+    p.ctx.close()
