@@ -38,8 +38,12 @@ for seed in range(100, 100 + n):
         p = luminair_amd.Prover(0, protocol_variant=flags)
     got = p.prove(luminair_amd.LuminairPie.from_tables(tabs), luminair_amd.CircuitSettings(luts)).to_bincode()
     want = to_bincode(prove(tabs, variant=ProtocolVariant(flags), kernels=ck, luts=luts))
-    if rand_flags:
-        luminair_amd.verify(luminair_amd.LuminairProof(got), protocol_variant=flags)
+    if rand_flags:   # the product verifier under the same flags (random pies do not balance their logup sums: that verdict is expected)
+        try:
+            luminair_amd.verify(luminair_amd.LuminairProof(got), protocol_variant=flags)
+        except luminair_amd.LuminairError as e:
+            if e.variant != "InvalidLogUp":
+                raise
     if got != want:
         bad.append(seed)
 print("random pies: %d seeds, %d trace rows in total, %.0f s, mismatching seeds: %s" % (n, rows, time.time() - t0, bad))
