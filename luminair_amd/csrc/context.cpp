@@ -64,12 +64,10 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
       LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     }
   }
-  if (getenv("LMN_FRI_OVERLAP") && atoi(getenv("LMN_FRI_OVERLAP")) != 0) {
-    LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-    ev_fork_ = lmn_event_create_sync();
-    ev_join_ = lmn_event_create_sync();
-    have_stream2_ = true;
-  }
+#ifndef LMN_BATCH
+  // LMN_FRI_OVERLAP (experiment; default off): 1 = always, 2 = while this is the process's only proof in flight
+  fri_overlap_mode_ = getenv("LMN_FRI_OVERLAP") ? std::max(0, std::min(2, atoi(getenv("LMN_FRI_OVERLAP")))) : 0;
+#endif
 #else
   stream_ = 0;
 #endif
@@ -82,6 +80,27 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
     lmn_h2d(bad_flag_, zero, 8, stream_);
     lmn_sync(stream_);
   }
+}
+
+std::atomic<int> g_proofs_in_flight{0};
+
+// Experiment switch: the smaller FRI quotient column on a second stream next to the leaf hashing of the larger one's.  It
+// helped a solo proof in round 3 (-50 us) and cost 7 % of throughput; with round 4's fused first layer it costs a solo
+// proof 60 - 100 us as well (round 5, gpu_session_r8k: 2.37 - 2.46 vs 2.33 - 2.37 ms), also in the "only while no other proof
+// of the process is in flight" form (mode 2).  Off by default; the stream is created on first use.
+bool Context::second_stream_wanted() {
+#if defined(LMN_EMU) || defined(LMN_BATCH)
+  return false;
+#else
+  if (fri_overlap_mode_ == 0 || (fri_overlap_mode_ == 2 && g_proofs_in_flight.load(std::memory_order_relaxed) != 1)) return false;
+  if (!have_stream2_) {
+    LMN_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    ev_fork_ = lmn_event_create_sync();
+    ev_join_ = lmn_event_create_sync();
+    have_stream2_ = true;
+  }
+  return true;
+#endif
 }
 
 Context::~Context() {

@@ -176,7 +176,7 @@ void Context::run_quotients(ProofRun& r) {
       }
       // unsharded proofs with two LDE sizes: the second (smaller) size is computed on the second stream, next to the
       // leaf hashing of the first size's quotient columns; build_merkle_levels waits for it before level `ls`
-      const bool overlap = have_stream2_ && !sh && sizes.size() == 2 && ls == sizes[1];
+      const bool overlap = !sh && sizes.size() == 2 && ls == sizes[1] && second_stream_wanted();
       if (overlap) {
         lmn_event_record(ev_fork_, stream_);            // everything enqueued so far (incl. the entry-table upload)
         lmn_stream_wait_event(stream2_, ev_fork_);

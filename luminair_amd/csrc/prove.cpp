@@ -30,6 +30,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   LMN_HIP_CHECK(hipSetDevice(device_));
 #endif
   if (!tables || n_tables == 0) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "no trace tables");
+  struct InFlight {
+    InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
+    ~InFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+  } in_flight;
   ProofRun r(cfg.protocol_variant);
   r.tables = tables;
   r.n_tables = n_tables;

@@ -345,6 +345,8 @@ class Context {
   lmn_stream_t stream2_{};
   lmn_event_t ev_fork_{}, ev_join_{};
   bool have_stream2_ = false;
+  int fri_overlap_mode_ = 0;          // 0 never, 1 always, 2 while this is the process's only proof in flight
+  bool second_stream_wanted();
   lmn_event_t wait_before_level_ev_{};
   int wait_before_level_ = -1;    // build_merkle_levels: make stream_ wait for wait_before_level_ev_ before this level
   bool merkle_cut_ = false;       // inside prove() of an unsharded proof: trees are stored without their register levels

@@ -127,6 +127,9 @@ struct HostMarks {
 };
 
 
+// proofs between entry and exit of Context::prove in this process (context.cpp)
+extern std::atomic<int> g_proofs_in_flight;
+
 // single-proof sharding transport (shard.cpp)
 void rccl_release(void* transport);
 void rccl_unique_id(uint8_t* out);
