@@ -144,7 +144,28 @@ void* Context::pin_alloc(size_t bytes) {
   pin_off_ = a + bytes;
   return pin_base_ + a;
 }
+void Context::stage_group_begin(size_t reserve_bytes) {
+  if (grp_pin_) throw LmnError(LMN_ERR_INTERNAL, "upload group already open");
+  grp_pin_ = (char*)pin_alloc(reserve_bytes);
+  grp_dev_ = (char*)arena_.alloc_bytes(reserve_bytes);
+  grp_cap_ = reserve_bytes;
+  grp_off_ = 0;
+}
+void Context::stage_group_end() {
+  if (!grp_pin_) return;
+  if (grp_off_) lmn_h2d(grp_dev_, grp_pin_, grp_off_, stream_);
+  grp_pin_ = grp_dev_ = nullptr;
+  grp_cap_ = grp_off_ = 0;
+}
 void* Context::stage_upload(const void* host, size_t bytes) {
+  if (grp_pin_ && bytes) {
+    const size_t at = (grp_off_ + 63) & ~(size_t)63;
+    if (at + bytes <= grp_cap_) {
+      memcpy(grp_pin_ + at, host, bytes);
+      grp_off_ = at + bytes;
+      return grp_dev_ + at;
+    }
+  }
   void* d = arena_.alloc_bytes(bytes ? bytes : 4);
   if (bytes == 0) return d;
   void* p = pin_alloc(bytes);

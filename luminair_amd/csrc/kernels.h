@@ -105,8 +105,9 @@ struct ChanElemSets {
   int set[CHAN_N_ELEMS];
 };
 // mix_root(root); then one draw_felts(2) per entry of set_of_draw (a negative entry draws and discards)
-void launch_chan_root_elems(DevChannel* ch, const uint32_t* root, const uint32_t* bad_word, const int* set_of_draw,
-                            int n_draws, DevReport* rep, lmn_stream_t s);
+// (`start`: the channel's state at this point, written to *ch first - a launch argument instead of an upload)
+void launch_chan_root_elems(DevChannel* ch, const DevChannel& start, const uint32_t* root, const uint32_t* bad_word,
+                            const int* set_of_draw, int n_draws, DevReport* rep, lmn_stream_t s);
 // mix_felts([claimed_i]) per component, mix_root(root), draw_felt() = the composition randomness alpha; then the
 // coefficient of every kernel constraint slot of every component: sign * alpha^(n_total - 1 - (k0 + proto_index)), 0 for a
 // slot the protocol lacks (Context's constraint_layout) - 16 per component at coeff_out + 16 * i
@@ -128,8 +129,9 @@ struct ChanOodsPlan {
   int n_points, n_maps;
   uint32_t step_x[CHAN_MAX_POINTS], step_y[CHAN_MAX_POINTS];
 };
+// (`rep_host`: page-locked memory the finished report is copied to by the kernel itself - no download behind it)
 void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep,
-                           QM31* maps_out /* n_points x n_maps */, lmn_stream_t s);
+                           QM31* maps_out /* n_points x n_maps */, DevReport* rep_host, lmn_stream_t s);
 
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.

@@ -616,10 +616,11 @@ LMN_D void chan_draw_base_felts(DevChannel* ch, uint32_t f[8]) {
   }
 }
 
-LMN_KERNEL k_chan_root_elems(DevChannel* ch, const uint32_t* __restrict__ root, const uint32_t* __restrict__ bad_word,
-                             ChanElemSets sets, DevReport* rep) {
+LMN_KERNEL k_chan_root_elems(DevChannel* ch, DevChannel start, const uint32_t* __restrict__ root,
+                             const uint32_t* __restrict__ bad_word, ChanElemSets sets, DevReport* rep) {
   LMN_SERIAL_KERNEL();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  *ch = start;   // the channel's state when the device takes it over travels as a launch argument
   DevElems* out = &rep->elems;
   rep->bad = *bad_word;
   uint32_t r[8];
@@ -635,13 +636,13 @@ LMN_KERNEL k_chan_root_elems(DevChannel* ch, const uint32_t* __restrict__ root, 
     }
   }
 }
-void launch_chan_root_elems(DevChannel* ch, const uint32_t* root, const uint32_t* bad_word, const int* set_of_draw,
-                            int n_draws, DevReport* rep, lmn_stream_t s) {
+void launch_chan_root_elems(DevChannel* ch, const DevChannel& start, const uint32_t* root, const uint32_t* bad_word,
+                            const int* set_of_draw, int n_draws, DevReport* rep, lmn_stream_t s) {
   if (n_draws < 1 || n_draws > CHAN_N_ELEMS) throw LmnError(-100, "chan_root_elems: bad draw count");
   ChanElemSets sets{};
   sets.n = n_draws;
   for (int i = 0; i < n_draws; ++i) sets.set[i] = set_of_draw[i];
-  LMN_LAUNCH(k_chan_root_elems, dim3(1), dim3(64), 0, s, ch, root, bad_word, sets, rep);
+  LMN_LAUNCH(k_chan_root_elems, dim3(1), dim3(64), 0, s, ch, start, root, bad_word, sets, rep);
 }
 
 LMN_KERNEL k_chan_claims_root_alpha(DevChannel* ch, ChanCoeffPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
@@ -690,7 +691,7 @@ void launch_chan_claims_root_alpha(DevChannel* ch, const ChanCoeffPlan& plan, co
 }
 
 LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
-                            QM31* maps_out) {
+                            QM31* maps_out, uint32_t* rep_host) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh_pt[8];
   if (threadIdx.x == 0) {
@@ -725,11 +726,15 @@ LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* _
       mp[k] = cur;
     }
   }
+  // the report is complete: the last of the device-resident steps writes the host's copy itself (page-locked memory;
+  // lane 0's words of this launch are visible to the block since the barrier above)
+  const uint32_t* rw = reinterpret_cast<const uint32_t*>(rep);
+  for (uint32_t k = threadIdx.x; k < (uint32_t)(sizeof(DevReport) / 4); k += blockDim.x) rep_host[k] = rw[k];
 }
 void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep, QM31* maps_out,
-                           lmn_stream_t s) {
+                           DevReport* rep_host, lmn_stream_t s) {
   if (plan.n_points < 1 || plan.n_points > CHAN_MAX_POINTS || plan.n_maps < 2) throw LmnError(-100, "chan_root_oods: bad plan");
-  LMN_LAUNCH(k_chan_root_oods, dim3(1), dim3(64), 0, s, ch, plan, root, rep, maps_out);
+  LMN_LAUNCH(k_chan_root_oods, dim3(1), dim3(64), 0, s, ch, plan, root, rep, maps_out, reinterpret_cast<uint32_t*>(rep_host));
 }
 
 // =============================================================================================

@@ -33,12 +33,13 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
   split = split && shard_.active && shard_.world > 1;
   const uint32_t W = split ? shard_.world : 1u, R = split ? shard_.rank : 0u;
   const size_t nj = jobs.size();
-  QM31* d_out = (QM31*)arena_.alloc_bytes((size_t)W * nj * sizeof(QM31));   // slot r: rank r's partial sums
+  // slot r: rank r's partial sums.  An unsharded proof's reduce kernel writes the values straight to page-locked memory
+  QM31* d_out = split ? (QM31*)arena_.alloc_bytes((size_t)W * nj * sizeof(QM31)) : (QM31*)result_block(nj * sizeof(QM31));
   launch_eval_tables(d_maps, nmaps, np, d_lo, d_hi, hi_n, hi_bits, stream_);
   launch_eval_at_point(d_jobs, (int)nj, d_lo, d_hi, hi_n, max_log, d_part, max_chunks, stream_, R, W);
   launch_eval_reduce(d_jobs, (int)nj, d_part, max_chunks, d_out + (size_t)R * nj, stream_);
   if (split) gather_columns((uint32_t*)d_out, 0, 1, nj * 4);
-  const QM31* res = (const QM31*)stage_download(d_out, (size_t)W * nj * sizeof(QM31));
+  const QM31* res = split ? (const QM31*)stage_download(d_out, (size_t)W * nj * sizeof(QM31)) : d_out;
   lmn_sync(stream_);
   std::vector<QM31> out(res, res + nj);
   for (uint32_t r = 1; r < W; ++r)

@@ -110,12 +110,13 @@ void Context::run_decommit(ProofRun& r) {
       if (!hs.jobs.empty() && sh) throw LmnError(LMN_ERR_INTERNAL, "sharded proofs keep whole trees");
       MerkleRecompute* d_j = (MerkleRecompute*)pin_alloc((hs.jobs.size() + 1) * sizeof(MerkleRecompute));
       memcpy(d_j, hs.jobs.data(), hs.jobs.size() * sizeof(MerkleRecompute));
-      uint32_t* d_o = arena_.alloc_words((size_t)slots * out_words);
+      // an unsharded proof's gather writes straight to page-locked memory: nothing to download behind it
+      uint32_t* d_o = sh ? arena_.alloc_words((size_t)slots * out_words) : (uint32_t*)result_block((size_t)out_words * 4);
       hm.mark("decommit planned");
       if (hm.on) fprintf(stderr, "[host] decommit: %zu runs gathered, %zu tree nodes recomputed\n", entries.size(), hs.jobs.size());
       launch_gather(arena_.base_words(), d_e, (uint32_t)entries.size(), d_j, (uint32_t)hs.jobs.size(), d_o, stream_);
       if (sh) gather_columns(d_o, 0, 1, out_words);
-      gathered = (const uint32_t*)stage_download(d_o, (size_t)slots * out_words * 4);
+      gathered = sh ? (const uint32_t*)stage_download(d_o, (size_t)slots * out_words * 4) : d_o;
       lmn_sync(stream_);
       if (sh) {
         merged.resize(out_words);

@@ -5,6 +5,55 @@
 
 namespace lmn {
 
+// Called by run_quotients inside its upload group, after the quotient columns have their sizes (r.quots).
+void Context::plan_fri_buffers(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  ProofRun::FriPlan& fp = r.fri;
+  const int ls0 = quots[0].log;
+  fp.last_size_log = std::min((int)cfg.log_last_layer + lb, ls0 - 1);   // (a trace smaller than the configured last layer stops at its first line)
+  fp.max_layers = ls0 + 1;
+  const size_t root_words = (size_t)fp.max_layers * 8, alpha_words = (size_t)fp.max_layers * 4;
+  const size_t last_words = 4ull << fp.last_size_log;
+  fp.d_out = arena_.alloc_words(root_words + alpha_words + last_words);
+  fp.d_roots = fp.d_out;
+  fp.d_alphas = (QM31*)(fp.d_out + root_words);
+  fp.d_last = fp.d_out + root_words + alpha_words;
+  fp.out_bytes = (root_words + alpha_words + last_words) * 4;
+  DevChannel hc{};
+  memcpy(hc.digest, channel.digest().w, 32);   // nothing is mixed between the draw of the quotient randomness and the first layer's root
+  hc.n_sent = 0;
+  hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
+  fp.d_chan = (DevChannel*)stage_upload(&hc, sizeof hc);
+  fp.tail_log = -1;
+  if (sh) return;
+  // unsharded: the layers from min(2^10, the size at which the last quotient column has joined) down are one launch
+  const int tail_log = std::min(std::min(10, ls0 - 1), quots.back().log - 1);
+  if (tail_log <= fp.last_size_log) return;
+  const int n_tail = tail_log - fp.last_size_log;
+  fp.tail_log = tail_log;
+  fp.tail_first = tail_log == fp.last_size_log ? fp.d_last : arena_.alloc_words(4ull << tail_log);
+  std::vector<FriTailLayer> tl(n_tail);
+  uint32_t* layer = fp.tail_first;
+  for (int li = 0; li < n_tail; ++li) {
+    const int L = tail_log - li;
+    FriLayer fl;
+    fl.log = L;
+    fl.vals = layer;
+    fl.sharded = false;
+    fl.merkle.max_log = L;
+    fl.merkle.layers.assign(L + 1, nullptr);
+    for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
+    uint32_t* next = L - 1 == fp.last_size_log ? fp.d_last : arena_.alloc_words(4ull << (L - 1));
+    tl[li].vals = layer;
+    tl[li].next = next;
+    tl[li].itw = itwX_[L + 1];
+    for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
+    fp.tail_layers.push_back(fl);
+    layer = next;
+  }
+  fp.d_tail = upload_vec(tl);
+}
+
 void Context::run_fri_commit(ProofRun& r) {
   LMN_RUN_ALIASES(r);
   // ---- FRI commit
@@ -16,15 +65,11 @@ void Context::run_fri_commit(ProofRun& r) {
     // The FRI commit loop runs without host round trips: a device-resident copy of the channel
     // mixes each layer root and draws the folding alpha; the host replays the same steps afterwards.
     int ls0 = quots[0].log;
+    ProofRun::FriPlan& fp = r.fri;   // buffers and tables: plan_fri_buffers (uploaded with the quotient phase's tables)
     const int last_size_log = (int)cfg.log_last_layer + lb;
-    const int max_layers = ls0 + 1;
-    DevChannel hc{};
-    memcpy(hc.digest, channel.digest().w, 32);
-    hc.n_sent = 0;
-    hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
-    DevChannel* d_ch = (DevChannel*)stage_upload(&hc, sizeof hc);
-    QM31* d_alphas = (QM31*)arena_.alloc_bytes((size_t)max_layers * sizeof(QM31));
-    uint32_t* d_roots = arena_.alloc_words((size_t)max_layers * 8);
+    DevChannel* d_ch = fp.d_chan;
+    QM31* d_alphas = fp.d_alphas;
+    uint32_t* d_roots = fp.d_roots;
     int n_roots = 0;
     build_merkle(first_merkle, first_cols, d_ch, d_alphas + n_roots, d_roots + 8 * n_roots, sharded_log(ls0));
     ++n_roots;
@@ -50,7 +95,12 @@ void Context::run_fri_commit(ProofRun& r) {
       else
         launch_fold_line(d, src, src_len, itw + off, alpha, stream_, dstride);
     };
-    auto layer_alloc = [&](int lg, bool s) { return arena_.alloc_words(s ? (4ull << (lg - g)) : (4ull << lg)); };
+    // the tail's first layer and the last layer have their places already (FriPlan)
+    auto layer_alloc = [&](int lg, bool s) {
+      if (!s && lg == fp.last_size_log) return fp.d_last;
+      if (!s && lg == fp.tail_log) return fp.tail_first;
+      return arena_.alloc_words(s ? (4ull << (lg - g)) : (4ull << lg));
+    };
     int layer_log = ls0 - 1;
     bool lay_sh = sharded_log(layer_log);
     uint32_t* layer = layer_alloc(layer_log, lay_sh);
@@ -84,25 +134,32 @@ void Context::run_fri_commit(ProofRun& r) {
       if (!lay_sh && layer_log <= 10 && qi == quots.size()) {
         // all remaining layers fit one block: commit + fold them in a single launch
         int n_tail = layer_log - last_size_log;
-        std::vector<FriTailLayer> tl(n_tail);
-        for (int li = 0; li < n_tail; ++li) {
-          int L = layer_log - li;
-          FriLayer fl;
-          fl.log = L;
-          fl.vals = layer;
-          fl.sharded = false;
-          fl.merkle.max_log = L;
-          fl.merkle.layers.assign(L + 1, nullptr);
-          for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
-          uint32_t* next = arena_.alloc_words(4ull << (L - 1));
-          tl[li].vals = layer;
-          tl[li].next = next;
-          tl[li].itw = itwX_[L + 1];
-          for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
-          inner.push_back(fl);
-          layer = next;
+        FriTailLayer* d_tl = fp.d_tail;
+        if (layer_log == fp.tail_log && layer == fp.tail_first) {
+          for (auto& fl : fp.tail_layers) inner.push_back(fl);
+          layer = fp.d_last;
+        } else {
+          // sharded proofs (the replicated part starts where the shard plan says)
+          std::vector<FriTailLayer> tl(n_tail);
+          for (int li = 0; li < n_tail; ++li) {
+            int L = layer_log - li;
+            FriLayer fl;
+            fl.log = L;
+            fl.vals = layer;
+            fl.sharded = false;
+            fl.merkle.max_log = L;
+            fl.merkle.layers.assign(L + 1, nullptr);
+            for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
+            uint32_t* next = layer_alloc(L - 1, false);
+            tl[li].vals = layer;
+            tl[li].next = next;
+            tl[li].itw = itwX_[L + 1];
+            for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
+            inner.push_back(fl);
+            layer = next;
+          }
+          d_tl = upload_vec(tl);
         }
-        FriTailLayer* d_tl = upload_vec(tl);
         {
           StageTimer t(this, log, stream_, C_MERKLE);
           launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
@@ -156,11 +213,15 @@ void Context::run_fri_commit(ProofRun& r) {
     materialise(layer);  // a last layer larger than the fused threshold (log_last_layer > 9) is still pending
     hm.mark("fri enqueued");
     // one sync: roots + alphas back, then replay the transcript on the host channel
-    const uint32_t* h_roots = (const uint32_t*)stage_download(d_roots, (size_t)n_roots * 32);
-    const QM31* h_alphas = (const QM31*)stage_download(d_alphas, (size_t)n_roots * sizeof(QM31));
     if (qi != quots.size()) throw LmnError(LMN_ERR_INTERNAL, "FRI: unconsumed columns");
+    if (n_roots > fp.max_layers || layer_log != fp.last_size_log || layer != fp.d_last)
+      throw LmnError(LMN_ERR_INTERNAL, "FRI: the layer plan does not match the layers committed");
     last_log = layer_log;
-    const uint32_t* raw = (const uint32_t*)stage_download(layer, (size_t)16 << last_log);
+    // roots | alphas | last layer: one block, one download
+    const uint32_t* h_out = (const uint32_t*)stage_download(fp.d_out, fp.out_bytes);
+    const uint32_t* h_roots = h_out;
+    const QM31* h_alphas = (const QM31*)(h_out + ((const uint32_t*)fp.d_alphas - fp.d_out));
+    const uint32_t* raw = h_out + (fp.d_last - fp.d_out);
     lmn_sync(stream_);
     {
       uint32_t n = 1u << last_log;

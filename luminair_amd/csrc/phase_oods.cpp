@@ -60,7 +60,8 @@ void Context::run_oods(ProofRun& r) {
   };
   if (r.dev_fs) {
     // the device draws the point and expands the mappings (k_chan_root_oods); everything the device-resident steps
-    // produced comes back in one download, valid after the wait inside eval_at_points below
+    // produced comes back in one block the last of them writes to page-locked memory, valid after the wait inside
+    // eval_at_points below
     if (neg_step.size() > (size_t)CHAN_MAX_POINTS) throw LmnError(LMN_ERR_INTERNAL, "more sample points than the device transcript plans for");
     ChanOodsPlan plan{};
     plan.n_points = (int)neg_step.size();
@@ -70,8 +71,9 @@ void Context::run_oods(ProofRun& r) {
       plan.step_y[p] = neg_step[p].y;
     }
     r.d_maps = (QM31*)arena_.alloc_bytes((size_t)plan.n_points * plan.n_maps * sizeof(QM31));
-    launch_chan_root_oods(r.d_chan, plan, tree3.merkle.layers[0], r.d_report, r.d_maps, stream_);
-    r.h_report = (const DevReport*)stage_download(r.d_report, sizeof(DevReport));
+    DevReport* h_rep = (DevReport*)result_block(sizeof(DevReport));
+    launch_chan_root_oods(r.d_chan, plan, tree3.merkle.layers[0], r.d_report, r.d_maps, h_rep, stream_);
+    r.h_report = h_rep;
   } else {
     set_points(channel.draw_felt());
   }
@@ -147,16 +149,21 @@ void Context::run_quotients(ProofRun& r) {
   sizes.assign(size_set.begin(), size_set.end());
   {
     StageTimer st(this, log, stream_, C_QUOT);
+    // Everything this phase and the FRI commit loop read from tables on the device - the sample entries of each LDE size,
+    // the channel's start state, the tail's layer table - goes up in ONE transfer ahead of the first quotient kernel
+    // (each transfer is a blit launch of ~5 us in the proof's one stream)
+    size_t n_samples = 0;
+    for (auto& f : flat) n_samples += f.samples.size();
+    stage_group_begin(n_samples * sizeof(QuotEntry) + 64 * sizes.size() + 4096);
+    std::vector<QuotientArgs> qargs;
     for (int ls : sizes) {
-      std::vector<const FlatCol*> cols;
-      for (auto& f : flat)
-        if (f.lde_log == ls) cols.push_back(&f);
       std::vector<const uint32_t*> ptrs;
       std::vector<std::vector<std::pair<int, QM31>>> smp;
-      for (auto* c : cols) {
-        ptrs.push_back(c->lde);
-        smp.push_back(c->samples);
-      }
+      for (auto& f : flat)
+        if (f.lde_log == ls) {
+          ptrs.push_back(f.lde);
+          smp.push_back(f.samples);
+        }
       QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha, !sh);
       uint32_t* vals = a.out;
       const bool qs = sharded_log(ls);
@@ -174,11 +181,20 @@ void Context::run_quotients(ProofRun& r) {
           a.out_stride = L;
         }
       }
-      // unsharded proofs with two LDE sizes: the second (smaller) size is computed on the second stream, next to the
-      // leaf hashing of the first size's quotient columns; build_merkle_levels waits for it before level `ls`
+      qargs.push_back(a);
+      quots.push_back({ls, vals, qs});
+    }
+    plan_fri_buffers(r);
+    stage_group_end();
+    hm.mark("quotient + FRI tables uploaded");
+    for (size_t k = 0; k < sizes.size(); ++k) {
+      const int ls = sizes[k];
+      const QuotientArgs& a = qargs[k];
+      // LMN_FRI_OVERLAP (experiment): unsharded proofs with two LDE sizes compute the second (smaller) size on the second
+      // stream, next to the leaf hashing of the first size's quotient columns; build_merkle_levels waits for it before level `ls`
       const bool overlap = !sh && sizes.size() == 2 && ls == sizes[1] && second_stream_wanted();
       if (overlap) {
-        lmn_event_record(ev_fork_, stream_);            // everything enqueued so far (incl. the entry-table upload)
+        lmn_event_record(ev_fork_, stream_);            // everything enqueued so far (incl. the table upload)
         lmn_stream_wait_event(stream2_, ev_fork_);
         launch_quotients(a, stream2_);
         lmn_event_record(ev_join_, stream2_);
@@ -187,8 +203,7 @@ void Context::run_quotients(ProofRun& r) {
       } else {
         launch_quotients(a, stream_);
       }
-      if (sh && !qs) gather_columns(vals, L, 4, Lb);
-      quots.push_back({ls, vals, qs});
+      if (sh && !quots[k].sharded) gather_columns(quots[k].vals, 1ull << ls, 4, (1ull << ls) >> g);
     }
   }
 

@@ -143,11 +143,11 @@ void Context::run_main_trace(ProofRun& r) {
       memcpy(hc.digest, channel.digest().w, 32);
       hc.n_sent = 0;
       hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;
-      r.d_chan = (DevChannel*)stage_upload(&hc, sizeof hc);
+      r.d_chan = (DevChannel*)arena_.alloc_bytes(sizeof(DevChannel));
       r.d_report = (DevReport*)arena_.alloc_bytes(sizeof(DevReport));
       int sets[CHAN_N_ELEMS];
       const int n_draws = relation_draw_sets(cfg.protocol_variant, sets);
-      launch_chan_root_elems(r.d_chan, tree1.merkle.layers[0], d_bad, sets, n_draws, r.d_report, stream_);
+      launch_chan_root_elems(r.d_chan, hc, tree1.merkle.layers[0], d_bad, sets, n_draws, r.d_report, stream_);
       for (int i = 0; i < n_draws; ++i)
         if (sets[i] >= 0) elems.drawn[sets[i]] = true;
       hm.mark("main trace enqueued (device transcript)");

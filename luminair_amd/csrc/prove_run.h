@@ -73,6 +73,23 @@ struct ProofRun {
   DevMerkle first_merkle;
   std::vector<ColRef> first_cols;
   std::vector<FriLayer> inner;
+  // What the FRI commit loop reads from and leaves on the device, laid out before the quotient kernels are launched
+  // (plan_fri_buffers) so that its tables travel in the quotient phase's one upload and its results come back in one
+  // download: roots | alphas | last layer in one block; the device channel's start state; for unsharded proofs the
+  // layers of the single-block tail (k_fri_tail) with their trees and the table that names them.
+  struct FriPlan {
+    int max_layers = 0, last_size_log = 0;
+    uint32_t* d_out = nullptr;      // max_layers x 8 root words | max_layers x QM31 alphas | 4 x 2^last_size_log last layer
+    uint32_t* d_roots = nullptr;
+    QM31* d_alphas = nullptr;
+    uint32_t* d_last = nullptr;
+    size_t out_bytes = 0;
+    DevChannel* d_chan = nullptr;
+    int tail_log = -1;              // first layer of the tail (-1: none planned)
+    uint32_t* tail_first = nullptr; // that layer's values
+    std::vector<FriLayer> tail_layers;
+    FriTailLayer* d_tail = nullptr;
+  } fri;
   std::vector<QM31> last_vals;
   int last_log = 0;
   std::vector<uint32_t> queries;

@@ -301,6 +301,7 @@ class Context {
   // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
   void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
+  void plan_fri_buffers(struct ProofRun& r);   // phase_fri.cpp
   QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                   const std::vector<std::vector<std::pair<int, QM31>>>& samples,
                                   const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);
@@ -316,6 +317,15 @@ class Context {
   void reset_event_log();
   void* pin_alloc(size_t bytes);
   void* stage_upload(const void* host, size_t bytes);           // -> device pointer (arena), async
+  // Several small uploads as ONE transfer: between stage_group_begin and stage_group_end, stage_upload places its data
+  // in a block reserved up front (same offsets on both sides) and nothing is transferred until the group ends.  What
+  // does not fit the reservation is uploaded on its own as before.
+  void stage_group_begin(size_t reserve_bytes);
+  void stage_group_end();
+  // a page-locked block that kernels write their (small) results into directly: no transfer behind the kernel, valid
+  // after the next wait.  Unsharded proofs; the pointer is a device pointer as well (gather's entry table already
+  // relies on that)
+  void* result_block(size_t bytes) { return pin_alloc(bytes ? bytes : 4); }
   const void* stage_download(const void* dev, size_t bytes);    // -> pinned host pointer, valid after sync
   template <class T>
   T* upload_vec(const std::vector<T>& v) {
@@ -326,6 +336,8 @@ class Context {
   uint32_t bad_epoch_ = 1;        // the mark of the current unsharded proof (see Context::prove)
   char* pin_base_ = nullptr;
   size_t pin_cap_ = 0, pin_off_ = 0;
+  char *grp_pin_ = nullptr, *grp_dev_ = nullptr;   // open upload group (stage_group_begin)
+  size_t grp_cap_ = 0, grp_off_ = 0;
 
   struct Shard {
     bool active = false;
