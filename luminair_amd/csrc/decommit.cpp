@@ -75,6 +75,7 @@ void plan_merkle_decommit(const DevMerkle& m, const std::vector<ColRef>& cols_so
 
 std::vector<uint32_t> fold_positions(const std::vector<uint32_t>& p, int n) {
   std::vector<uint32_t> out;
+  out.reserve(p.size());
   for (auto v : p) {
     uint32_t q = v >> n;
     if (out.empty() || out.back() != q) out.push_back(q);
@@ -85,14 +86,16 @@ std::vector<uint32_t> fold_positions(const std::vector<uint32_t>& p, int n) {
 // compute_decommitment_positions_and_witness_evals with fold_step = 1; `cols` = the 4 coordinate columns
 void plan_fri_witness(const ColRef (&cols)[4], int g, const std::vector<uint32_t>& qpos,
                              std::vector<uint32_t>& dec_pos, std::vector<Ref>& wit) {
+  // (planning runs between the proof's last two waits: no allocation per pair)
+  dec_pos.reserve(dec_pos.size() + 2 * qpos.size());
   size_t i = 0;
   while (i < qpos.size()) {
-    uint32_t start = (qpos[i] >> 1) << 1;
-    std::vector<uint32_t> subset;
-    while (i < qpos.size() && ((qpos[i] >> 1) << 1) == start) subset.push_back(qpos[i++]);
+    const uint32_t start = (qpos[i] >> 1) << 1;
+    bool have[2] = {false, false};   // which of the pair's two positions are queried (sorted, distinct positions)
+    while (i < qpos.size() && ((qpos[i] >> 1) << 1) == start) have[qpos[i++] - start] = true;
     for (uint32_t pos = start; pos < start + 2; ++pos) {
       dec_pos.push_back(pos);
-      if (std::find(subset.begin(), subset.end(), pos) != subset.end()) continue;
+      if (have[pos - start]) continue;
       for (int k = 0; k < 4; ++k) wit.push_back(col_ref(cols[k], pos, g));
     }
   }

@@ -261,41 +261,58 @@ struct Proof {
 };
 
 // bincode 1.3: little-endian, u64 lengths, Option = 1 tag byte
+// (the host is little-endian like the format: words and arrays of words are appended as they lie in memory - this runs
+// behind the proof's last wait, i.e. on its latency)
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "BinWriter appends host words as little-endian bytes");
+static_assert(sizeof(QM31) == 16 && sizeof(Hash32) == 32, "QM31 / Hash32 arrays are appended as they lie in memory");
 class BinWriter {
  public:
   std::vector<uint8_t> buf;
+  void raw(const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    buf.insert(buf.end(), b, b + n);
+  }
   void u8(uint8_t v) { buf.push_back(v); }
-  void u32(uint32_t v) {
-    for (int i = 0; i < 4; ++i) buf.push_back((uint8_t)(v >> (8 * i)));
+  void u32(uint32_t v) { raw(&v, 4); }
+  void u64(uint64_t v) { raw(&v, 8); }
+  void q(const QM31& f) { raw(&f, 16); }
+  void hash(const Hash32& h) { raw(h.w, 32); }
+  void qs(const std::vector<QM31>& v) {
+    u64(v.size());
+    raw(v.data(), v.size() * 16);
   }
-  void u64(uint64_t v) {
-    for (int i = 0; i < 8; ++i) buf.push_back((uint8_t)(v >> (8 * i)));
-  }
-  void q(const QM31& f) {
-    u32(f.a);
-    u32(f.b);
-    u32(f.c);
-    u32(f.d);
-  }
-  void hash(const Hash32& h) {
-    for (int i = 0; i < 8; ++i) u32(h.w[i]);
+  void words(const std::vector<uint32_t>& v) {
+    u64(v.size());
+    raw(v.data(), v.size() * 4);
   }
   void decommit(const Decommitment& d) {
     u64(d.hash_witness.size());
-    for (auto& h : d.hash_witness) hash(h);
-    u64(d.column_witness.size());
-    for (auto v : d.column_witness) u32(v);
+    raw(d.hash_witness.data(), d.hash_witness.size() * 32);
+    words(d.column_witness);
   }
   void layer(const FriLayerProof& l) {
-    u64(l.fri_witness.size());
-    for (auto& f : l.fri_witness) q(f);
+    qs(l.fri_witness);
     decommit(l.decommitment);
     hash(l.commitment);
   }
+  static size_t bytes_of(const Decommitment& d) { return 16 + d.hash_witness.size() * 32 + d.column_witness.size() * 4; }
+  static size_t bytes_of(const FriLayerProof& l) { return 8 + l.fri_witness.size() * 16 + bytes_of(l.decommitment) + 32; }
 };
 
 inline std::vector<uint8_t> proof_to_bincode(const Proof& p) {
   BinWriter w;
+  {
+    size_t n = 256 + 17 * (p.claim.size() + p.interaction_claim.size()) + 32 * p.commitments.size() + 16 * p.last_layer_coeffs.size();
+    for (auto& t : p.sampled_values) {
+      n += 8;
+      for (auto& col : t) n += 8 + 16 * col.size();
+    }
+    for (auto& d : p.decommitments) n += BinWriter::bytes_of(d);
+    for (auto& t : p.queried_values) n += 8 + 4 * t.size();
+    n += BinWriter::bytes_of(p.first_layer);
+    for (auto& l : p.inner_layers) n += BinWriter::bytes_of(l);
+    w.buf.reserve(n);
+  }
   for (int c : p.claim) {
     if (c < 0) {
       w.u8(0);
@@ -321,24 +338,17 @@ inline std::vector<uint8_t> proof_to_bincode(const Proof& p) {
   w.u64(p.sampled_values.size());
   for (auto& t : p.sampled_values) {
     w.u64(t.size());
-    for (auto& col : t) {
-      w.u64(col.size());
-      for (auto& v : col) w.q(v);
-    }
+    for (auto& col : t) w.qs(col);
   }
   w.u64(p.decommitments.size());
   for (auto& d : p.decommitments) w.decommit(d);
   w.u64(p.queried_values.size());
-  for (auto& t : p.queried_values) {
-    w.u64(t.size());
-    for (auto v : t) w.u32(v);
-  }
+  for (auto& t : p.queried_values) w.words(t);
   w.u64(p.proof_of_work);
   w.layer(p.first_layer);
   w.u64(p.inner_layers.size());
   for (auto& l : p.inner_layers) w.layer(l);
-  w.u64(p.last_layer_coeffs.size());
-  for (auto& c : p.last_layer_coeffs) w.q(c);
+  w.qs(p.last_layer_coeffs);
   w.u32(p.last_layer_log_size);
   return std::move(w.buf);
 }

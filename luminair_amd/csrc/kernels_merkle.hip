@@ -453,15 +453,18 @@ LMN_D void chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_al
 // threads of the block (block-uniform control flow); the hashing runs on the first quad with the
 // quad-cooperative Blake2s (0.9 us per hash instead of 2 us).  `scratch`: 28 words of LDS that do not
 // overlap the root's 8 words.  Ends with a barrier and returns the drawn alpha to every thread.
-LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32_t root_stride, uint32_t* scratch,
-                                    QM31* out_alpha, uint32_t* root_copy) {
+// `dg` (lanes 0..7: word `lane` of the channel's digest) and `variant` are loaded by the caller - at its start, so that
+// the round trip to memory is hidden behind its hashing; `dg` is updated (a kernel that makes several steps never
+// reads the channel back), and the channel in memory as well (for the next launch).
+LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, uint32_t& dg, uint32_t variant, const uint32_t* root,
+                                    uint32_t root_stride, uint32_t* scratch, QM31* out_alpha, uint32_t* root_copy) {
   uint32_t* msg = scratch;       // 16 words: digest || root, then digest || counter
   uint32_t* wbuf = scratch + 16;  // 8 words: drawn words
   const uint32_t tid = threadIdx.x, q = tid & 3u;
-  const uint32_t t_draw = ch->variant == 0u ? 64u : 37u;
+  const uint32_t t_draw = variant == 0u ? 64u : 37u;
   __syncthreads();
   if (tid < 8u) {
-    msg[tid] = ch->digest[tid];
+    msg[tid] = dg;
     const uint32_t r = root[tid * root_stride];   // word k of the root at root[k * root_stride] (word-major node array)
     msg[8u + tid] = r;
     root_copy[tid] = r;
@@ -506,6 +509,7 @@ LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, const uint32_t* root, uint32
     }
     __syncthreads();  // everyone has read wbuf before the next draw overwrites it
   }
+  if (tid < 8u) dg = msg[tid];   // the digest after the mix (the draws leave it alone)
   __syncthreads();
   return QM31{scratch[24], scratch[25], scratch[26], scratch[27]};
 }
@@ -518,6 +522,13 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   const uint32_t i = threadIdx.x;
+  // when this launch produces the root, it also runs the device-resident Fiat-Shamir step: fetch the channel now
+  const bool fs = ch != nullptr && (size >> nfused) == 1u;
+  uint32_t dg = 0u, variant = 0u;
+  if (fs) {
+    if (i < 8u) dg = ch->digest[i];
+    variant = ch->variant;
+  }
   uint32_t cur[8];
   if (i < size) {
     uint32_t m[16];
@@ -529,9 +540,7 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   }
   LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
   merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
-  // when this launch produced the root, it can also run the device-resident Fiat-Shamir step
-  if (ch != nullptr && (size >> nfused) == 1u)
-    chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
+  if (fs) chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
 }
 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
@@ -746,7 +755,18 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
                       QM31* alphas_out, uint32_t* roots_out) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  LMN_SHARED uint32_t shv[MERKLE_SMALL_BLOCK * 4];   // the layer's values, coordinate-major: the fold reads its pair here
   const uint32_t i = threadIdx.x;
+  // the channel is read once and the layers' values once: a lane keeps value i of the current layer (its fold output is
+  // the next layer's value i), so that no step of the chain waits for memory
+  uint32_t dg = i < 8u ? ch->digest[i] : 0u;
+  const uint32_t variant = ch->variant;
+  QM31 mine = q_zero();
+  {
+    const uint32_t* v0 = layers[0].vals;
+    const uint32_t size0 = 1u << first_log;
+    if (i < size0) mine = QM31{v0[i], v0[size0 + i], v0[2 * size0 + i], v0[3 * size0 + i]};
+  }
   for (int li = 0; li < n_layers; ++li) {
     const FriTailLayer ly = layers[li];
     const int L = first_log - li;
@@ -756,22 +776,28 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
       uint32_t m[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) m[k] = 0u;
-      m[0] = ly.vals[i];
-      m[1] = ly.vals[size + i];
-      m[2] = ly.vals[2 * size + i];
-      m[3] = ly.vals[3 * size + i];
+      m[0] = mine.a;
+      m[1] = mine.b;
+      m[2] = mine.c;
+      m[3] = mine.d;
+      shv[i] = mine.a;
+      shv[MERKLE_SMALL_BLOCK + i] = mine.b;
+      shv[2 * MERKLE_SMALL_BLOCK + i] = mine.c;
+      shv[3 * MERKLE_SMALL_BLOCK + i] = mine.d;
       b2_compress_fresh(cur, m, 16u);
       store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
 #pragma unroll
       for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
     }
     for (int l = L - 1; l >= 0; --l) merkle_lds_level<MERKLE_SMALL_BLOCK>(sh, ly.merkle[l], 0u, 1u << l);
-    const QM31 alpha = chan_mix_root_draw_block(ch, sh, MERKLE_SMALL_BLOCK, sh + 16, &alphas_out[li], roots_out + li * 8);
+    const QM31 alpha = chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, &alphas_out[li],
+                                                roots_out + li * 8);
     const uint32_t n = size >> 1;
     if (i < n) {
-      QM31 a{ly.vals[2 * i], ly.vals[size + 2 * i], ly.vals[2 * size + 2 * i], ly.vals[3 * size + 2 * i]};
-      QM31 b{ly.vals[2 * i + 1], ly.vals[size + 2 * i + 1], ly.vals[2 * size + 2 * i + 1],
-             ly.vals[3 * size + 2 * i + 1]};
+      const QM31 a{shv[2 * i], shv[MERKLE_SMALL_BLOCK + 2 * i], shv[2 * MERKLE_SMALL_BLOCK + 2 * i],
+                   shv[3 * MERKLE_SMALL_BLOCK + 2 * i]};
+      const QM31 b{shv[2 * i + 1], shv[MERKLE_SMALL_BLOCK + 2 * i + 1], shv[2 * MERKLE_SMALL_BLOCK + 2 * i + 1],
+                   shv[3 * MERKLE_SMALL_BLOCK + 2 * i + 1]};
       QM31 f0 = q_add(a, b);
       QM31 f1 = q_mul_m(q_sub(a, b), ly.itw[i]);
       QM31 r = q_add(f0, q_mul(alpha, f1));
@@ -779,6 +805,7 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
       ly.next[n + i] = r.b;
       ly.next[2 * n + i] = r.c;
       ly.next[3 * n + i] = r.d;
+      mine = r;
     }
     __syncthreads();
   }

@@ -118,6 +118,7 @@ void Context::run_decommit(ProofRun& r) {
       if (sh) gather_columns(d_o, 0, 1, out_words);
       gathered = sh ? (const uint32_t*)stage_download(d_o, (size_t)slots * out_words * 4) : d_o;
       lmn_sync(stream_);
+      hm.mark("gathered");
       if (sh) {
         merged.resize(out_words);
         uint32_t at = 0;
@@ -130,33 +131,28 @@ void Context::run_decommit(ProofRun& r) {
       }
     }
     size_t g = 0;
+    // (runs behind the proof's last wait: whole runs are copied, not words)
     auto take_q = [&](size_t nrefs) {
-      std::vector<QM31> v;
-      v.reserve(nrefs / 4);
-      for (size_t i = 0; i < nrefs / 4; ++i) {
-        v.push_back({gathered[g], gathered[g + 1], gathered[g + 2], gathered[g + 3]});
-        g += 4;
-      }
-      return v;
+      const QM31* b = reinterpret_cast<const QM31*>(gathered + g);
+      g += nrefs / 4 * 4;
+      return std::vector<QM31>(b, b + nrefs / 4);
     };
     auto take_u32 = [&](size_t n) {
       std::vector<uint32_t> v(gathered + g, gathered + g + n);
       g += n;
       return v;
     };
+    auto skip = [&](size_t n) { g += n; };
     auto take_hashes = [&](size_t n) {
-      std::vector<Hash32> v(n);
-      for (size_t i = 0; i < n; ++i) {
-        memcpy(v[i].w, &gathered[g], 32);
-        g += 8;
-      }
-      return v;
+      const Hash32* b = reinterpret_cast<const Hash32*>(gathered + g);
+      g += 8 * n;
+      return std::vector<Hash32>(b, b + n);
     };
     size_t pi = 0;
     auto fill_layer = [&](FriLayerProof& lp, const Hash32& root) {
       Plan& p = plans[pi++];
       lp.fri_witness = take_q(p.fri_wit.size());
-      take_u32(p.queried.size());
+      skip(p.queried.size());
       lp.decommitment.hash_witness = take_hashes(p.hash_wit.size());
       lp.decommitment.column_witness = take_u32(p.col_wit.size());
       lp.commitment = root;
@@ -166,7 +162,7 @@ void Context::run_decommit(ProofRun& r) {
     for (size_t i = 0; i < inner.size(); ++i) fill_layer(proof.inner_layers[i], inner[i].merkle.root);
     for (int t = 0; t < 4; ++t) {
       Plan& p = plans[pi++];
-      take_q(p.fri_wit.size());
+      skip(p.fri_wit.size());
       proof.queried_values.push_back(take_u32(p.queried.size()));
       Decommitment d;
       d.hash_witness = take_hashes(p.hash_wit.size());

@@ -168,7 +168,9 @@ std::vector<uint8_t> Context::run_finish(ProofRun& r) {
   timings.fft_ms = acc[C_FFT];
   timings.merkle_ms = acc[C_MERKLE];
   timings.merkle_fused_ms = acc[C_MERKLE_FUSED];
-  return proof_to_bincode(proof);
+  std::vector<uint8_t> bytes = proof_to_bincode(proof);
+  hm.mark("serialized");
+  return bytes;
 }
 
 }  // namespace lmn
