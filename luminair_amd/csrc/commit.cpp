@@ -19,8 +19,11 @@ void Context::merkle_layer_timed(const uint32_t* prev, const uint32_t* const* co
 // columns) plus up to 8 following levels that have no columns of their own.
 void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                                   const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch,
-                                  QM31* alpha_out, uint32_t* root_copy, const MerkleFold* fold, std::vector<MerkleCut>* cuts) {
+                                  QM31* alpha_out, uint32_t* root_copy, const MerkleFold* fold, std::vector<MerkleCut>* cuts,
+                                  const ChanStep* step) {
   bool chan_done = false;
+  // LMN_CHAN_STEP_SEPARATE=1 (measurements, tests): a commitment phase's transcript step as a launch of its own behind the tree
+  const bool step_inside = step && getenv("LMN_CHAN_STEP_SEPARATE") == nullptr;
   auto layer = [&](int l) {   // storage of level l, allocated when the first launch writes it
     if (!layers[l]) layers[l] = arena_.alloc_words((size_t)8 << l);
     return layers[l];
@@ -92,9 +95,10 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         nfused = std::min(plain, 10);
         for (int l = 0; l <= nfused; ++l) outs.p[l] = layer(level - l);
         bool to_root = level - nfused == 0;
-        launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, to_root ? ch : nullptr, alpha_out,
-                            root_copy, stream_);
-        if (to_root && ch) chan_done = true;
+        const bool with_ch = to_root && ch && (!step || step_inside);
+        launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, with_ch ? ch : nullptr, alpha_out,
+                            root_copy, stream_, with_ch ? step : nullptr);
+        if (with_ch) chan_done = true;
       } else {
         nfused = std::min(std::min(plain, MERKLE_MAX_FUSED), level - 10);
         // per-lane subtree depth: only as deep as still leaves >= 2^17 lanes (latency-bound below that)
@@ -139,12 +143,18 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
       level -= nfused + 1;
     }
   }
-  if (ch && !chan_done) launch_chan_mix_root_draw(ch, layers[0], alpha_out, root_copy, stream_);
+  if (ch && !chan_done) {
+    if (step)
+      launch_chan_step(ch, *step, layers[0], stream_);
+    else
+      launch_chan_mix_root_draw(ch, layers[0], alpha_out, root_copy, stream_);
+  }
 }
 
 void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch, QM31* alpha_out,
-                           uint32_t* root_copy, bool sharded, const MerkleFold* fold) {
+                           uint32_t* root_copy, bool sharded, const MerkleFold* fold, const ChanStep* step) {
   if (fold && sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: folded leaf levels are not sharded");
+  if (step && (sharded || !ch || cols_sorted.empty())) throw LmnError(LMN_ERR_INTERNAL, "merkle: a transcript step needs an unsharded tree and a channel");
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].log;
   m.layers.assign(m.max_log + 1, nullptr);
   m.cuts.clear();
@@ -159,7 +169,7 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
       if (c.sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: sharded column in a replicated tree");
       per_level[c.log].push_back(c.ptr);
     }
-    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy, fold, merkle_cut_ ? &m.cuts : nullptr);
+    build_merkle_levels(m.layers, m.max_log, per_level, ch, alpha_out, root_copy, fold, merkle_cut_ ? &m.cuts : nullptr, step);
     return;
   }
   // Sharded tree (SURVEY.md §8e stage C/D): the aligned block of rows [rank * 2^(k-g), (rank+1) * 2^(k-g)) of every
@@ -350,7 +360,7 @@ Context::CommitOut Context::interpolate_for_commit(uint32_t* coeffs, const uint3
 // columns hold coefficients; produce LDE evaluations (contiguous runs of equal size share launches).  With a
 // shard set, only this rank's aligned block of rows of every LDE is evaluated (launch_fft_block: the top
 // log2(world) layers collapse to a world-point combination at fixed row, the rest runs inside the block).
-void Context::lde_and_merkle(DevTree& tree, bool fetch_root) {
+void Context::lde_and_merkle(DevTree& tree, bool fetch_root, DevChannel* step_ch, const ChanStep* step) {
   const int lb = (int)cfg.log_blowup;
   const bool sh = shard_.active;
   const int g = sh ? shard_.g : 0;
@@ -388,7 +398,7 @@ void Context::lde_and_merkle(DevTree& tree, bool fetch_root) {
   std::vector<ColRef> sorted;
   for (auto& c : tree.cols) sorted.push_back({c.lde, c.log_size + lb, c.sharded});
   std::stable_sort(sorted.begin(), sorted.end(), [](auto& a, auto& b) { return a.log > b.log; });
-  build_merkle(tree.merkle, sorted, nullptr, nullptr, nullptr, sh);
+  build_merkle(tree.merkle, sorted, step ? step_ch : nullptr, nullptr, nullptr, sh, nullptr, step);
   if (fetch_root) fetch_root_async(tree.merkle);   // (device-resident transcript: the root travels with the DevReport)
 }
 

@@ -102,15 +102,8 @@ struct DevReport {
 };
 struct ChanElemSets {
   int n;
-  int set[CHAN_N_ELEMS];
+  int set[CHAN_N_ELEMS];                     // relation element set of each draw_felts(2); negative: drawn and discarded
 };
-// mix_root(root); then one draw_felts(2) per entry of set_of_draw (a negative entry draws and discards)
-// (`start`: the channel's state at this point, written to *ch first - a launch argument instead of an upload)
-void launch_chan_root_elems(DevChannel* ch, const DevChannel& start, const uint32_t* root, const uint32_t* bad_word,
-                            const int* set_of_draw, int n_draws, DevReport* rep, lmn_stream_t s);
-// mix_felts([claimed_i]) per component, mix_root(root), draw_felt() = the composition randomness alpha; then the
-// coefficient of every kernel constraint slot of every component: sign * alpha^(n_total - 1 - (k0 + proto_index)), 0 for a
-// slot the protocol lacks (Context's constraint_layout) - 16 per component at coeff_out + 16 * i
 constexpr int CHAN_MAX_INST = 17;
 struct ChanCoeffPlan {
   int n_inst, n_total;
@@ -120,18 +113,36 @@ struct ChanCoeffPlan {
   int8_t proto_index[CHAN_MAX_INST][16];
   uint16_t neg[CHAN_MAX_INST];               // bit k: the protocol's constraint is minus kernel slot k
 };
-void launch_chan_claims_root_alpha(DevChannel* ch, const ChanCoeffPlan& plan, const uint32_t* root, DevReport* rep,
-                                   QM31* coeff_out, lmn_stream_t s);
-// mix_root(root), t = draw_felt(), the OODS point ((1 - t^2) / (1 + t^2), 2t / (1 + t^2)), the points oods + step_i
-// (i >= 1; step_0 unused) and per point the mappings y, x, pi(x), pi^2(x), ... that launch_eval_tables expands
 constexpr int CHAN_MAX_POINTS = 24;
 struct ChanOodsPlan {
   int n_points, n_maps;
   uint32_t step_x[CHAN_MAX_POINTS], step_y[CHAN_MAX_POINTS];
 };
-// (`rep_host`: page-locked memory the finished report is copied to by the kernel itself - no download behind it)
-void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep,
-                           QM31* maps_out /* n_points x n_maps */, DevReport* rep_host, lmn_stream_t s);
+// One transcript step of the commitment phases, made by the launch that produces the tree's root (launch_merkle_small)
+// or by a launch of its own (launch_chan_step):
+//  kind 1  the channel starts at `start` (a launch argument instead of an upload); mix_root(root 1); one draw_felts(2) per
+//          entry of `sets` -> rep->elems; rep->bad = *bad_word
+//  kind 2  mix_felts([claimed_i]) per component, mix_root(root 2), draw_felt() = the composition randomness alpha; then the
+//          coefficient of every kernel constraint slot of every component: sign * alpha^(n_total - 1 - (k0 + proto_index)),
+//          0 for a slot the protocol lacks (Context's constraint_layout) - 16 per component at coeff_out + 16 * i
+//  kind 3  mix_root(root 3), t = draw_felt(), the OODS point ((1 - t^2) / (1 + t^2), 2t / (1 + t^2)), the points
+//          oods + step_i (i >= 1; step_0 unused) and per point the mappings y, x, pi(x), pi^2(x), ... that
+//          launch_eval_tables expands -> maps_out (n_points x n_maps); the finished report is copied to rep_host
+//          (page-locked memory) by the kernel itself - no download behind it
+//  kind 0  none (launch_merkle_small with a channel: mix_root + the draw of a folding alpha, the FRI layers' step)
+struct ChanStep {
+  int kind;
+  DevChannel start;
+  const uint32_t* bad_word;
+  ChanElemSets sets;
+  ChanCoeffPlan coeff;
+  QM31* coeff_out;
+  ChanOodsPlan oods;
+  QM31* maps_out;
+  uint32_t* rep_host;
+  DevReport* rep;
+};
+void launch_chan_step(DevChannel* ch, const ChanStep& step, const uint32_t* root, lmn_stream_t s);
 
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.
@@ -180,11 +191,11 @@ struct MerkleFold {
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int sub, int nfused, lmn_stream_t s, const MerkleFold* fold = nullptr);
 // one block, size <= 1024 start nodes, nfused <= 10
-// If `ch` is given and this launch reaches the root, it also mixes the root into the device channel
-// and draws the next felt (saves a launch per FRI layer).
+// If `ch` is given and this launch reaches the root, it also makes the transcript step that consumes the root: without
+// `step`, mix_root and the draw of the next felt (saves a launch per FRI layer); with it, that ChanStep.
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
-                         lmn_stream_t s);
+                         lmn_stream_t s, const ChanStep* step = nullptr);
 
 // FRI tail: layers of log size first_log, first_log-1, ... (n_layers of them, all <= 2^10) committed
 // and folded in one single-block launch.  layers[li].next is the evaluation buffer of the next layer.

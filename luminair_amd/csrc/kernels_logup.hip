@@ -164,40 +164,45 @@ LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restric
 constexpr int SCAN_SUMS_THREADS = 1024;
 LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
   LMN_SERIAL_KERNEL();
-  LMN_SHARED QM31 sh[SCAN_SUMS_THREADS];
+  LMN_SHARED QM31 sh[SCAN_SUMS_THREADS / 64];
   const int T = (int)blockDim.x;
   const int per = (nblocks + T - 1) / T;
   const int b0 = threadIdx.x * per;
   // pass 1: the lane's total (loads in independent batches of 8, so that they overlap)
   QM31 run = q_zero();
+  QM31 first[8];   // the lane's first batch stays in registers for pass 2 (up to 8 192 totals: the only batch)
   for (int k0 = 0; k0 < per; k0 += 8) {
     QM31 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int b = b0 + k0 + j;
       v[j] = (k0 + j < per && b < nblocks) ? blocksums[b] : q_zero();
+      if (k0 == 0) first[j] = v[j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) run = q_add(run, v[j]);
   }
-  // Hillis-Steele over the lanes' totals
-  sh[threadIdx.x] = run;
-  __syncthreads();
-  for (int off = 1; off < T; off <<= 1) {
-    QM31 add = q_zero();
-    if ((int)threadIdx.x >= off) add = sh[threadIdx.x - off];
-    __syncthreads();
-    sh[threadIdx.x] = q_add(sh[threadIdx.x], add);
-    __syncthreads();
+  // the lanes' totals: an inclusive scan inside each wave (six shuffle steps, no barrier), then the wave totals
+  // (at most 16) through LDS - one barrier instead of the twenty a block-wide Hillis-Steele scan takes
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  QM31 inc = run;
+#pragma unroll
+  for (uint32_t off = 1; off < 64u; off <<= 1) {
+    const QM31 o{lmn_shfl_up(inc.a, off), lmn_shfl_up(inc.b, off), lmn_shfl_up(inc.c, off), lmn_shfl_up(inc.d, off)};
+    if (lane >= off) inc = q_add(inc, o);
   }
+  if (lane == 63u) sh[wave] = inc;
+  __syncthreads();
+  QM31 before = q_zero();
+  for (uint32_t w = 0; w < wave; ++w) before = q_add(before, sh[w]);
   // pass 2: inclusive prefix inside the lane's run, starting from the lanes before it
-  QM31 acc = q_sub(sh[threadIdx.x], run);
+  QM31 acc = q_add(before, q_sub(inc, run));
   for (int k0 = 0; k0 < per; k0 += 8) {
     QM31 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int b = b0 + k0 + j;
-      v[j] = (k0 + j < per && b < nblocks) ? blocksums[b] : q_zero();
+      v[j] = k0 == 0 ? first[j] : ((k0 + j < per && b < nblocks) ? blocksums[b] : q_zero());
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

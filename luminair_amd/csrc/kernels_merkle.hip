@@ -514,18 +514,23 @@ LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, uint32_t& dg, uint32_t varia
   return QM31{scratch[24], scratch[25], scratch[26], scratch[27]};
 }
 
+constexpr int CHAN_STEP_SCRATCH = 32 + 4 * CHAN_MAX_INST;   // LDS words of a ChanStep (layout: chan_step_* below)
+LMN_D void chan_step_run(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t variant, uint32_t root_word, const ChanStep& st);
+
 // Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
+// The launch that produces the root also makes the transcript step that consumes it when `ch` is given: mix_root and
+// the draw of a folding alpha (step.kind 0, the FRI layers), or one of the commitment phases' steps (ChanStep, kernels.h).
 constexpr int MERKLE_SMALL_BLOCK = 1024;
 template <int MODE>
 LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
-                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy) {
+                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy, ChanStep step) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   const uint32_t i = threadIdx.x;
   // when this launch produces the root, it also runs the device-resident Fiat-Shamir step: fetch the channel now
   const bool fs = ch != nullptr && (size >> nfused) == 1u;
   uint32_t dg = 0u, variant = 0u;
-  if (fs) {
+  if (fs && step.kind != 1) {   // (kind 1 starts the channel from step.start)
     if (i < 8u) dg = ch->digest[i];
     variant = ch->variant;
   }
@@ -540,7 +545,12 @@ LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
   }
   LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
   merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
-  if (fs) chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
+  if (fs && step.kind == 0) chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
+  if (fs && step.kind != 0) {
+    __syncthreads();   // the root's words (the climb ends without a barrier)
+    const uint32_t root_word = i < 8u ? sh[i * MERKLE_SMALL_BLOCK] : 0u;
+    chan_step_run(sh + 16, ch, dg, variant, root_word, step);   // sh[16 .. 16 + CHAN_STEP_SCRATCH): word 0 of dead nodes
+  }
 }
 
 void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
@@ -572,16 +582,20 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
 
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
-                         lmn_stream_t s) {
+                         lmn_stream_t s, const ChanStep* step) {
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
   if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
+  static_assert(16 + CHAN_STEP_SCRATCH <= MERKLE_SMALL_BLOCK, "the step's scratch lies inside word 0 of the node array");
   const dim3 g(1), b(MERKLE_SMALL_BLOCK);
+  ChanStep none{};
+  const ChanStep& st = step ? *step : none;
+  if (st.kind != 0 && (!ch || (size >> nfused) != 1u)) throw LmnError(-100, "merkle_small: a transcript step needs the root and a channel");
   if (!prev && ncols <= 16 && sg.n[0] == ncols)
-    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
   else if (prev && ncols == 0)
-    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
   else
-    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy);
+    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
 }
 
 // =============================================================================================
@@ -600,83 +614,119 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 }
 
 // =============================================================================================
-// Device-resident Fiat-Shamir of the commitment phases (kernels.h): single-lane transcript steps - two to four dependent
-// compressions each - between the big kernels of a proof, instead of a host round trip (30 - 45 us of idle GPU each)
+// Device-resident Fiat-Shamir of the commitment phases (kernels.h): the transcript steps between the big kernels of a
+// proof - two to eight dependent compressions each - instead of a host round trip (30 - 45 us of idle GPU each).
+// Block-cooperative: every thread of the block calls these with block-uniform arguments; the compressions run on the
+// first quad (b2_quad_parent: 0.9 us per hash against 2 us on one lane).  They are the last thing the launch that
+// produces the tree's root does (k_merkle_small), or a launch of their own where no such launch exists (k_chan_step).
+// Scratch (LDS, CHAN_STEP_SCRATCH words): msg 16 | drawn words 8 | point 8 | claimed sums 4 x CHAN_MAX_INST.
 // =============================================================================================
-// digest <- H(digest || w[0..n)), n <= 8 words (one block)
-LMN_D void chan_mix_words(DevChannel* ch, const uint32_t* w, int n) {
-  uint32_t m[16], h[8];
-  for (int k = 0; k < 8; ++k) m[k] = ch->digest[k];
-  for (int k = 0; k < 8; ++k) m[8 + k] = k < n ? w[k] : 0u;
-  b2_compress_fresh(h, m, 32u + 4u * (uint32_t)n);
-  for (int k = 0; k < 8; ++k) ch->digest[k] = h[k];
-  ch->n_sent = 0u;
+// digest (msg[0..8)) <- H(digest || msg[8..8+n)); the caller has written msg[8..16) (zero-padded).  No barrier at the end.
+LMN_D void qchan_mix(uint32_t* msg, uint32_t n_words) {
+  const uint32_t tid = threadIdx.x, q = tid & 3u;
+  __syncthreads();
+  uint32_t lo = 0u, hi = 0u;
+  if (tid < 64u) b2_quad_parent(msg, q, lo, hi, 32u + 4u * n_words);
+  __syncthreads();
+  if (tid < 4u) {
+    msg[q] = lo;
+    msg[4u + q] = hi;
+  }
 }
-// Channel::draw_base_felts: 8 M31 from one hash, redrawn while a word is >= 2P
-LMN_D void chan_draw_base_felts(DevChannel* ch, uint32_t f[8]) {
+// Channel::draw_base_felts: 8 M31 from one hash of digest || counter, redrawn while a word is >= 2P; every thread gets them
+LMN_D void qchan_draw_felts8(uint32_t* msg, uint32_t* wbuf, uint32_t& n_sent, uint32_t t_draw, uint32_t f[8]) {
+  const uint32_t tid = threadIdx.x, q = tid & 3u;
   for (;;) {
-    uint32_t w[8];
-    chan_draw_words(ch, w);
+    if (tid >= 8u && tid < 16u) msg[tid] = tid == 8u ? n_sent : 0u;
+    __syncthreads();
+    uint32_t lo = 0u, hi = 0u;
+    if (tid < 64u) b2_quad_parent(msg, q, lo, hi, t_draw);
+    if (tid < 4u) {
+      wbuf[q] = lo;
+      wbuf[4u + q] = hi;
+    }
+    n_sent += 1u;
+    __syncthreads();
     bool ok = true;
-    for (int k = 0; k < 8; ++k) ok = ok && (w[k] < 2u * P31);
-    if (!ok) continue;
-    for (int k = 0; k < 8; ++k) f[k] = w[k] >= P31 ? w[k] - P31 : w[k];
-    return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f[k] = wbuf[k];
+      ok = ok && (f[k] < 2u * P31);
+    }
+    __syncthreads();  // everyone has read wbuf before the next draw overwrites it
+    if (ok) break;    // block-uniform
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = f[k] >= P31 ? f[k] - P31 : f[k];
+}
+LMN_D void qchan_store(DevChannel* ch, const uint32_t* msg, uint32_t n_sent, uint32_t variant) {
+  if (threadIdx.x < 8u) ch->digest[threadIdx.x] = msg[threadIdx.x];
+  if (threadIdx.x == 0u) {
+    ch->n_sent = n_sent;
+    ch->variant = variant;
   }
 }
 
-LMN_KERNEL k_chan_root_elems(DevChannel* ch, DevChannel start, const uint32_t* __restrict__ root,
-                             const uint32_t* __restrict__ bad_word, ChanElemSets sets, DevReport* rep) {
-  LMN_SERIAL_KERNEL();
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  *ch = start;   // the channel's state when the device takes it over travels as a launch argument
-  DevElems* out = &rep->elems;
-  rep->bad = *bad_word;
-  uint32_t r[8];
-  for (int k = 0; k < 8; ++k) r[k] = rep->roots[0][k] = root[k];
-  chan_mix_words(ch, r, 8);
-  for (int i = 0; i < sets.n; ++i) {
-    uint32_t f[8];
-    chan_draw_base_felts(ch, f);
-    const int e = sets.set[i];
-    if (e >= 0) {
-      out->z[e] = QM31{f[0], f[1], f[2], f[3]};
-      out->alpha[e] = QM31{f[4], f[5], f[6], f[7]};
-    }
+// kind 1: the channel starts at step.start; mix_root(root 1); one draw_felts(2) per relation element set
+LMN_D void chan_step_root_elems(uint32_t* scr, DevChannel* ch, uint32_t root_word, const ChanStep& st) {
+  uint32_t *msg = scr, *wbuf = scr + 16;
+  const uint32_t tid = threadIdx.x;
+  DevReport* rep = st.rep;
+  __syncthreads();
+  if (tid < 8u) {
+    msg[tid] = st.start.digest[tid];
+    msg[8u + tid] = root_word;
+    rep->roots[0][tid] = root_word;
   }
-}
-void launch_chan_root_elems(DevChannel* ch, const DevChannel& start, const uint32_t* root, const uint32_t* bad_word,
-                            const int* set_of_draw, int n_draws, DevReport* rep, lmn_stream_t s) {
-  if (n_draws < 1 || n_draws > CHAN_N_ELEMS) throw LmnError(-100, "chan_root_elems: bad draw count");
-  ChanElemSets sets{};
-  sets.n = n_draws;
-  for (int i = 0; i < n_draws; ++i) sets.set[i] = set_of_draw[i];
-  LMN_LAUNCH(k_chan_root_elems, dim3(1), dim3(64), 0, s, ch, start, root, bad_word, sets, rep);
-}
-
-LMN_KERNEL k_chan_claims_root_alpha(DevChannel* ch, ChanCoeffPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
-                                    QM31* coeff_out) {
-  LMN_SERIAL_KERNEL();
-  LMN_SHARED uint32_t sh_alpha[4];
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < plan.n_inst; ++i) {
-      const QM31 c = plan.claimed[i][0];
-      rep->claimed[i] = c;
-      const uint32_t w[4] = {c.a, c.b, c.c, c.d};
-      chan_mix_words(ch, w, 4);
-    }
-    uint32_t r[8];
-    for (int k = 0; k < 8; ++k) r[k] = rep->roots[1][k] = root[k];
-    chan_mix_words(ch, r, 8);
+  if (tid == 0u) rep->bad = *st.bad_word;
+  qchan_mix(msg, 8u);
+  uint32_t n_sent = 0u;
+  const uint32_t t_draw = st.start.variant == 0u ? 64u : 37u;
+  for (int i = 0; i < st.sets.n; ++i) {
     uint32_t f[8];
-    chan_draw_base_felts(ch, f);
-    rep->comp_alpha = QM31{f[0], f[1], f[2], f[3]};
-    for (int k = 0; k < 4; ++k) sh_alpha[k] = f[k];
+    qchan_draw_felts8(msg, wbuf, n_sent, t_draw, f);
+    const int e = st.sets.set[i];
+    if (tid == 0u && e >= 0) {
+      rep->elems.z[e] = QM31{f[0], f[1], f[2], f[3]};
+      rep->elems.alpha[e] = QM31{f[4], f[5], f[6], f[7]};
+    }
   }
   __syncthreads();
-  const QM31 alpha{sh_alpha[0], sh_alpha[1], sh_alpha[2], sh_alpha[3]};
+  qchan_store(ch, msg, n_sent, st.start.variant);
+}
+
+// kind 2: mix_felts([claimed_i]) per component, mix_root(root 2), draw_felt() = the composition randomness; then the
+// signed coefficient of every kernel constraint slot.  dg: lanes 0..7 hold the channel's digest (loaded by the caller)
+LMN_D void chan_step_claims_root_alpha(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t variant, uint32_t root_word,
+                                       const ChanStep& st) {
+  uint32_t *msg = scr, *wbuf = scr + 16, *cl = scr + 32;
+  const uint32_t tid = threadIdx.x;
+  const ChanCoeffPlan& plan = st.coeff;
+  DevReport* rep = st.rep;
+  __syncthreads();
+  if (tid < (uint32_t)plan.n_inst * 4u) {   // every claimed sum in one round trip to memory
+    const uint32_t w = reinterpret_cast<const uint32_t*>(plan.claimed[tid >> 2])[tid & 3u];
+    cl[tid] = w;
+    reinterpret_cast<uint32_t*>(&rep->claimed[tid >> 2])[tid & 3u] = w;
+  }
+  if (tid < 8u) msg[tid] = dg;
+  for (int i = 0; i < plan.n_inst; ++i) {
+    __syncthreads();
+    if (tid >= 8u && tid < 16u) msg[tid] = tid < 12u ? cl[4 * i + (int)tid - 8] : 0u;
+    qchan_mix(msg, 4u);
+  }
+  if (tid < 8u) {
+    msg[8u + tid] = root_word;
+    rep->roots[1][tid] = root_word;
+  }
+  qchan_mix(msg, 8u);
+  uint32_t n_sent = 0u, f[8];
+  qchan_draw_felts8(msg, wbuf, n_sent, variant == 0u ? 64u : 37u, f);
+  const QM31 alpha{f[0], f[1], f[2], f[3]};
+  if (tid == 0u) rep->comp_alpha = alpha;
+  qchan_store(ch, msg, n_sent, variant);
   // one lane per (component, kernel slot): alpha^e by square-and-multiply
-  for (int idx = (int)threadIdx.x; idx < plan.n_inst * 16; idx += (int)blockDim.x) {
+  for (int idx = (int)tid; idx < plan.n_inst * 16; idx += (int)blockDim.x) {
     const int i = idx >> 4, k = idx & 15;
     QM31 c = q_zero();
     if (k < plan.n_kernel[i] && plan.proto_index[i][k] >= 0) {
@@ -690,25 +740,29 @@ LMN_KERNEL k_chan_claims_root_alpha(DevChannel* ch, ChanCoeffPlan plan, const ui
       }
       if ((plan.neg[i] >> k) & 1u) c = q_neg(c);
     }
-    coeff_out[idx] = c;
+    st.coeff_out[idx] = c;
   }
 }
-void launch_chan_claims_root_alpha(DevChannel* ch, const ChanCoeffPlan& plan, const uint32_t* root, DevReport* rep,
-                                   QM31* coeff_out, lmn_stream_t s) {
-  if (plan.n_inst < 1 || plan.n_inst > CHAN_MAX_INST) throw LmnError(-100, "chan_claims_root_alpha: bad component count");
-  LMN_LAUNCH(k_chan_claims_root_alpha, dim3(1), dim3(TPB), 0, s, ch, plan, root, rep, coeff_out);
-}
 
-LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* __restrict__ root, DevReport* rep,
-                            QM31* maps_out, uint32_t* rep_host) {
-  LMN_SERIAL_KERNEL();
-  LMN_SHARED uint32_t sh_pt[8];
-  if (threadIdx.x == 0) {
-    uint32_t r[8];
-    for (int k = 0; k < 8; ++k) r[k] = rep->roots[2][k] = root[k];
-    chan_mix_words(ch, r, 8);
-    uint32_t f[8];
-    chan_draw_base_felts(ch, f);
+// kind 3: mix_root(root 3), t = draw_felt(), the OODS point, the sample points and their mappings; the finished report
+// goes to the host's page-locked copy
+LMN_D void chan_step_root_oods(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t variant, uint32_t root_word,
+                               const ChanStep& st) {
+  uint32_t *msg = scr, *wbuf = scr + 16, *sh_pt = scr + 24;
+  const uint32_t tid = threadIdx.x;
+  const ChanOodsPlan& plan = st.oods;
+  DevReport* rep = st.rep;
+  __syncthreads();
+  if (tid < 8u) {
+    msg[tid] = dg;
+    msg[8u + tid] = root_word;
+    rep->roots[2][tid] = root_word;
+  }
+  qchan_mix(msg, 8u);
+  uint32_t n_sent = 0u, f[8];
+  qchan_draw_felts8(msg, wbuf, n_sent, variant == 0u ? 64u : 37u, f);
+  qchan_store(ch, msg, n_sent, variant);
+  if (tid == 0u) {
     const QM31 tt{f[0], f[1], f[2], f[3]};
     rep->t = tt;
     const QM31 t2 = q_sqr(tt);
@@ -719,14 +773,14 @@ LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* _
   }
   __syncthreads();
   const QM31 ox{sh_pt[0], sh_pt[1], sh_pt[2], sh_pt[3]}, oy{sh_pt[4], sh_pt[5], sh_pt[6], sh_pt[7]};
-  for (int p = (int)threadIdx.x; p < plan.n_points; p += (int)blockDim.x) {
+  for (int p = (int)tid; p < plan.n_points; p += (int)blockDim.x) {
     QM31 px = ox, py = oy;
     if (p > 0) {   // secure point + base point (host.h qpt_add_m)
       const uint32_t bx = plan.step_x[p], by = plan.step_y[p];
       px = q_sub(q_mul_m(ox, bx), q_mul_m(oy, by));
       py = q_add(q_mul_m(ox, by), q_mul_m(oy, bx));
     }
-    QM31* mp = maps_out + (size_t)p * plan.n_maps;
+    QM31* mp = st.maps_out + (size_t)p * plan.n_maps;
     mp[0] = py;
     mp[1] = px;
     QM31 cur = px;
@@ -736,14 +790,41 @@ LMN_KERNEL k_chan_root_oods(DevChannel* ch, ChanOodsPlan plan, const uint32_t* _
     }
   }
   // the report is complete: the last of the device-resident steps writes the host's copy itself (page-locked memory;
-  // lane 0's words of this launch are visible to the block since the barrier above)
+  // this launch's own words of it are visible to the block since the barrier above)
   const uint32_t* rw = reinterpret_cast<const uint32_t*>(rep);
-  for (uint32_t k = threadIdx.x; k < (uint32_t)(sizeof(DevReport) / 4); k += blockDim.x) rep_host[k] = rw[k];
+  for (uint32_t k = tid; k < (uint32_t)(sizeof(DevReport) / 4); k += blockDim.x) st.rep_host[k] = rw[k];
 }
-void launch_chan_root_oods(DevChannel* ch, const ChanOodsPlan& plan, const uint32_t* root, DevReport* rep, QM31* maps_out,
-                           DevReport* rep_host, lmn_stream_t s) {
-  if (plan.n_points < 1 || plan.n_points > CHAN_MAX_POINTS || plan.n_maps < 2) throw LmnError(-100, "chan_root_oods: bad plan");
-  LMN_LAUNCH(k_chan_root_oods, dim3(1), dim3(64), 0, s, ch, plan, root, rep, maps_out, reinterpret_cast<uint32_t*>(rep_host));
+
+// root_word: lanes 0..7 hold the root's words; dg / variant: the channel as the caller fetched it at its start (kind 1
+// starts from step.start instead)
+LMN_D void chan_step_run(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t variant, uint32_t root_word, const ChanStep& st) {
+  if (st.kind == 1)
+    chan_step_root_elems(scr, ch, root_word, st);
+  else if (st.kind == 2)
+    chan_step_claims_root_alpha(scr, ch, dg, variant, root_word, st);
+  else if (st.kind == 3)
+    chan_step_root_oods(scr, ch, dg, variant, root_word, st);
+}
+
+// a step as a launch of its own (trees whose root is not produced by k_merkle_small)
+LMN_KERNEL k_chan_step(DevChannel* ch, ChanStep st, const uint32_t* __restrict__ root) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED uint32_t scr[CHAN_STEP_SCRATCH];
+  uint32_t dg = 0u, variant = 0u, root_word = 0u;
+  if (threadIdx.x < 8u) root_word = root[threadIdx.x];
+  if (st.kind != 1) {
+    if (threadIdx.x < 8u) dg = ch->digest[threadIdx.x];
+    variant = ch->variant;
+  }
+  chan_step_run(scr, ch, dg, variant, root_word, st);
+}
+void launch_chan_step(DevChannel* ch, const ChanStep& st, const uint32_t* root, lmn_stream_t s) {
+  if (st.kind < 1 || st.kind > 3) throw LmnError(-100, "chan_step: bad kind");
+  if (st.kind == 1 && (st.sets.n < 1 || st.sets.n > CHAN_N_ELEMS)) throw LmnError(-100, "chan_step: bad draw count");
+  if (st.kind == 2 && (st.coeff.n_inst < 1 || st.coeff.n_inst > CHAN_MAX_INST)) throw LmnError(-100, "chan_step: bad component count");
+  if (st.kind == 3 && (st.oods.n_points < 1 || st.oods.n_points > CHAN_MAX_POINTS || st.oods.n_maps < 2))
+    throw LmnError(-100, "chan_step: bad sample plan");
+  LMN_LAUNCH(k_chan_step, dim3(1), dim3(TPB), 0, s, ch, st, root);
 }
 
 // =============================================================================================
@@ -768,7 +849,7 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
     if (i < size0) mine = QM31{v0[i], v0[size0 + i], v0[2 * size0 + i], v0[3 * size0 + i]};
   }
   for (int li = 0; li < n_layers; ++li) {
-    const FriTailLayer ly = layers[li];
+    const FriTailLayer& ly = layers[li];   // (read through the scalar cache where needed: a copy would be indexed in scratch memory)
     const int L = first_log - li;
     const uint32_t size = 1u << L;
     uint32_t cur[8];

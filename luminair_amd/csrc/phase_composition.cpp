@@ -151,7 +151,9 @@ void Context::run_composition(ProofRun& r) {
   {
     StageTimer st(this, log, stream_, C_COMP_COMMIT);
     if (r.dev_fs) {
-      lde_and_merkle(tree3, false);   // no wait: run_oods goes on with k_chan_root_oods
+      ChanStep step;
+      plan_oods_step(r, step);
+      lde_and_merkle(tree3, false, r.d_chan, &step);   // no wait: the launch that produces root 3 draws the OODS point
       hm.mark("composition enqueued (device transcript)");
       return;
     }

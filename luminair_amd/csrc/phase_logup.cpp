@@ -116,8 +116,9 @@ void Context::run_interaction(ProofRun& r) {
     if (r.dev_fs) {
       // no wait: the device mixes the claimed sums and the root, draws the composition randomness and lays out every
       // component's constraint coefficients (k_chan_claims_root_alpha)
-      lde_and_merkle(tree2, false);
-      ChanCoeffPlan plan{};
+      ChanStep step{};
+      step.kind = 2;
+      ChanCoeffPlan& plan = step.coeff;
       if (inst.size() > (size_t)CHAN_MAX_INST) throw LmnError(LMN_ERR_INTERNAL, "more components than claim slots");
       plan.n_inst = (int)inst.size();
       int k0 = 0;
@@ -134,7 +135,9 @@ void Context::run_interaction(ProofRun& r) {
       }
       plan.n_total = k0;
       r.d_coeff = (QM31*)arena_.alloc_bytes(inst.size() * 16 * sizeof(QM31));
-      launch_chan_claims_root_alpha(r.d_chan, plan, tree2.merkle.layers[0], r.d_report, r.d_coeff, stream_);
+      step.coeff_out = r.d_coeff;
+      step.rep = r.d_report;
+      lde_and_merkle(tree2, false, r.d_chan, &step);   // the launch that produces root 2 makes the step (ChanStep kind 2)
       hm.mark("interaction trace enqueued (device transcript)");
       return;
     }

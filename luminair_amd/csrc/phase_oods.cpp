@@ -41,16 +41,46 @@ void Context::replay_device_transcript(ProofRun& r, const std::function<void(QM3
   hm.mark("replay: transcript up to the OODS point");
 }
 
+// ---- OODS point + mask points: point 0 = the OODS point, then per trace size the point one trace step before it
+void Context::plan_sample_points(ProofRun& r) {
+  if (!r.neg_step.empty()) return;
+  r.neg_step.assign(1, Pt{1u, 0u});
+  for (auto& ci : r.inst) {
+    if (r.prev_point_of_log.count(ci.log_size)) continue;
+    r.prev_point_of_log[ci.log_size] = (int)r.neg_step.size();
+    r.neg_step.push_back(pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu));  // -step
+  }
+}
+
+// Device-resident transcript: the launch that produces the composition tree's root draws the OODS point and expands the
+// sample points' mappings (ChanStep kind 3); everything the device-resident steps produced comes back in one block that
+// step writes to page-locked memory, valid after the wait inside run_oods's eval_at_points.
+void Context::plan_oods_step(ProofRun& r, ChanStep& step) {
+  plan_sample_points(r);
+  const std::vector<Pt>& neg_step = r.neg_step;
+  if (neg_step.size() > (size_t)CHAN_MAX_POINTS) throw LmnError(LMN_ERR_INTERNAL, "more sample points than the device transcript plans for");
+  step = ChanStep{};
+  step.kind = 3;
+  ChanOodsPlan& plan = step.oods;
+  plan.n_points = (int)neg_step.size();
+  plan.n_maps = std::max(r.comp_log, EVAL_LB);
+  for (size_t p = 0; p < neg_step.size(); ++p) {
+    plan.step_x[p] = neg_step[p].x;
+    plan.step_y[p] = neg_step[p].y;
+  }
+  r.d_maps = (QM31*)arena_.alloc_bytes((size_t)plan.n_points * plan.n_maps * sizeof(QM31));
+  DevReport* h_rep = (DevReport*)result_block(sizeof(DevReport));
+  r.h_report = h_rep;
+  step.maps_out = r.d_maps;
+  step.rep_host = reinterpret_cast<uint32_t*>(h_rep);
+  step.rep = r.d_report;
+}
+
 void Context::run_oods(ProofRun& r) {
   LMN_RUN_ALIASES(r);
-  // ---- OODS point + mask points: point 0 = the OODS point, then per trace size the point one trace step before it
-  std::map<int, int> prev_point_of_log;
-  std::vector<Pt> neg_step{Pt{1u, 0u}};
-  for (auto& ci : inst) {
-    if (prev_point_of_log.count(ci.log_size)) continue;
-    prev_point_of_log[ci.log_size] = (int)neg_step.size();
-    neg_step.push_back(pt_of_index((0x80000000u - subgroup_gen_index(ci.log_size)) & 0x7fffffffu));  // -step
-  }
+  plan_sample_points(r);
+  std::map<int, int>& prev_point_of_log = r.prev_point_of_log;
+  const std::vector<Pt>& neg_step = r.neg_step;
   auto set_points = [&](QM31 tt) {
     QM31 t2 = q_sqr(tt);
     QM31 tinv = q_inv(q_add_m(t2, 1u));
@@ -58,25 +88,7 @@ void Context::run_oods(ProofRun& r) {
     points.assign(1, oods);
     for (size_t p = 1; p < neg_step.size(); ++p) points.push_back(qpt_add_m(oods, neg_step[p]));
   };
-  if (r.dev_fs) {
-    // the device draws the point and expands the mappings (k_chan_root_oods); everything the device-resident steps
-    // produced comes back in one block the last of them writes to page-locked memory, valid after the wait inside
-    // eval_at_points below
-    if (neg_step.size() > (size_t)CHAN_MAX_POINTS) throw LmnError(LMN_ERR_INTERNAL, "more sample points than the device transcript plans for");
-    ChanOodsPlan plan{};
-    plan.n_points = (int)neg_step.size();
-    plan.n_maps = std::max(comp_log, EVAL_LB);
-    for (size_t p = 0; p < neg_step.size(); ++p) {
-      plan.step_x[p] = neg_step[p].x;
-      plan.step_y[p] = neg_step[p].y;
-    }
-    r.d_maps = (QM31*)arena_.alloc_bytes((size_t)plan.n_points * plan.n_maps * sizeof(QM31));
-    DevReport* h_rep = (DevReport*)result_block(sizeof(DevReport));
-    launch_chan_root_oods(r.d_chan, plan, tree3.merkle.layers[0], r.d_report, r.d_maps, h_rep, stream_);
-    r.h_report = h_rep;
-  } else {
-    set_points(channel.draw_felt());
-  }
+  if (!r.dev_fs) set_points(channel.draw_felt());   // (device-resident transcript: run_composition's plan_oods_step)
   // sample point indices per tree/column, in sampled_values order
   spoints.assign(4, {});
   spoints[0].assign(tree0.cols.size(), {0});

@@ -136,18 +136,23 @@ void Context::run_main_trace(ProofRun& r) {
       if (proof.claim[k] >= 0) channel.mix_u64((uint64_t)proof.claim[k]);
     r.bad_mark = bad_mark;
     if (r.dev_fs) {
-      // no wait: the device mixes the root and draws the relation elements (k_chan_root_elems); the host replays the
-      // step in run_oods, where the non-canonical-word verdict is read as well
-      lde_and_merkle(tree1, false);
-      DevChannel hc{};
-      memcpy(hc.digest, channel.digest().w, 32);
-      hc.n_sent = 0;
-      hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;
+      // no wait: the launch that produces the root also mixes it and draws the relation elements (ChanStep kind 1); the
+      // host replays the step in run_oods, where the non-canonical-word verdict is read as well
       r.d_chan = (DevChannel*)arena_.alloc_bytes(sizeof(DevChannel));
       r.d_report = (DevReport*)arena_.alloc_bytes(sizeof(DevReport));
+      ChanStep step{};
+      step.kind = 1;
+      memcpy(step.start.digest, channel.digest().w, 32);
+      step.start.n_sent = 0;
+      step.start.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;
+      step.bad_word = d_bad;
       int sets[CHAN_N_ELEMS];
       const int n_draws = relation_draw_sets(cfg.protocol_variant, sets);
-      launch_chan_root_elems(r.d_chan, hc, tree1.merkle.layers[0], d_bad, sets, n_draws, r.d_report, stream_);
+      if (n_draws < 1 || n_draws > CHAN_N_ELEMS) throw LmnError(LMN_ERR_INTERNAL, "relation draws: bad count");
+      step.sets.n = n_draws;
+      for (int i = 0; i < n_draws; ++i) step.sets.set[i] = sets[i];
+      step.rep = r.d_report;
+      lde_and_merkle(tree1, false, r.d_chan, &step);
       for (int i = 0; i < n_draws; ++i)
         if (sets[i] >= 0) elems.drawn[sets[i]] = true;
       hm.mark("main trace enqueued (device transcript)");

@@ -27,6 +27,7 @@
 #define LMN_SHARED __shared__
 typedef hipStream_t lmn_stream_t;
 #define lmn_shfl_xor(v, mask) __shfl_xor((v), (mask), 64)
+#define lmn_shfl_up(v, delta) __shfl_up((v), (delta), 64)   // lanes below `delta` of a wave keep their own value
 // value of lane (quad base + ((CTRL >> 2*(lane&3)) & 3)): DPP quad_perm, no LDS round trip
 #define lmn_quad_perm(v, CTRL) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (CTRL), 0xf, 0xf, true))
 #define LMN_ASSUME(x) __builtin_assume(x)
@@ -222,6 +223,13 @@ inline unsigned lmn_shfl_xor(unsigned v, int mask) {  // all lanes of the block 
   lmn_emu_shfl_scratch[threadIdx.x] = v;
   lmn_emu_syncthreads();
   unsigned r = lmn_emu_shfl_scratch[threadIdx.x ^ (unsigned)mask];
+  lmn_emu_syncthreads();
+  return r;
+}
+inline unsigned lmn_shfl_up(unsigned v, unsigned delta) {  // all lanes of the block must call it together
+  lmn_emu_shfl_scratch[threadIdx.x] = v;
+  lmn_emu_syncthreads();
+  unsigned r = (threadIdx.x & 63u) >= delta ? lmn_emu_shfl_scratch[threadIdx.x - delta] : v;
   lmn_emu_syncthreads();
   return r;
 }

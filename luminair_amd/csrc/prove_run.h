@@ -58,7 +58,9 @@ struct ProofRun {
   QM31* d_coeff = nullptr;               // 16 constraint-slot coefficients per component
   QM31* d_maps = nullptr;                // point mappings for launch_eval_tables
   uint32_t bad_mark = 0;                 // this proof's mark of the non-canonical-word verdict
-  // OODS
+  // OODS: point 0 = the OODS point, then per trace size the point one trace step before it (plan_sample_points)
+  std::map<int, int> prev_point_of_log;
+  std::vector<Pt> neg_step;
   QPt oods{};
   std::vector<QPt> points;
   std::vector<std::vector<std::vector<int>>> spoints;     // sample point indices per tree / column, sampled_values order

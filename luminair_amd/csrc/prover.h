@@ -285,23 +285,27 @@ class Context {
   bool shard_a2a_columns(int log_size) const;   // stage A / B for columns of this size
   bool shard_rows_front(int log_size) const;    // row-parallel transposes and logup fractions for tables of this size
   // commit `cols` (coefficients already in place) -> LDE + Merkle (row-block sharded when a shard is set)
-  void lde_and_merkle(DevTree& tree, bool fetch_root = true);
+  // `step` (device-resident transcript): made by the launch that produces the root, or by launch_chan_step behind it
+  void lde_and_merkle(DevTree& tree, bool fetch_root = true, DevChannel* step_ch = nullptr, const ChanStep* step = nullptr);
   // Merkle tree over columns sorted by size (descending, stable).  sharded: every rank hashes the subtree over its
   // row block, the subtree roots are all-gathered and the top log2(world) levels are hashed on every rank.
   // `fold` (unsharded FRI layers of more than 2^10 rows only): the leaf level computes the layer as the fold of the
   // previous one while hashing it (MerkleFold, kernels.h); cols_sorted then names the 4 columns it writes.
   void build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch = nullptr,
                     QM31* alpha_out = nullptr, uint32_t* root_copy = nullptr, bool sharded = false,
-                    const MerkleFold* fold = nullptr);
+                    const MerkleFold* fold = nullptr, const ChanStep* step = nullptr);
   // null entries of `layers` are allocated from the arena as the launches reach them; with `cuts` given, the levels a
   // fused launch keeps in registers stay null and are recorded there instead
   void build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
                            const std::vector<std::vector<const uint32_t*>>& per_level, DevChannel* ch, QM31* alpha_out,
-                           uint32_t* root_copy, const MerkleFold* fold = nullptr, std::vector<MerkleCut>* cuts = nullptr);
+                           uint32_t* root_copy, const MerkleFold* fold = nullptr, std::vector<MerkleCut>* cuts = nullptr,
+                           const ChanStep* step = nullptr);
   // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
   void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
   void plan_fri_buffers(struct ProofRun& r);   // phase_fri.cpp
+  void plan_sample_points(struct ProofRun& r);   // phase_oods.cpp
+  void plan_oods_step(struct ProofRun& r, ChanStep& step);   // phase_oods.cpp: ChanStep kind 3 for the composition tree's root
   QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                   const std::vector<std::vector<std::pair<int, QM31>>>& samples,
                                   const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);

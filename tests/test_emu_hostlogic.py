@@ -440,8 +440,8 @@ def test_emu_rows_in_lmn_host_alloc_memory(emu_ctx):
 
 
 def test_emu_device_and_host_transcript_give_the_same_bytes_and_errors(root, monkeypatch):
-    """The commitment phases' Fiat-Shamir steps run on the device by default (k_chan_* kernels, no host wait before the
-    sampled values) and on the host under LMN_HOST_FS=1: same proof bytes for a multi-component pie with LUT relations
+    """The commitment phases' Fiat-Shamir steps run on the device by default (ChanStep: made by the launch that produces
+    each tree's root, or by k_chan_step under LMN_CHAN_STEP_SEPARATE=1; no host wait before the sampled values) and on the host under LMN_HOST_FS=1: same proof bytes for a multi-component pie with LUT relations
     and a non-default constraint form, same rejection of a non-canonical word and of an unsatisfied constraint."""
     lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
     cfg = lib.default_config()
@@ -456,6 +456,10 @@ def test_emu_device_and_host_transcript_give_the_same_bytes_and_errors(root, mon
         dev = ctx.prove_tables(t, luts)
         monkeypatch.setenv("LMN_HOST_FS", "1")
         assert ctx.prove_tables(t, luts) == dev
+        monkeypatch.delenv("LMN_HOST_FS")
+        monkeypatch.setenv("LMN_CHAN_STEP_SEPARATE", "1")      # the steps as launches of their own (k_chan_step)
+        assert ctx.prove_tables(t, luts) == dev
+        monkeypatch.delenv("LMN_CHAN_STEP_SEPARATE")
     tabs = syn.chain_graph(300, 3)
     for env in (None, "1"):
         if env:
