@@ -24,6 +24,13 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
   bool chan_done = false;
   // LMN_CHAN_STEP_SEPARATE=1 (measurements, tests): a commitment phase's transcript step as a launch of its own behind the tree
   const bool step_inside = step && getenv("LMN_CHAN_STEP_SEPARATE") == nullptr;
+  const ChanStep* d_step = nullptr;   // the kernels read the plan from page-locked memory (one load per lane)
+  if (step) {
+    check_chan_step(*step);
+    ChanStep* p = (ChanStep*)pin_alloc(sizeof(ChanStep));
+    *p = *step;
+    d_step = p;
+  }
   auto layer = [&](int l) {   // storage of level l, allocated when the first launch writes it
     if (!layers[l]) layers[l] = arena_.alloc_words((size_t)8 << l);
     return layers[l];
@@ -97,7 +104,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
         bool to_root = level - nfused == 0;
         const bool with_ch = to_root && ch && (!step || step_inside);
         launch_merkle_small(prev, sg, (int)lc.size(), 1u << level, outs, nfused, with_ch ? ch : nullptr, alpha_out,
-                            root_copy, stream_, with_ch ? step : nullptr);
+                            root_copy, stream_, with_ch ? d_step : nullptr, with_ch && step ? step->kind : 0);
         if (with_ch) chan_done = true;
       } else {
         nfused = std::min(std::min(plain, MERKLE_MAX_FUSED), level - 10);
@@ -145,7 +152,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
   }
   if (ch && !chan_done) {
     if (step)
-      launch_chan_step(ch, *step, layers[0], stream_);
+      launch_chan_step(ch, d_step, step->kind, layers[0], stream_);
     else
       launch_chan_mix_root_draw(ch, layers[0], alpha_out, root_copy, stream_);
   }

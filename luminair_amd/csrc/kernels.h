@@ -142,7 +142,10 @@ struct ChanStep {
   uint32_t* rep_host;
   DevReport* rep;
 };
-void launch_chan_step(DevChannel* ch, const ChanStep& step, const uint32_t* root, lmn_stream_t s);
+// The kernels take the step as a device-visible pointer (+ its kind by value) and fetch it into LDS with one load per lane:
+// page-locked host memory serves (one round trip, behind the launch's first loads).  check_chan_step validates a plan.
+void check_chan_step(const ChanStep& step);
+void launch_chan_step(DevChannel* ch, const ChanStep* step, int step_kind, const uint32_t* root, lmn_stream_t s);
 
 // fused subtree variants: start level (children hashes and/or its own columns) + plain levels above.
 // The start level's columns are given as runs of contiguous equal-size columns.
@@ -195,7 +198,7 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
 // `step`, mix_root and the draw of the next felt (saves a launch per FRI layer); with it, that ChanStep.
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
-                         lmn_stream_t s, const ChanStep* step = nullptr);
+                         lmn_stream_t s, const ChanStep* step = nullptr, int step_kind = 0);
 
 // FRI tail: layers of log size first_log, first_log-1, ... (n_layers of them, all <= 2^10) committed
 // and folded in one single-block launch.  layers[li].next is the evaluation buffer of the next layer.

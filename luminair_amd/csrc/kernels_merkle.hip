@@ -514,7 +514,9 @@ LMN_D QM31 chan_mix_root_draw_block(DevChannel* ch, uint32_t& dg, uint32_t varia
   return QM31{scratch[24], scratch[25], scratch[26], scratch[27]};
 }
 
-constexpr int CHAN_STEP_SCRATCH = 32 + 4 * CHAN_MAX_INST;   // LDS words of a ChanStep (layout: chan_step_* below)
+constexpr int CHAN_STEP_SCRATCH = 32 + 4 * CHAN_MAX_INST;   // LDS words a ChanStep works in (layout: chan_step_* below)
+constexpr int CHAN_STEP_WORDS = (int)(sizeof(ChanStep) / 4);
+static_assert(sizeof(ChanStep) % 8 == 0 && CHAN_STEP_WORDS <= 1024, "a ChanStep is fetched by one word per lane of a block");
 LMN_D void chan_step_run(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t variant, uint32_t root_word, const ChanStep& st);
 
 // Small trees / tree tops: one node per lane, one block of up to 1024 lanes, up to 10 LDS levels.
@@ -523,33 +525,42 @@ LMN_D void chan_step_run(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t va
 constexpr int MERKLE_SMALL_BLOCK = 1024;
 template <int MODE>
 LMN_KERNEL k_merkle_small(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
-                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy, ChanStep step) {
+                          MerkleLevels outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
+                          const ChanStep* __restrict__ step, int step_kind) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
+  LMN_SHARED alignas(16) uint32_t sh_step[CHAN_STEP_WORDS];
   const uint32_t i = threadIdx.x;
   // when this launch produces the root, it also runs the device-resident Fiat-Shamir step: fetch the channel now
   const bool fs = ch != nullptr && (size >> nfused) == 1u;
   uint32_t dg = 0u, variant = 0u;
-  if (fs && step.kind != 1) {   // (kind 1 starts the channel from step.start)
+  if (fs && step_kind != 1) {   // (kind 1 starts the channel from step.start)
     if (i < 8u) dg = ch->digest[i];
     variant = ch->variant;
   }
   uint32_t cur[8];
+  uint32_t m[16];
+  if (i < size) merkle_load_mode<MODE>(prev, sg, ncols, size, i, m);
+  // the step's plan lies in page-locked host memory: fetched behind the node loads (one round trip over the link, over
+  // by the time the first compression is), kept in LDS
+  uint32_t step_word = 0u;
+  const bool step_lane = fs && step_kind != 0 && i < (uint32_t)CHAN_STEP_WORDS;
+  if (step_lane) step_word = reinterpret_cast<const uint32_t*>(step)[i];
   if (i < size) {
-    uint32_t m[16];
-    merkle_load_mode<MODE>(prev, sg, ncols, size, i, m);
     merkle_hash_mode<MODE>(prev, sg, ncols, size, i, m, cur);
     store_hash(outs.p[0] + (uint64_t)i * 8, cur);
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)
   }
+  if (step_lane) sh_step[i] = step_word;
   LMN_SERIAL_KERNEL();  // the leaf compression left the wave at its low phase priority
   merkle_lds_climb<MERKLE_SMALL_BLOCK>(sh, outs, 1, nfused, size);
-  if (fs && step.kind == 0) chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
-  if (fs && step.kind != 0) {
-    __syncthreads();   // the root's words (the climb ends without a barrier)
+  if (fs && step_kind == 0) chan_mix_root_draw_block(ch, dg, variant, sh, MERKLE_SMALL_BLOCK, sh + 16, alpha_out, root_copy);
+  if (fs && step_kind != 0) {
+    __syncthreads();   // the root's words (the climb ends without a barrier) and the plan
     const uint32_t root_word = i < 8u ? sh[i * MERKLE_SMALL_BLOCK] : 0u;
-    chan_step_run(sh + 16, ch, dg, variant, root_word, step);   // sh[16 .. 16 + CHAN_STEP_SCRATCH): word 0 of dead nodes
+    // sh[16 .. 16 + CHAN_STEP_SCRATCH): word 0 of dead nodes
+    chan_step_run(sh + 16, ch, dg, variant, root_word, *reinterpret_cast<const ChanStep*>(sh_step));
   }
 }
 
@@ -582,20 +593,20 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
 
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
                          const MerkleLevels& outs, int nfused, DevChannel* ch, QM31* alpha_out, uint32_t* root_copy,
-                         lmn_stream_t s, const ChanStep* step) {
+                         lmn_stream_t s, const ChanStep* step, int step_kind) {
   if (!prev && ncols == 0) throw LmnError(-100, "merkle level with no input");
   if (size > (uint32_t)MERKLE_SMALL_BLOCK || nfused > 10) throw LmnError(-100, "merkle_small: bad arguments");
   static_assert(16 + CHAN_STEP_SCRATCH <= MERKLE_SMALL_BLOCK, "the step's scratch lies inside word 0 of the node array");
   const dim3 g(1), b(MERKLE_SMALL_BLOCK);
-  ChanStep none{};
-  const ChanStep& st = step ? *step : none;
-  if (st.kind != 0 && (!ch || (size >> nfused) != 1u)) throw LmnError(-100, "merkle_small: a transcript step needs the root and a channel");
+  if (!step) step_kind = 0;
+  if (step_kind < 0 || step_kind > 3) throw LmnError(-100, "merkle_small: bad transcript step");
+  if (step_kind != 0 && (!ch || (size >> nfused) != 1u)) throw LmnError(-100, "merkle_small: a transcript step needs the root and a channel");
   if (!prev && ncols <= 16 && sg.n[0] == ncols)
-    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
+    LMN_LAUNCH(k_merkle_small<1>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, step, step_kind);
   else if (prev && ncols == 0)
-    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
+    LMN_LAUNCH(k_merkle_small<2>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, step, step_kind);
   else
-    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, st);
+    LMN_LAUNCH(k_merkle_small<0>, g, b, 0, s, prev, sg, ncols, size, outs, nfused, ch, alpha_out, root_copy, step, step_kind);
 }
 
 // =============================================================================================
@@ -807,24 +818,31 @@ LMN_D void chan_step_run(uint32_t* scr, DevChannel* ch, uint32_t dg, uint32_t va
 }
 
 // a step as a launch of its own (trees whose root is not produced by k_merkle_small)
-LMN_KERNEL k_chan_step(DevChannel* ch, ChanStep st, const uint32_t* __restrict__ root) {
+LMN_KERNEL k_chan_step(DevChannel* ch, const ChanStep* __restrict__ step, int step_kind, const uint32_t* __restrict__ root) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t scr[CHAN_STEP_SCRATCH];
+  LMN_SHARED alignas(16) uint32_t sh_step[CHAN_STEP_WORDS];
+  for (uint32_t k = threadIdx.x; k < (uint32_t)CHAN_STEP_WORDS; k += blockDim.x) sh_step[k] = reinterpret_cast<const uint32_t*>(step)[k];
   uint32_t dg = 0u, variant = 0u, root_word = 0u;
   if (threadIdx.x < 8u) root_word = root[threadIdx.x];
-  if (st.kind != 1) {
+  if (step_kind != 1) {
     if (threadIdx.x < 8u) dg = ch->digest[threadIdx.x];
     variant = ch->variant;
   }
-  chan_step_run(scr, ch, dg, variant, root_word, st);
+  __syncthreads();
+  chan_step_run(scr, ch, dg, variant, root_word, *reinterpret_cast<const ChanStep*>(sh_step));
 }
-void launch_chan_step(DevChannel* ch, const ChanStep& st, const uint32_t* root, lmn_stream_t s) {
+void check_chan_step(const ChanStep& st) {
   if (st.kind < 1 || st.kind > 3) throw LmnError(-100, "chan_step: bad kind");
   if (st.kind == 1 && (st.sets.n < 1 || st.sets.n > CHAN_N_ELEMS)) throw LmnError(-100, "chan_step: bad draw count");
   if (st.kind == 2 && (st.coeff.n_inst < 1 || st.coeff.n_inst > CHAN_MAX_INST)) throw LmnError(-100, "chan_step: bad component count");
   if (st.kind == 3 && (st.oods.n_points < 1 || st.oods.n_points > CHAN_MAX_POINTS || st.oods.n_maps < 2))
     throw LmnError(-100, "chan_step: bad sample plan");
-  LMN_LAUNCH(k_chan_step, dim3(1), dim3(TPB), 0, s, ch, st, root);
+}
+// `step`: device-visible (page-locked host memory is: read once)
+void launch_chan_step(DevChannel* ch, const ChanStep* step, int step_kind, const uint32_t* root, lmn_stream_t s) {
+  if (!step || step_kind < 1 || step_kind > 3) throw LmnError(-100, "chan_step: bad kind");
+  LMN_LAUNCH(k_chan_step, dim3(1), dim3(TPB), 0, s, ch, step, step_kind, root);
 }
 
 // =============================================================================================

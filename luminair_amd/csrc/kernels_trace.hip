@@ -8,33 +8,45 @@ namespace lmn {
 // =============================================================================================
 // a3  AoS -> SoA transpose with padding rows (is_last_idx = 1, everything else 0)
 // =============================================================================================
-constexpr int TR_ROWS = 64;
 // Rows [blk_row0, blk_row0 + blk_rows) of the padded table are produced (the whole table, or one rank's row block of a
 // sharded proof); row r of column c lands at cols[c * out_stride + (r - blk_row0)].
+// ROWS rows per workgroup: 256 (a lane has `ncols` independent loads in flight and every column gets a 1 KB run) wherever
+// the row block allows, 64 for smaller blocks.
+template <int ROWS>
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
                            uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic,
                            uint64_t out_stride, uint64_t blk_row0, uint32_t bad_value) {
-  LMN_DYN_SMEM(uint32_t, tile);  // TR_ROWS x stride
+  LMN_DYN_SMEM(uint32_t, tile);  // ROWS x stride
   // odd row stride: the column-major read below walks rows at that stride, and an even one (16 words for the 15 columns of
-  // Add) maps the 64 rows of a column onto 2 of the 32 LDS banks
+  // Add) maps the rows of a column onto 2 of the 32 LDS banks
   const int stride = ncols | 1;
-  const uint64_t row0 = blk_row0 + (uint64_t)blockIdx.x * TR_ROWS;
-  const int total = TR_ROWS * ncols;
-  for (int k = threadIdx.x; k < total; k += blockDim.x) {
-    // k / ncols by the precomputed reciprocal (exact for k < 2^16): a runtime integer division is ~30 VALU ops
-    const int r = magic ? (int)(((uint64_t)(uint32_t)k * magic) >> 32) : k, c = k - r * ncols;  // magic 0: one column
-    uint64_t gr = row0 + r;
-    uint32_t v;
-    if (gr < n_rows)
-      v = rows[gr * (uint64_t)ncols + c];
-    else
-      v = pad.v[c];
-    if (v >= P31) *bad_flag = bad_value;  // the boundary takes raw u32 words: reject non-canonical M31 values
-    tile[r * stride + c] = v;
+  const uint64_t row0 = blk_row0 + (uint64_t)blockIdx.x * ROWS;
+  const int total = ROWS * ncols;
+  constexpr int BATCH = 8;   // loads issued before the first of them is used
+  for (int k0 = threadIdx.x; k0 < total; k0 += BATCH * TPB) {
+    uint32_t v[BATCH];
+    int rr[BATCH], cc[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int k = k0 + j * TPB;
+      // k / ncols by the precomputed reciprocal (exact for k < 2^16): a runtime integer division is ~30 VALU ops
+      const int r = magic ? (int)(((uint64_t)(uint32_t)k * magic) >> 32) : k, c = k - r * ncols;  // magic 0: one column
+      rr[j] = r;
+      cc[j] = c;
+      const uint64_t gr = row0 + r;
+      v[j] = 0u;
+      if (k < total) v[j] = gr < n_rows ? rows[gr * (uint64_t)ncols + c] : pad.v[c];
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      if (k0 + j * TPB >= total) break;
+      if (v[j] >= P31) *bad_flag = bad_value;  // the boundary takes raw u32 words: reject non-canonical M31 values
+      tile[rr[j] * stride + cc[j]] = v[j];
+    }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < total; k += blockDim.x) {
-    int c = k / TR_ROWS, r = k - c * TR_ROWS;
+  for (int k = threadIdx.x; k < total; k += TPB) {
+    const int c = k / ROWS, r = k - c * ROWS;
     if (row0 + r < size) cols[(uint64_t)c * out_stride + (row0 - blk_row0) + r] = tile[r * stride + c];
   }
 }
@@ -43,14 +55,20 @@ void launch_transpose_pad_rows(const uint32_t* rows, uint64_t n_rows, int ncols,
                                uint64_t out_stride, uint64_t blk_row0, uint64_t blk_rows, const PadRow& pad, uint32_t* bad_flag,
                                lmn_stream_t s, uint32_t bad_value) {
   uint64_t size = 1ull << log_size;
-  if (blk_row0 % TR_ROWS || blk_row0 + blk_rows > size) throw LmnError(-100, "transpose: bad row block");
-  unsigned grid = cdiv(blk_rows, TR_ROWS);
-  size_t smem = (size_t)TR_ROWS * (ncols + 1) * 4;
+  const bool big = blk_row0 % 256 == 0 && blk_rows % 256 == 0;
+  const unsigned tr_rows = big ? 256u : 64u;
+  if (blk_row0 % tr_rows || blk_row0 + blk_rows > size) throw LmnError(-100, "transpose: bad row block");
+  unsigned grid = cdiv(blk_rows, tr_rows);
+  size_t smem = (size_t)tr_rows * (ncols + 1) * 4;
   if (ncols > 32 || ncols < 1) throw LmnError(-100, "transpose: bad column count");
   const uint32_t magic = ncols == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)ncols - 1) / (uint64_t)ncols);  // ceil(2^32 / ncols)
   // rows beyond the block are cut off by treating its end as the table's size
-  LMN_LAUNCH(k_transpose_pad, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, blk_row0 + blk_rows, cols, pad, bad_flag, magic,
-             out_stride, blk_row0, bad_value);
+  if (big)
+    LMN_LAUNCH(k_transpose_pad<256>, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, blk_row0 + blk_rows, cols, pad, bad_flag,
+               magic, out_stride, blk_row0, bad_value);
+  else
+    LMN_LAUNCH(k_transpose_pad<64>, dim3(grid), dim3(TPB), smem, s, rows, n_rows, ncols, blk_row0 + blk_rows, cols, pad, bad_flag,
+               magic, out_stride, blk_row0, bad_value);
 }
 void launch_transpose_pad(const uint32_t* rows, uint64_t n_rows, int ncols, int log_size, uint32_t* cols,
                           const PadRow& pad, uint32_t* bad_flag, lmn_stream_t s) {
