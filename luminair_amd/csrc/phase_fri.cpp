@@ -5,11 +5,13 @@
 
 namespace lmn {
 
-// Called by run_quotients inside its upload group, after the quotient columns have their sizes (r.quots).
-void Context::plan_fri_buffers(ProofRun& r) {
-  LMN_RUN_ALIASES(r);
+// The FRI commit loop's buffers, in two steps.  plan_fri_layout needs only the quotient columns' sizes: run_oods calls it
+// BEFORE its wait for the sampled values, while the host is a millisecond ahead of the device anyway; plan_fri_buffers
+// (run_quotients, inside its upload group, on the proof's critical path) then only adds the channel's state and stages the
+// tail's table.
+void Context::plan_fri_layout(ProofRun& r, int ls0, int smallest_quot_log) {
   ProofRun::FriPlan& fp = r.fri;
-  const int ls0 = quots[0].log;
+  const int lb = r.lb;
   fp.last_size_log = std::min((int)cfg.log_last_layer + lb, ls0 - 1);   // (a trace smaller than the configured last layer stops at its first line)
   fp.max_layers = ls0 + 1;
   const size_t root_words = (size_t)fp.max_layers * 8, alpha_words = (size_t)fp.max_layers * 4;
@@ -19,24 +21,23 @@ void Context::plan_fri_buffers(ProofRun& r) {
   fp.d_alphas = (QM31*)(fp.d_out + root_words);
   fp.d_last = fp.d_out + root_words + alpha_words;
   fp.out_bytes = (root_words + alpha_words + last_words) * 4;
-  DevChannel hc{};
-  memcpy(hc.digest, channel.digest().w, 32);   // nothing is mixed between the draw of the quotient randomness and the first layer's root
-  hc.n_sent = 0;
-  hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
-  fp.d_chan = (DevChannel*)stage_upload(&hc, sizeof hc);
   fp.tail_log = -1;
-  if (sh) return;
+  fp.tail_table.clear();
+  fp.planned_ls0 = ls0;
+  if (shard_.active) return;
   // unsharded: the layers from min(2^10, the size at which the last quotient column has joined) down are one launch
-  const int tail_log = std::min(std::min(10, ls0 - 1), quots.back().log - 1);
+  const int tail_log = std::min(std::min(10, ls0 - 1), smallest_quot_log - 1);
   if (tail_log <= fp.last_size_log) return;
   const int n_tail = tail_log - fp.last_size_log;
   fp.tail_log = tail_log;
-  fp.tail_first = tail_log == fp.last_size_log ? fp.d_last : arena_.alloc_words(4ull << tail_log);
-  std::vector<FriTailLayer> tl(n_tail);
+  fp.tail_first = arena_.alloc_words(4ull << tail_log);
+  fp.tail_table.resize(n_tail);
+  fp.tail_layers.reserve(n_tail);
   uint32_t* layer = fp.tail_first;
   for (int li = 0; li < n_tail; ++li) {
     const int L = tail_log - li;
-    FriLayer fl;
+    fp.tail_layers.emplace_back();
+    FriLayer& fl = fp.tail_layers.back();
     fl.log = L;
     fl.vals = layer;
     fl.sharded = false;
@@ -44,14 +45,25 @@ void Context::plan_fri_buffers(ProofRun& r) {
     fl.merkle.layers.assign(L + 1, nullptr);
     for (int l = 0; l <= L; ++l) fl.merkle.layers[l] = arena_.alloc_words((size_t)8 << l);
     uint32_t* next = L - 1 == fp.last_size_log ? fp.d_last : arena_.alloc_words(4ull << (L - 1));
-    tl[li].vals = layer;
-    tl[li].next = next;
-    tl[li].itw = itwX_[L + 1];
-    for (int l = 0; l <= L; ++l) tl[li].merkle[l] = fl.merkle.layers[l];
-    fp.tail_layers.push_back(fl);
+    FriTailLayer& t = fp.tail_table[li];
+    t.vals = layer;
+    t.next = next;
+    t.itw = itwX_[L + 1];
+    for (int l = 0; l <= L; ++l) t.merkle[l] = fl.merkle.layers[l];
     layer = next;
   }
-  fp.d_tail = upload_vec(tl);
+}
+
+void Context::plan_fri_buffers(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  ProofRun::FriPlan& fp = r.fri;
+  if (fp.planned_ls0 != quots[0].log) plan_fri_layout(r, quots[0].log, quots.back().log);   // (sharded proofs, level-2 callers)
+  DevChannel hc{};
+  memcpy(hc.digest, channel.digest().w, 32);   // nothing is mixed between the draw of the quotient randomness and the first layer's root
+  hc.n_sent = 0;
+  hc.variant = (cfg.protocol_variant & LMN_PV_DRAW_CTR_U32) ? 1u : 0u;   // the only encoding the FRI loop's channel ops depend on
+  fp.d_chan = (DevChannel*)stage_upload(&hc, sizeof hc);
+  fp.d_tail = fp.tail_table.empty() ? nullptr : upload_vec(fp.tail_table);
 }
 
 void Context::run_fri_commit(ProofRun& r) {

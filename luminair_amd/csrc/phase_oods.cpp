@@ -100,6 +100,17 @@ void Context::run_oods(ProofRun& r) {
     for (int c = nic - 4; c < nic; ++c) spoints[2][ci.inter_start + c] = {prev_point_of_log[ci.log_size], 0};
   }
   sampled.assign(4, {});
+  if (!shard_.active) {
+    // the host is about to wait for the sampled values and is a millisecond ahead of the device: lay out the FRI commit
+    // loop's buffers now instead of behind the wait (plan_fri_layout needs the LDE sizes only)
+    int lo = 1 << 30, hi = 0;
+    for (int t = 0; t < 4; ++t)
+      for (auto& c : trees[t]->cols) {
+        lo = std::min(lo, c.log_size + lb);
+        hi = std::max(hi, c.log_size + lb);
+      }
+    if (hi > 0) plan_fri_layout(r, hi, lo);
+  }
   {
     StageTimer st(this, log, stream_, C_OODS);
     std::vector<EvalJob> jobs;
@@ -150,6 +161,7 @@ void Context::run_quotients(ProofRun& r) {
     std::vector<std::pair<int, QM31>> samples;  // (point index, value)
   };
   std::vector<FlatCol> flat;
+  flat.reserve(tree0.cols.size() + tree1.cols.size() + tree2.cols.size() + tree3.cols.size());
   for (int t = 0; t < 4; ++t)
     for (size_t c = 0; c < trees[t]->cols.size(); ++c) {
       FlatCol f{trees[t]->cols[c].lde, trees[t]->cols[c].log_size + lb, {}};
@@ -171,10 +183,12 @@ void Context::run_quotients(ProofRun& r) {
     for (int ls : sizes) {
       std::vector<const uint32_t*> ptrs;
       std::vector<std::vector<std::pair<int, QM31>>> smp;
+      ptrs.reserve(flat.size());
+      smp.reserve(flat.size());
       for (auto& f : flat)
-        if (f.lde_log == ls) {
+        if (f.lde_log == ls) {   // (each column has one size: its samples move on)
           ptrs.push_back(f.lde);
-          smp.push_back(f.samples);
+          smp.push_back(std::move(f.samples));
         }
       QuotientArgs a = make_quotient_args(ls, ptrs, smp, points, quot_alpha, !sh);
       uint32_t* vals = a.out;

@@ -90,7 +90,9 @@ struct ProofRun {
     int tail_log = -1;              // first layer of the tail (-1: none planned)
     uint32_t* tail_first = nullptr; // that layer's values
     std::vector<FriLayer> tail_layers;
+    std::vector<FriTailLayer> tail_table;   // host copy, staged by plan_fri_buffers
     FriTailLayer* d_tail = nullptr;
+    int planned_ls0 = -1;           // plan_fri_layout ran for a first layer of this size
   } fri;
   std::vector<QM31> last_vals;
   int last_log = 0;

@@ -303,6 +303,7 @@ class Context {
   // in-place all-gather of `ncols` columns `col_stride` words apart: rank r owns words [r*w, (r+1)*w) of each
   void gather_columns(uint32_t* base, uint64_t col_stride, int ncols, uint64_t words_per_rank);
   void merkle_layer_timed(const uint32_t* prev, const uint32_t* const* cols, int ncols, uint32_t size, uint32_t* out);
+  void plan_fri_layout(struct ProofRun& r, int ls0, int smallest_quot_log);   // phase_fri.cpp
   void plan_fri_buffers(struct ProofRun& r);   // phase_fri.cpp
   void plan_sample_points(struct ProofRun& r);   // phase_oods.cpp
   void plan_oods_step(struct ProofRun& r, ChanStep& step);   // phase_oods.cpp: ChanStep kind 3 for the composition tree's root

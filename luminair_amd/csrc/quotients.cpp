@@ -13,6 +13,8 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
                                          const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out) {
   std::vector<int> batch_point;
   std::vector<std::vector<std::pair<int, QM31>>> batch_cols;
+  batch_point.reserve(QUOT_MAX_BATCH + 1);
+  batch_cols.reserve(QUOT_MAX_BATCH + 1);
   for (size_t c = 0; c < cols.size(); ++c)
     for (auto& sm : samples[c]) {
       size_t b = 0;
@@ -20,6 +22,7 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
       if (b == batch_point.size()) {
         batch_point.push_back(sm.first);
         batch_cols.emplace_back();
+        batch_cols.back().reserve(cols.size());
       }
       batch_cols[b].push_back({(int)c, sm.second});
     }
@@ -29,6 +32,8 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
   a.nbatch = (int)batch_point.size();
   std::vector<int> col_idx;
   std::vector<QM31> coeff_c;
+  col_idx.reserve(2 * cols.size());
+  coeff_c.reserve(2 * cols.size());
   for (size_t b = 0; b < batch_point.size(); ++b) {
     QPt pt = points[batch_point[b]];
     a.batch_start[b] = (int)col_idx.size();
