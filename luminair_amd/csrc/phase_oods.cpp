@@ -211,6 +211,7 @@ void Context::run_quotients(ProofRun& r) {
       quots.push_back({ls, vals, qs});
     }
     plan_fri_buffers(r);
+    hm.mark("quotient + FRI tables built");
     stage_group_end();
     hm.mark("quotient + FRI tables uploaded");
     for (size_t k = 0; k < sizes.size(); ++k) {
