@@ -4,6 +4,8 @@
 // that stays resident in HBM from the first transpose to the last query gather.
 #include "prove_run.h"
 
+#include <exception>
+
 namespace lmn {
 
 #ifdef LMN_BATCH
@@ -34,6 +36,21 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
     InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
     ~InFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
   } in_flight;
+  // A proof that ends in an exception may leave launches in flight that read plans from, or write results to, the
+  // page-locked staging memory the next proof reuses from its start: drain the stream on that way out (not in a
+  // lock-step batch, whose waits are rendezvous of all members), and close an upload group left open.
+  struct FailureDrain {
+    Context* c;
+    int pending = std::uncaught_exceptions();
+    ~FailureDrain() {
+      if (std::uncaught_exceptions() <= pending) return;
+      c->grp_pin_ = c->grp_dev_ = nullptr;
+      c->grp_cap_ = c->grp_off_ = 0;
+#if !defined(LMN_BATCH) && !defined(LMN_EMU)
+      (void)hipStreamSynchronize(c->stream_);
+#endif
+    }
+  } failure_drain{this};
   ProofRun r(cfg.protocol_variant);
   r.tables = tables;
   r.n_tables = n_tables;
