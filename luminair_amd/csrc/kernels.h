@@ -298,9 +298,11 @@ int logup_num_blocks(uint32_t n);
 void launch_logup_fracs(const LogupArgs& a, lmn_stream_t s);
 // claimed_out[0] = sum of partials; claimed_out[1] = shift = claimed * n_inv
 void launch_logup_reduce(const uint32_t* partials, int nblocks, uint32_t n_inv, QM31* claimed_out, lmn_stream_t s);
-// prefix sum of (last_tmp - shift) in coset order, written to the last 4 interaction columns
-void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_size, uint32_t* out_cols /*4 x n*/,
-                       QM31* blocksums, lmn_stream_t s);
+// prefix sum of (last_tmp - shift) in coset order, written to the last 4 interaction columns.
+// derive_claim: claimed_shift is OUTPUT - the claimed sum (= sum of last_tmp) and shift = claimed * n_inv come out of the
+// scan of the block totals itself (no launch_logup_reduce in front); otherwise it is read.
+void launch_logup_scan(const QM31* last_tmp, QM31* claimed_shift, int log_size, uint32_t* out_cols /*4 x n*/,
+                       QM31* blocksums, lmn_stream_t s, bool derive_claim = false, uint32_t n_inv = 0);
 int logup_scan_num_blocks(int log_size);
 
 // ---- a7: constraint quotients on the eval domain (log_size + 1)

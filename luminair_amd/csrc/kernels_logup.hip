@@ -122,12 +122,12 @@ LMN_D QM31 block_scan_inclusive(QM31 v, QM31* sh) {
   return sh[threadIdx.x];
 }
 
-// mode 0: write block totals; mode 1: write scanned values (+ exclusive block offsets)
+// mode 0: write block totals; mode 2: block totals of the unshifted values; mode 1: write scanned values (+ exclusive block offsets)
 LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restrict__ claimed_shift, int log_size,
                         uint32_t* __restrict__ out_cols, QM31* blocksums, int mode) {
   LMN_SHARED QM31 sh[TPB];
   const uint32_t n = 1u << log_size;
-  const QM31 shift = claimed_shift[1];
+  const QM31 shift = mode == 2 ? q_zero() : claimed_shift[1];   // mode 2: totals of the raw values (the shift does not exist yet)
   uint32_t i0 = (blockIdx.x * TPB + threadIdx.x) * SCAN_PER_THREAD;
   QM31 v[SCAN_PER_THREAD];
   uint32_t st[SCAN_PER_THREAD];
@@ -143,7 +143,7 @@ LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restric
     v[k] = run;
   }
   QM31 incl = block_scan_inclusive(run, sh);
-  if (mode == 0) {
+  if (mode != 1) {
     if (threadIdx.x == TPB - 1) blocksums[blockIdx.x] = incl;
     return;
   }
@@ -162,7 +162,11 @@ LMN_KERNEL k_logup_scan(const QM31* __restrict__ last_tmp, const QM31* __restric
 
 // inclusive scan of the block totals in place (single block of up to 1024 lanes; lane t owns a contiguous run)
 constexpr int SCAN_SUMS_THREADS = 1024;
-LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
+// `claim_out` given: the totals are those of the UNSHIFTED values (every block holds `per_block` of the n values, the last
+// one possibly fewer).  Their sum is the claimed sum, shift = sum / n; both are written to claim_out[0 .. 1], and the scan
+// is that of the shifted values: prefix(b) - (values up to and including block b) * shift.  One launch instead of a
+// reduction over the fraction kernel's partial sums in front of the totals.
+LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks, QM31* claim_out, uint32_t n_inv, uint32_t per_block, uint32_t n) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED QM31 sh[SCAN_SUMS_THREADS / 64];
   const int T = (int)blockDim.x;
@@ -195,6 +199,16 @@ LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
   __syncthreads();
   QM31 before = q_zero();
   for (uint32_t w = 0; w < wave; ++w) before = q_add(before, sh[w]);
+  QM31 shift = q_zero();
+  if (claim_out) {
+    QM31 total = before;
+    for (uint32_t w = wave; w < (uint32_t)(T + 63) / 64u; ++w) total = q_add(total, sh[w]);
+    shift = q_mul_m(total, n_inv);
+    if (threadIdx.x == 0) {
+      claim_out[0] = total;
+      claim_out[1] = shift;
+    }
+  }
   // pass 2: inclusive prefix inside the lane's run, starting from the lanes before it
   QM31 acc = q_add(before, q_sub(inc, run));
   for (int k0 = 0; k0 < per; k0 += 8) {
@@ -208,7 +222,10 @@ LMN_KERNEL k_scan_blocksums(QM31* blocksums, int nblocks) {
     for (int j = 0; j < 8; ++j) {
       const int b = b0 + k0 + j;
       acc = q_add(acc, v[j]);
-      if (k0 + j < per && b < nblocks) blocksums[b] = acc;
+      if (k0 + j < per && b < nblocks) {
+        const uint64_t upto = ((uint64_t)b + 1u) * per_block;
+        blocksums[b] = claim_out ? q_sub(acc, q_mul_m(shift, (uint32_t)(upto < n ? upto : n))) : acc;
+      }
     }
   }
 }
@@ -236,7 +253,7 @@ LMN_KERNEL k_logup_scan2(const QM31* __restrict__ last_tmp, const QM31* __restri
   const int gbits = log_size - 1 - A - C;                 // bits of the region index G
   const uint32_t n = 1u << log_size;
   const uint32_t g = blockIdx.x, gmask = (1u << gbits) - 1u;
-  const QM31 shift = claimed_shift[1];
+  const QM31 shift = MODE == 2 ? q_zero() : claimed_shift[1];   // MODE 2: block totals of the unshifted values
   // element e of the tile: ((Gi * 2^A + r) * 2^C + x) * 2 + parity  <->  storage 2u + parity,
   // u = r << (k-1-A) | G << C | x   (r = brev_A(ml))
   auto storage_of = [&](uint32_t e) {
@@ -281,7 +298,7 @@ LMN_KERNEL k_logup_scan2(const QM31* __restrict__ last_tmp, const QM31* __restri
   }
   const uint32_t G = gi ? (~g & gmask) : g;
   const uint32_t mh = __brev((G << C) | x) >> (32 - (gbits + C));
-  if (MODE == 0) {
+  if (MODE != 1) {
     if (part == 0) blocksums[mh] = tot;
     return;
   }
@@ -306,26 +323,35 @@ int logup_scan_num_blocks(int log_size) {
   return (int)cdiv(1ull << log_size, SCAN_PER_BLOCK);
 }
 
-void launch_logup_scan(const QM31* last_tmp, const QM31* claimed_shift, int log_size, uint32_t* out_cols,
-                       QM31* blocksums, lmn_stream_t s) {
+void launch_logup_scan(const QM31* last_tmp, QM31* claimed_shift, int log_size, uint32_t* out_cols, QM31* blocksums,
+                       lmn_stream_t s, bool derive_claim, uint32_t n_inv) {
   static const bool scattered = getenv("LMN_LOGUP_SCAN_V1") != nullptr;   // ablation: the round-1 kernel
   int nb = logup_scan_num_blocks(log_size);
+  const uint32_t n = 1u << log_size;
+  QM31* claim_out = derive_claim ? claimed_shift : nullptr;
+  const dim3 sums_block(nb > 2048 ? SCAN_SUMS_THREADS : TPB);
   if (log_size >= SCAN2_MIN_LOG && !scattered) {
     const dim3 grid(1u << (log_size - 2 - SCAN2_A - SCAN2_C));
     const size_t smem = (size_t)SCAN2_ELEMS * sizeof(QM31);
 #if !defined(LMN_EMU) && !defined(LMN_BATCH)
     allow_big_lds((const void*)k_logup_scan2<0>, (int)smem);
     allow_big_lds((const void*)k_logup_scan2<1>, (int)smem);
+    allow_big_lds((const void*)k_logup_scan2<2>, (int)smem);
 #endif
-    LMN_LAUNCH(k_logup_scan2<0>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
-    LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb);
-    LMN_LAUNCH(k_logup_scan2<1>, grid, dim3(TPB), smem, s, last_tmp, claimed_shift, log_size, out_cols, blocksums);
+    if (derive_claim)
+      LMN_LAUNCH(k_logup_scan2<2>, grid, dim3(TPB), smem, s, last_tmp, (const QM31*)claimed_shift, log_size, out_cols, blocksums);
+    else
+      LMN_LAUNCH(k_logup_scan2<0>, grid, dim3(TPB), smem, s, last_tmp, (const QM31*)claimed_shift, log_size, out_cols, blocksums);
+    LMN_LAUNCH(k_scan_blocksums, dim3(1), sums_block, 0, s, blocksums, nb, claim_out, n_inv, 2u << SCAN2_A, n);
+    LMN_LAUNCH(k_logup_scan2<1>, grid, dim3(TPB), smem, s, last_tmp, (const QM31*)claimed_shift, log_size, out_cols, blocksums);
     return;
   }
   if (scattered) nb = (int)cdiv(1ull << log_size, SCAN_PER_BLOCK);
-  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 0);
-  LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb);
-  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, claimed_shift, log_size, out_cols, blocksums, 1);
+  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, (const QM31*)claimed_shift, log_size, out_cols, blocksums,
+             derive_claim ? 2 : 0);
+  LMN_LAUNCH(k_scan_blocksums, dim3(1), dim3(nb > 2048 ? SCAN_SUMS_THREADS : TPB), 0, s, blocksums, nb, claim_out, n_inv,
+             (uint32_t)SCAN_PER_BLOCK, n);
+  LMN_LAUNCH(k_logup_scan, dim3(nb), dim3(TPB), 0, s, last_tmp, (const QM31*)claimed_shift, log_size, out_cols, blocksums, 1);
 }
 
 }  // namespace lmn

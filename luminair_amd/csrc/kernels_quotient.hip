@@ -346,21 +346,28 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
   // QM31 product per owned lo position closes the chunk.
   QAcc in0 = qacc_zero(), in1 = qacc_zero(), in2 = qacc_zero(), in3 = qacc_zero();
   uint32_t pending = 0;
-  for (uint32_t hh = 0; hh < hpc; ++hh) {
+  // a chunk is at most EVAL_HI_PER_CHUNK runs of coefficients: all their loads are issued before the first product
+  uint32_t cv[EVAL_HI_PER_CHUNK][4];
+  QM31 Hv[EVAL_HI_PER_CHUNK];
+#pragma unroll
+  for (uint32_t hh = 0; hh < (uint32_t)EVAL_HI_PER_CHUNK; ++hh) {
     const uint32_t hi = chunk * hpc + hh;
     const uint32_t* __restrict__ cp = job.coeffs + ((uint64_t)hi << lb);
-    const QM31 Hv = Hh[hi];
-    uint32_t cv[4];
+    Hv[hh] = hh < hpc ? Hh[hi] : q_zero();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
-      cv[k] = lo < lo_n ? cp[lo] : 0u;
+      const uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
+      cv[hh][k] = (hh < hpc && lo < lo_n) ? cp[lo] : 0u;
     }
+  }
+#pragma unroll
+  for (uint32_t hh = 0; hh < (uint32_t)EVAL_HI_PER_CHUNK; ++hh) {
+    if (hh >= hpc) break;
     LMN_QPHASE_PORT0();
-    qacc_mad(in0, Hv, cv[0]);
-    qacc_mad(in1, Hv, cv[1]);
-    qacc_mad(in2, Hv, cv[2]);
-    qacc_mad(in3, Hv, cv[3]);
+    qacc_mad(in0, Hv[hh], cv[hh][0]);
+    qacc_mad(in1, Hv[hh], cv[hh][1]);
+    qacc_mad(in2, Hv[hh], cv[hh][2]);
+    qacc_mad(in3, Hv[hh], cv[hh][3]);
     LMN_QPHASE_ANY();
     if (++pending == 3) {
       pending = 0;

@@ -370,9 +370,9 @@ lmn_col* Context::col_logup(uint32_t kind, const lmn_col* main, const lmn_col* p
   a.n = (uint32_t)n;
   launch_logup_fracs(a, stream_);
   QM31* d_cs = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
-  launch_logup_reduce(a.partials, nb, m_inv((uint32_t)(n % P31)), d_cs, stream_);
   QM31* bsums = (QM31*)arena_.alloc_bytes((size_t)logup_scan_num_blocks((int)main->log_size) * sizeof(QM31));
-  launch_logup_scan(a.last_tmp, d_cs, (int)main->log_size, out.c->d + (uint64_t)(nic - 4) * n, bsums, stream_);
+  launch_logup_scan(a.last_tmp, d_cs, (int)main->log_size, out.c->d + (uint64_t)(nic - 4) * n, bsums, stream_, true,
+                    m_inv((uint32_t)(n % P31)));
   const QM31* cs = (const QM31*)stage_download(d_cs, 2 * sizeof(QM31));
   lmn_sync(stream_);
   claimed_out[0] = cs[0].a;

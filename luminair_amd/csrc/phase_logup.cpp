@@ -95,9 +95,9 @@ void Context::run_interaction(ProofRun& r) {
       launch_logup_fracs(a, stream_);
       QM31* d_cs = (QM31*)arena_.alloc_bytes(2 * sizeof(QM31));
       uint32_t n_inv = m_inv((uint32_t)(n % P31));
-      launch_logup_reduce(a.partials, nb, n_inv, d_cs, stream_);
+      // claimed sum and shift come out of the scan's own block totals (no reduction launch over a.partials in front)
       QM31* bsums = (QM31*)arena_.alloc_bytes((size_t)logup_scan_num_blocks(ci.log_size) * sizeof(QM31));
-      launch_logup_scan(a.last_tmp, d_cs, ci.log_size, ievals + (uint64_t)(nic - 4) * n, bsums, stream_);
+      launch_logup_scan(a.last_tmp, d_cs, ci.log_size, ievals + (uint64_t)(nic - 4) * n, bsums, stream_, true, n_inv);
       ci.d_claimed_shift = d_cs;
       ci.inter_start = off;
       off += nic;
