@@ -763,6 +763,11 @@ LMN_D void chan_step_root_oods(uint32_t* scr, DevChannel* ch, uint32_t dg, uint3
   const uint32_t tid = threadIdx.x;
   const ChanOodsPlan& plan = st.oods;
   DevReport* rep = st.rep;
+  // the job table's words are fetched now (one round trip over the link, behind the hashing below) and stored at the end
+  const uint32_t copy_words = st.copy_words;
+  const uint32_t* copy_src = st.copy_src;
+  uint32_t* copy_dst = st.copy_dst;
+  const uint32_t copy_word = tid < copy_words ? copy_src[tid] : 0u;
   __syncthreads();
   if (tid < 8u) {
     msg[tid] = dg;
@@ -804,6 +809,8 @@ LMN_D void chan_step_root_oods(uint32_t* scr, DevChannel* ch, uint32_t dg, uint3
   // this launch's own words of it are visible to the block since the barrier above)
   const uint32_t* rw = reinterpret_cast<const uint32_t*>(rep);
   for (uint32_t k = tid; k < (uint32_t)(sizeof(DevReport) / 4); k += blockDim.x) st.rep_host[k] = rw[k];
+  if (tid < copy_words) copy_dst[tid] = copy_word;
+  for (uint32_t k = tid + blockDim.x; k < copy_words; k += blockDim.x) copy_dst[k] = copy_src[k];
 }
 
 // root_word: lanes 0..7 hold the root's words; dg / variant: the channel as the caller fetched it at its start (kind 1
@@ -851,7 +858,7 @@ void launch_chan_step(DevChannel* ch, const ChanStep* step, int step_kind, const
 // alpha, fold.  Every layer's evaluations and tree levels still go to HBM for decommitment.
 // =============================================================================================
 LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, int n_layers, int first_log,
-                      QM31* alphas_out, uint32_t* roots_out) {
+                      QM31* alphas_out, uint32_t* roots_out, FriTailPre pre) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   LMN_SHARED uint32_t shv[MERKLE_SMALL_BLOCK * 4];   // the layer's values, coordinate-major: the fold reads its pair here
@@ -862,9 +869,24 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
   const uint32_t variant = ch->variant;
   QM31 mine = q_zero();
   {
-    const uint32_t* v0 = layers[0].vals;
     const uint32_t size0 = 1u << first_log;
-    if (i < size0) mine = QM31{v0[i], v0[size0 + i], v0[2 * size0 + i], v0[3 * size0 + i]};
+    if (pre.src) {   // the first layer is the fold of the layer before it (same arithmetic as k_fold / MerkleFold)
+      if (i < size0) {
+        const uint64_t L = 2ull * size0;
+        const uint32_t* __restrict__ sp = pre.src + 2ull * i;
+        const QM31 a{sp[0], sp[L], sp[2 * L], sp[3 * L]};
+        const QM31 b{sp[1], sp[L + 1], sp[2 * L + 1], sp[3 * L + 1]};
+        mine = q_add(q_add(a, b), q_mul(*pre.alpha, q_mul_m(q_sub(a, b), pre.itw[i])));
+        uint32_t* v0 = const_cast<uint32_t*>(layers[0].vals);
+        v0[i] = mine.a;
+        v0[size0 + i] = mine.b;
+        v0[2 * size0 + i] = mine.c;
+        v0[3 * size0 + i] = mine.d;
+      }
+    } else {
+      const uint32_t* v0 = layers[0].vals;
+      if (i < size0) mine = QM31{v0[i], v0[size0 + i], v0[2 * size0 + i], v0[3 * size0 + i]};
+    }
   }
   for (int li = 0; li < n_layers; ++li) {
     const FriTailLayer& ly = layers[li];   // (read through the scalar cache where needed: a copy would be indexed in scratch memory)
@@ -908,13 +930,16 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
     }
     __syncthreads();
   }
+  if (pre.out_mirror)   // (this launch's own words of the block are visible to the block since the barrier above)
+    for (uint32_t k = i; k < pre.out_words; k += blockDim.x) pre.out_mirror[k] = pre.out_block[k];
 }
 
 void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
-                     uint32_t* roots_out, lmn_stream_t s) {
+                     uint32_t* roots_out, lmn_stream_t s, const FriTailPre* pre) {
   if (first_log > 10 || n_layers < 1 || n_layers > first_log) throw LmnError(-100, "fri_tail: bad arguments");
+  const FriTailPre p = pre ? *pre : FriTailPre{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   LMN_LAUNCH(k_fri_tail, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, ch, layers, n_layers, first_log, alphas_out,
-             roots_out);
+             roots_out, p);
 }
 
 // =============================================================================================

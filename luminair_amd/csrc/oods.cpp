@@ -6,7 +6,8 @@ namespace lmn {
 
 // ------------------------------------------------------------------------------------ OODS evaluation
 std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points,
-                                          int max_log, bool split, const QM31* d_maps_in, int n_points) {
+                                          int max_log, bool split, const QM31* d_maps_in, int n_points,
+                                          const EvalJob* d_jobs_in) {
   const int np = d_maps_in ? n_points : (int)points.size();
   const uint32_t lo_n = 1u << EVAL_LB;
   const int hi_bits = max_log > EVAL_LB ? max_log - EVAL_LB : 0;
@@ -25,7 +26,7 @@ std::vector<QM31> Context::eval_at_points(const std::vector<EvalJob>& jobs, cons
     }
   }
   int max_chunks = eval_num_chunks(max_log);
-  EvalJob* d_jobs = upload_vec(jobs);
+  const EvalJob* d_jobs = d_jobs_in ? d_jobs_in : upload_vec(jobs);
   const QM31* d_maps = d_maps_in ? d_maps_in : upload_vec(maps);
   QM31* d_lo = (QM31*)arena_.alloc_bytes((size_t)np * lo_n * sizeof(QM31));
   QM31* d_hi = (QM31*)arena_.alloc_bytes((size_t)np * hi_n * sizeof(QM31));

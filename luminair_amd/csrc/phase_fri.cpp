@@ -141,9 +141,15 @@ void Context::run_fri_commit(ProofRun& r) {
       if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
     }
     size_t qi = 1;
+    // the line fold that produces the tail's first layer is left to the tail's launch (FriTailPre)
+    FriTailPre tail_pre{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    const uint32_t* h_out = nullptr;   // the result block on the host: written by the tail itself, or downloaded
     while (layer_log > last_size_log) {
       if (pend.on && layer_log <= 10) materialise(layer);
-      if (!lay_sh && layer_log <= 10 && qi == quots.size()) {
+      const bool into_tail = !lay_sh && layer_log <= 10 && qi == quots.size();
+      if (tail_pre.src && !(into_tail && layer_log == fp.tail_log && layer == fp.tail_first))
+        throw LmnError(LMN_ERR_INTERNAL, "FRI: a fold left to the tail, and no tail where it was planned");
+      if (into_tail) {
         // all remaining layers fit one block: commit + fold them in a single launch
         int n_tail = layer_log - last_size_log;
         FriTailLayer* d_tl = fp.d_tail;
@@ -174,7 +180,14 @@ void Context::run_fri_commit(ProofRun& r) {
         }
         {
           StageTimer t(this, log, stream_, C_MERKLE);
-          launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_);
+          if (!sh && layer == fp.d_last) {   // the tail ends the loop: it hands the result block over itself
+            uint32_t* mirror = (uint32_t*)result_block(fp.out_bytes);
+            tail_pre.out_block = fp.d_out;
+            tail_pre.out_mirror = mirror;
+            tail_pre.out_words = (uint32_t)(fp.out_bytes / 4);
+            h_out = mirror;
+          }
+          launch_fri_tail(d_ch, d_tl, n_tail, layer_log, d_alphas + n_roots, d_roots + 8 * n_roots, stream_, &tail_pre);
         }
         for (int li = 0; li < n_tail; ++li) timings.merkle_compressions += (2ull << (layer_log - li));
         n_roots += n_tail;
@@ -208,6 +221,11 @@ void Context::run_fri_commit(ProofRun& r) {
       if (!sh && fuse_folds && next_log > 10 && (!joins || (fuse_joins && !quots[qi].sharded))) {
         pend = {true, false, layer, layer_log, d_alpha, joins ? quots[qi].vals : nullptr};
         if (joins) ++qi;   // (quotient sizes are distinct: at most one column joins a layer)
+      } else if (!sh && fuse_folds && !joins && qi == quots.size() && next_log == fp.tail_log && next == fp.tail_first &&
+                 next_log > last_size_log) {
+        tail_pre.src = layer;   // the tail starts with this fold: no launch for it
+        tail_pre.itw = itwX_[layer_log + 1];
+        tail_pre.alpha = d_alpha;
       } else {
         fold(false, next, next_sh, layer, layer_log, lay_sh, d_alpha, 0);
       }
@@ -230,7 +248,7 @@ void Context::run_fri_commit(ProofRun& r) {
       throw LmnError(LMN_ERR_INTERNAL, "FRI: the layer plan does not match the layers committed");
     last_log = layer_log;
     // roots | alphas | last layer: one block, one download
-    const uint32_t* h_out = (const uint32_t*)stage_download(fp.d_out, fp.out_bytes);
+    if (!h_out) h_out = (const uint32_t*)stage_download(fp.d_out, fp.out_bytes);
     const uint32_t* h_roots = h_out;
     const QM31* h_alphas = (const QM31*)(h_out + ((const uint32_t*)fp.d_alphas - fp.d_out));
     const uint32_t* raw = h_out + (fp.d_last - fp.d_out);

@@ -52,6 +52,28 @@ void Context::plan_sample_points(ProofRun& r) {
   }
 }
 
+// sample point indices per tree / column in sampled_values order, and the evaluation jobs they make (needs the four trees'
+// columns with their coefficient pointers: called once the composition polynomial has its place)
+void Context::plan_eval_jobs(ProofRun& r) {
+  if (!r.spoints.empty()) return;
+  LMN_RUN_ALIASES(r);
+  plan_sample_points(r);
+  spoints.assign(4, {});
+  spoints[0].assign(tree0.cols.size(), {0});
+  spoints[1].assign(tree1.cols.size(), {0});
+  spoints[2].assign(tree2.cols.size(), {0});
+  spoints[3].assign(4, {0});
+  for (auto& ci : inst) {
+    int nic = 4 * ci.spec->n_rel;
+    for (int c = nic - 4; c < nic; ++c) spoints[2][ci.inter_start + c] = {r.prev_point_of_log[ci.log_size], 0};
+  }
+  r.eval_jobs.clear();
+  for (int t = 0; t < 4; ++t)
+    for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+      for (int p : spoints[t][c])
+        r.eval_jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p, trees[t]->cols[c].owner});
+}
+
 // Device-resident transcript: the launch that produces the composition tree's root draws the OODS point and expands the
 // sample points' mappings (ChanStep kind 3); everything the device-resident steps produced comes back in one block that
 // step writes to page-locked memory, valid after the wait inside run_oods's eval_at_points.
@@ -74,6 +96,17 @@ void Context::plan_oods_step(ProofRun& r, ChanStep& step) {
   step.maps_out = r.d_maps;
   step.rep_host = reinterpret_cast<uint32_t*>(h_rep);
   step.rep = r.d_report;
+  // the evaluation kernels' job table goes to device memory through the step's workgroup (its lanes fetch it from
+  // page-locked memory next to the plan): no transfer in front of the evaluation
+  plan_eval_jobs(r);
+  const size_t bytes = r.eval_jobs.size() * sizeof(EvalJob);
+  static_assert(sizeof(EvalJob) % 4 == 0, "the job table is copied word by word");
+  EvalJob* pinned = (EvalJob*)pin_alloc(bytes);
+  memcpy(pinned, r.eval_jobs.data(), bytes);
+  r.d_eval_jobs = (EvalJob*)arena_.alloc_bytes(bytes);
+  step.copy_src = reinterpret_cast<const uint32_t*>(pinned);
+  step.copy_dst = reinterpret_cast<uint32_t*>(r.d_eval_jobs);
+  step.copy_words = (uint32_t)(bytes / 4);
 }
 
 void Context::run_oods(ProofRun& r) {
@@ -89,16 +122,7 @@ void Context::run_oods(ProofRun& r) {
     for (size_t p = 1; p < neg_step.size(); ++p) points.push_back(qpt_add_m(oods, neg_step[p]));
   };
   if (!r.dev_fs) set_points(channel.draw_felt());   // (device-resident transcript: run_composition's plan_oods_step)
-  // sample point indices per tree/column, in sampled_values order
-  spoints.assign(4, {});
-  spoints[0].assign(tree0.cols.size(), {0});
-  spoints[1].assign(tree1.cols.size(), {0});
-  spoints[2].assign(tree2.cols.size(), {0});
-  spoints[3].assign(4, {0});
-  for (auto& ci : inst) {
-    int nic = 4 * ci.spec->n_rel;
-    for (int c = nic - 4; c < nic; ++c) spoints[2][ci.inter_start + c] = {prev_point_of_log[ci.log_size], 0};
-  }
+  plan_eval_jobs(r);   // (device-resident transcript: already made by plan_oods_step)
   sampled.assign(4, {});
   if (!shard_.active) {
     // the host is about to wait for the sampled values and is a millisecond ahead of the device: lay out the FRI commit
@@ -113,11 +137,8 @@ void Context::run_oods(ProofRun& r) {
   }
   {
     StageTimer st(this, log, stream_, C_OODS);
-    std::vector<EvalJob> jobs;
-    for (int t = 0; t < 4; ++t)
-      for (size_t c = 0; c < trees[t]->cols.size(); ++c)
-        for (int p : spoints[t][c]) jobs.push_back({trees[t]->cols[c].coeffs, trees[t]->cols[c].log_size, p, trees[t]->cols[c].owner});
-    std::vector<QM31> vals = eval_at_points(jobs, points, comp_log, /*split=*/true, r.dev_fs ? r.d_maps : nullptr, (int)neg_step.size());
+    std::vector<QM31> vals = eval_at_points(r.eval_jobs, points, comp_log, /*split=*/true, r.dev_fs ? r.d_maps : nullptr,
+                                            (int)neg_step.size(), r.dev_fs ? r.d_eval_jobs : nullptr);
     if (r.dev_fs) replay_device_transcript(r, set_points);
     size_t k = 0;
     for (int t = 0; t < 4; ++t) {

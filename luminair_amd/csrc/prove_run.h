@@ -57,6 +57,8 @@ struct ProofRun {
   const DevReport* h_report = nullptr;   // page-locked copy, valid after the wait in run_oods
   QM31* d_coeff = nullptr;               // 16 constraint-slot coefficients per component
   QM31* d_maps = nullptr;                // point mappings for launch_eval_tables
+  std::vector<EvalJob> eval_jobs;        // one per (column, sample point), sampled_values order (plan_eval_jobs)
+  EvalJob* d_eval_jobs = nullptr;        // device copy made by the OODS step's workgroup (device-resident transcript)
   uint32_t bad_mark = 0;                 // this proof's mark of the non-canonical-word verdict
   // OODS: point 0 = the OODS point, then per trace size the point one trace step before it (plan_sample_points)
   std::map<int, int> prev_point_of_log;

@@ -306,6 +306,7 @@ class Context {
   void plan_fri_layout(struct ProofRun& r, int ls0, int smallest_quot_log);   // phase_fri.cpp
   void plan_fri_buffers(struct ProofRun& r);   // phase_fri.cpp
   void plan_sample_points(struct ProofRun& r);   // phase_oods.cpp
+  void plan_eval_jobs(struct ProofRun& r);       // phase_oods.cpp
   void plan_oods_step(struct ProofRun& r, ChanStep& step);   // phase_oods.cpp: ChanStep kind 3 for the composition tree's root
   QuotientArgs make_quotient_args(int ls, const std::vector<const uint32_t*>& cols,
                                   const std::vector<std::vector<std::pair<int, QM31>>>& samples,
@@ -313,8 +314,10 @@ class Context {
   // split: a sharded proof evaluates 1/world of every polynomial's coefficient chunks per rank and all-gathers the
   // partial sums (16 B per sample and rank)
   // d_maps (device, n_points x max(max_log, EVAL_LB) mappings, written by k_chan_root_oods) replaces `points` when given
+  // d_jobs (device copy of `jobs`, already in place) saves the upload
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log,
-                                   bool split = false, const QM31* d_maps = nullptr, int n_points = 0);
+                                   bool split = false, const QM31* d_maps = nullptr, int n_points = 0,
+                                   const EvalJob* d_jobs = nullptr);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
   void begin_op();
