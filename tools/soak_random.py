@@ -25,7 +25,8 @@ ck = CKernels()
 FREE_BITS = [B.PV_MIX_U64_HASHED, B.PV_DRAW_CTR_U32, B.PV_POW_PREFIXED, B.PV_MUL_ONE_SLOT, B.PV_RECIP_TWO_SLOTS, B.PV_RECIP_NEG,
              B.PV_SQRT_TWO_SLOTS, B.PV_SQRT_NEG, B.PV_REM_TWO_SLOTS, B.PV_REM_NEG]
 bad, t0, rows = [], time.time(), 0
-for seed in range(100, 100 + n):
+seed0 = int(os.environ.get("SOAK_SEED0", "100"))   # other seeds than the default run's
+for seed in range(seed0, seed0 + n):
     scale = scales[seed % 4]
     tabs, luts = random_pie(seed, scale)
     rows += sum(len(r) for _, r in tabs)
