@@ -133,7 +133,7 @@ void Context::run_fri_commit(ProofRun& r) {
       if (pend.join) fold(true, dst, false, pend.join, pend.src_log, false, pend.alpha, 1);
       pend.on = false;
     };
-    static const bool fuse_folds = getenv("LMN_NO_FOLD_FUSION") == nullptr;
+    const bool fuse_folds = getenv("LMN_NO_FOLD_FUSION") == nullptr;   // (read per proof: the tests toggle it)
     if (!sh && fuse_folds) {
       pend = {true, true, quots[0].vals, ls0, d_alphas + (n_roots - 1)};
     } else {

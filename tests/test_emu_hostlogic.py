@@ -77,6 +77,9 @@ def test_emu_trees_stored_without_their_register_levels(emu_ctx, name, tabs, mon
     assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
     monkeypatch.setenv("LMN_MERKLE_FULL", "1")
     assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
+    # every FRI fold as a launch of its own (k_fold) instead of inside the next layer's leaf hashing / the tail's launch
+    monkeypatch.setenv("LMN_NO_FOLD_FUSION", "1")
+    assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
 
 
 def test_emu_error_codes(emu_ctx):

@@ -535,6 +535,7 @@ def test_gpu_storage_and_fusion_switches_do_not_change_the_proof(gpu_prover, mon
     tabs = syn.config2_add_only(1 << 20, 42)
     want = _sha(_gpu_bytes(gpu_prover, tabs))
     for env in ({"LMN_MERKLE_FULL": "1"}, {"LMN_MERKLE_BELOW_MIN_LOG": "99"}, {"LMN_NO_JOIN_FUSION": "1"},
+                {"LMN_NO_FOLD_FUSION": "1"},   # every FRI fold a launch of its own
                 {"LMN_HOST_FS": "1"},    # round 5: the transcript of the commitment phases back on the host
                 {"LMN_CHAN_STEP_SEPARATE": "1"}):   # ... or on the device in launches of their own
         for k, v in env.items():
