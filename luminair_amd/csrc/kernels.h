@@ -88,7 +88,7 @@ void launch_chan_mix_root_draw(DevChannel* ch, const uint32_t* root, QM31* out_a
 // in between on a DevChannel and leave what the next kernels need in device memory.  The host replays the same steps on
 // its own Channel once the values have arrived and cross-checks every draw.
 constexpr int CHAN_N_ELEMS = 5;              // relation element sets (prover.h ELEMS_*)
-struct DevElems {                            // z / alpha of every set, written by k_chan_root_elems (or uploaded by the host)
+struct DevElems {                            // z / alpha of every set, written by the ChanStep of kind 1 (or uploaded by the host)
   QM31 z[CHAN_N_ELEMS], alpha[CHAN_N_ELEMS];
 };
 // Everything the host needs back from the device-resident steps, in one place: ONE download at the proof's first wait
@@ -303,7 +303,7 @@ struct LogupArgs {
   const uint32_t* mult[LOGUP_MAX_REL];  // multiplicity column
   int neg[LOGUP_MAX_REL];      // numerator is -mult
   QM31 z[LOGUP_MAX_REL], alpha[LOGUP_MAX_REL];  // element set of each relation (used when d_elems is null)
-  const DevElems* d_elems;     // device-resident draws (k_chan_root_elems): relation j uses set es[j]
+  const DevElems* d_elems;     // device-resident draws (ChanStep kind 1): relation j uses set es[j]
   int es[LOGUP_MAX_REL];
   uint32_t* inter;             // interaction eval columns (4k columns, stride n)
   QM31* last_tmp;              // S_{k-1} per row (AoS), n entries
@@ -344,7 +344,7 @@ struct CompositionArgs {
   const uint32_t* pre2;
   const QM31* claimed_shift;   // device: [claimed, shift]
   QM31 coeff[16];              // alpha^(N-1-k) for this component's constraints, in order
-  const QM31* d_coeff;         // when set: the 16 coefficients are read from device memory (k_chan_claims_root_alpha) instead
+  const QM31* d_coeff;         // when set: the 16 coefficients are read from device memory (ChanStep kind 2) instead
   uint32_t zinv[2];            // 1/Z for rows with (s >> log_size) == 0 / 1
 };
 void launch_composition(const CompositionArgs& a, lmn_stream_t s);

@@ -7,7 +7,7 @@ namespace lmn {
 void Context::run_composition(ProofRun& r) {
   LMN_RUN_ALIASES(r);
   // ---- stwo::prover::prove (prover.rs:312): composition polynomial
-  // (device-resident transcript: the randomness was drawn and every coefficient laid out by k_chan_claims_root_alpha)
+  // (device-resident transcript: the randomness was drawn and every coefficient laid out by the ChanStep of kind 2)
   int n_total = 0;
   for (auto& ci : inst) n_total += constraint_layout(*ci.spec, cfg.protocol_variant).n_protocol;
   std::vector<QM31> powers(std::max(n_total, 1));

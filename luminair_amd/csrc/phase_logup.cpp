@@ -115,7 +115,7 @@ void Context::run_interaction(ProofRun& r) {
     StageTimer st(this, log, stream_, C_INTER_COMMIT);
     if (r.dev_fs) {
       // no wait: the device mixes the claimed sums and the root, draws the composition randomness and lays out every
-      // component's constraint coefficients (k_chan_claims_root_alpha)
+      // component's constraint coefficients (ChanStep kind 2)
       ChanStep step{};
       step.kind = 2;
       ChanCoeffPlan& plan = step.coeff;

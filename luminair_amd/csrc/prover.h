@@ -313,7 +313,7 @@ class Context {
                                   const std::vector<QPt>& points, QM31 quot_alpha, bool alloc_out = true);
   // split: a sharded proof evaluates 1/world of every polynomial's coefficient chunks per rank and all-gathers the
   // partial sums (16 B per sample and rank)
-  // d_maps (device, n_points x max(max_log, EVAL_LB) mappings, written by k_chan_root_oods) replaces `points` when given
+  // d_maps (device, n_points x max(max_log, EVAL_LB) mappings, written by the ChanStep of kind 3) replaces `points` when given
   // d_jobs (device copy of `jobs`, already in place) saves the upload
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log,
                                    bool split = false, const QM31* d_maps = nullptr, int n_points = 0,
