@@ -212,11 +212,12 @@ struct FriTailLayer {
   const uint32_t* itw;         // 1/x twiddles of the line domain of log size L
   uint32_t* merkle[11];        // merkle[l]: 2^l hashes, l = 0..L
 };
-// `pre` (src != null): the tail's first layer does not exist yet - it is the line fold of `src` (2^(first_log+1) values,
-// 1/x twiddles `itw`, folding randomness *alpha), computed by the tail itself (and written to layers[0].vals)
-// (out_mirror != null): when the tail is done it copies the FRI loop's result block (`out_words` words at out_block:
+// What the tail does at its two ends besides its layers.
+// In front (src != null): its first layer does not exist yet - it is the line fold of `src` (2^(first_log+1) values,
+// 1/x twiddles `itw`, folding randomness *alpha), computed by the tail itself (and written to layers[0].vals).
+// Behind (out_mirror != null): when the tail is done it copies the FRI loop's result block (`out_words` words at out_block:
 // roots | alphas | last layer, written by this and the earlier launches) to page-locked memory - no download behind it
-struct FriTailPre {
+struct FriTailIo {
   const uint32_t* src;
   const uint32_t* itw;
   const QM31* alpha;
@@ -225,7 +226,7 @@ struct FriTailPre {
   uint32_t out_words;
 };
 void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
-                     uint32_t* roots_out, lmn_stream_t s, const FriTailPre* pre = nullptr);
+                     uint32_t* roots_out, lmn_stream_t s, const FriTailIo* io = nullptr);
 
 // ---- twiddle tables on the device (a11): entry h of a table of 2^bits entries is the y (coord 0) or x (coord 1)
 // coordinate of the point init + bit_reverse(h, bits) * step of a half coset; sx / sy = step * 2^k.  Four forms are written:

@@ -858,7 +858,7 @@ void launch_chan_step(DevChannel* ch, const ChanStep* step, int step_kind, const
 // alpha, fold.  Every layer's evaluations and tree levels still go to HBM for decommitment.
 // =============================================================================================
 LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, int n_layers, int first_log,
-                      QM31* alphas_out, uint32_t* roots_out, FriTailPre pre) {
+                      QM31* alphas_out, uint32_t* roots_out, FriTailIo pre) {
   LMN_SERIAL_KERNEL();
   LMN_SHARED uint32_t sh[MERKLE_SMALL_BLOCK * 8];
   LMN_SHARED uint32_t shv[MERKLE_SMALL_BLOCK * 4];   // the layer's values, coordinate-major: the fold reads its pair here
@@ -935,9 +935,9 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
 }
 
 void launch_fri_tail(DevChannel* ch, const FriTailLayer* layers, int n_layers, int first_log, QM31* alphas_out,
-                     uint32_t* roots_out, lmn_stream_t s, const FriTailPre* pre) {
+                     uint32_t* roots_out, lmn_stream_t s, const FriTailIo* pre) {
   if (first_log > 10 || n_layers < 1 || n_layers > first_log) throw LmnError(-100, "fri_tail: bad arguments");
-  const FriTailPre p = pre ? *pre : FriTailPre{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+  const FriTailIo p = pre ? *pre : FriTailIo{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   LMN_LAUNCH(k_fri_tail, dim3(1), dim3(MERKLE_SMALL_BLOCK), 0, s, ch, layers, n_layers, first_log, alphas_out,
              roots_out, p);
 }

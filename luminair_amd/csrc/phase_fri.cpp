@@ -141,8 +141,8 @@ void Context::run_fri_commit(ProofRun& r) {
       if (quots[0].sharded && !lay_sh) gather_columns(layer, 1ull << layer_log, 4, (1ull << layer_log) >> g);
     }
     size_t qi = 1;
-    // the line fold that produces the tail's first layer is left to the tail's launch (FriTailPre)
-    FriTailPre tail_pre{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    // the line fold that produces the tail's first layer is left to the tail's launch (FriTailIo)
+    FriTailIo tail_pre{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     const uint32_t* h_out = nullptr;   // the result block on the host: written by the tail itself, or downloaded
     while (layer_log > last_size_log) {
       if (pend.on && layer_log <= 10) materialise(layer);
