@@ -278,7 +278,14 @@ def main(argv=None):
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":   # leave a real debug level alone
         # warnings only, into a per-process file (stdout carries ONE JSON line): dumped to stderr if a multi-GPU step fails
         os.environ["NCCL_DEBUG"] = "WARN"
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/lmn_bench_rccl.%h.%p.log")
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            # a directory of this run's own (ranks started by this process inherit it): a failure report must not pick up
+            # another run's - or another user's - files from a predictable path; removed at exit
+            import atexit, shutil, tempfile
+            run_dir = tempfile.mkdtemp(prefix="lmn_bench_rccl_")
+            os.environ["NCCL_DEBUG_FILE"] = os.path.join(run_dir, "rccl.%h.%p.log")
+            os.environ["LMN_BENCH_RCCL_LOG_DIR"] = run_dir
+            atexit.register(shutil.rmtree, run_dir, True)
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
@@ -635,7 +642,8 @@ def main(argv=None):
 
         def dump_rccl_logs():
             import glob
-            for pth in sorted(glob.glob("/tmp/lmn_bench_rccl.*.log")):
+            log_dir = os.environ.get("LMN_BENCH_RCCL_LOG_DIR")   # only this run's files (main() made the directory)
+            for pth in sorted(glob.glob(os.path.join(log_dir, "rccl.*.log"))) if log_dir else []:
                 try:
                     txt = open(pth).read().strip()
                 except OSError:

@@ -698,6 +698,15 @@ int lmn_batch_prove(lmn_batch* b, uint32_t n, const lmn_table* const* tables, si
     } catch (const LmnError& e) {
       b->last_error = e.what();
       return (e.code == -100 || (e.code <= -1 && e.code >= -10)) ? e.code : LMN_ERR_INTERNAL;
+    } catch (const std::bad_alloc&) {   // (host-built twiddle vectors: nothing may cross the extern "C" boundary)
+      b->last_error = "lmn_batch_prove: out of host memory while preparing the contexts";
+      return LMN_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+      b->last_error = e.what();
+      return LMN_ERR_INTERNAL;
+    } catch (...) {
+      b->last_error = "lmn_batch_prove: unknown exception while preparing the contexts";
+      return LMN_ERR_INTERNAL;
     }
   }
   {

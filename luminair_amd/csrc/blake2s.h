@@ -204,6 +204,141 @@ LMN_HD void b2_compress_fresh(uint32_t out[8], const uint32_t m[16], uint32_t t0
 #endif
 }
 
+// out <- F(h0, m, t0, final) as b2_compress_fresh for a block whose message words m[NZ..15] are ZERO by construction
+// (a Merkle leaf of NZ < 16 columns; a FRI layer's leaf = 4 coordinate words): m[k >= NZ] is never read.
+// Which message word a quarter round adds is fixed by the sigma schedule, so for every one of the 160 message additions
+// it is known at compile time whether it adds zero: those become a two-operand v_add_u32 - an instruction of the class
+// that either issue port takes, issued in the wave's low-priority phase - instead of a v_add3_u32 on the first port, and
+// the zero words hold no registers.  4-column leaves (the composition tree and every FRI layer: 12.6 M of the 36 M
+// compressions of a 2^20-row proof): 120 of 160; 12 columns: 40; 15 columns: 10.  For NZ <= 4 the first half round's
+// columns 2 and 3 are compile-time constants (folded by the compiler: that half round is plain C++).
+#ifdef LMN_B2_HAVE_FRESH
+// One half of a half round (two of the four steps of four independent quarter rounds) as ONE asm statement whose text
+// depends on which of its four message words are zero: the message additions of the non-zero words first (v_add3_u32,
+// first issue port, priority HI), then - at priority LO - the two-operand additions of the zero words and the rest of
+// the phase structure of b2_half.  Operands: %0-3 a, %4-7 b, %8-11 c, %12-15 d, %16-19 message words (a zero word's
+// operand is a dummy and not referenced), %20 LO, %21 HI.  R1 / R2: the two rotation amounts (16, 12 or 8, 7).
+#define LMN_B2_P0_0(a, b, x) "v_add3_u32 " a ", " a ", " b ", " x "\n"
+#define LMN_B2_P0_1(a, b, x) ""
+#define LMN_B2_ANY_0(a, b) ""
+#define LMN_B2_ANY_1(a, b) "v_add_u32 " a ", " a ", " b "\n"
+#define LMN_B2_QSTEP_TEXT(Z0, Z1, Z2, Z3, R1, R2)                                                                      \
+  LMN_B2_P0_##Z0("%0", "%4", "%16") LMN_B2_P0_##Z1("%1", "%5", "%17") LMN_B2_P0_##Z2("%2", "%6", "%18")                \
+  LMN_B2_P0_##Z3("%3", "%7", "%19")                                                                                    \
+  "s_setprio %20\n"                                                                                                    \
+  LMN_B2_ANY_##Z0("%0", "%4") LMN_B2_ANY_##Z1("%1", "%5") LMN_B2_ANY_##Z2("%2", "%6") LMN_B2_ANY_##Z3("%3", "%7")      \
+  "v_xor_b32 %12, %12, %0\n v_xor_b32 %13, %13, %1\n v_xor_b32 %14, %14, %2\n v_xor_b32 %15, %15, %3\n"                \
+  "s_setprio %21\n"                                                                                                    \
+  "v_alignbit_b32 %12, %12, %12, " R1 "\n v_alignbit_b32 %13, %13, %13, " R1 "\n v_alignbit_b32 %14, %14, %14, " R1    \
+  "\n v_alignbit_b32 %15, %15, %15, " R1 "\n"                                                                          \
+  "s_setprio %20\n"                                                                                                    \
+  "v_add_u32 %8, %8, %12\n v_add_u32 %9, %9, %13\n v_add_u32 %10, %10, %14\n v_add_u32 %11, %11, %15\n"                \
+  "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %9\n v_xor_b32 %6, %6, %10\n v_xor_b32 %7, %7, %11\n"                      \
+  "s_setprio %21\n"                                                                                                    \
+  "v_alignbit_b32 %4, %4, %4, " R2 "\n v_alignbit_b32 %5, %5, %5, " R2 "\n v_alignbit_b32 %6, %6, %6, " R2             \
+  "\n v_alignbit_b32 %7, %7, %7, " R2 "\n"
+#define LMN_B2_QSTEP_CASE(Z0, Z1, Z2, Z3)                                                                               \
+  if constexpr (ZP == (Z0 | Z1 << 1 | Z2 << 2 | Z3 << 3)) {                                                             \
+    if constexpr (FIRST)                                                                                                \
+      asm volatile(LMN_B2_QSTEP_TEXT(Z0, Z1, Z2, Z3, "16", "12") LMN_B2_QSTEP_OPERANDS);                                \
+    else                                                                                                                \
+      asm volatile(LMN_B2_QSTEP_TEXT(Z0, Z1, Z2, Z3, "8", "7") LMN_B2_QSTEP_OPERANDS);                                  \
+  }
+#define LMN_B2_QSTEP_OPERANDS                                                                                           \
+  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1), "+v"(c2),       \
+    "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                                                                    \
+  : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "n"(LO), "n"(HI)
+// ZP: bit i = message word w_i is zero (then w_i is not read: callers pass any register)
+template <int LO, int HI, unsigned ZP, bool FIRST>
+__device__ __forceinline__ void b2_qstep_z(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t& b0, uint32_t& b1,
+                                           uint32_t& b2, uint32_t& b3, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                           uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t w0, uint32_t w1,
+                                           uint32_t w2, uint32_t w3) {
+  LMN_B2_QSTEP_CASE(0, 0, 0, 0) LMN_B2_QSTEP_CASE(1, 0, 0, 0) LMN_B2_QSTEP_CASE(0, 1, 0, 0) LMN_B2_QSTEP_CASE(1, 1, 0, 0)
+  LMN_B2_QSTEP_CASE(0, 0, 1, 0) LMN_B2_QSTEP_CASE(1, 0, 1, 0) LMN_B2_QSTEP_CASE(0, 1, 1, 0) LMN_B2_QSTEP_CASE(1, 1, 1, 0)
+  LMN_B2_QSTEP_CASE(0, 0, 0, 1) LMN_B2_QSTEP_CASE(1, 0, 0, 1) LMN_B2_QSTEP_CASE(0, 1, 0, 1) LMN_B2_QSTEP_CASE(1, 1, 0, 1)
+  LMN_B2_QSTEP_CASE(0, 0, 1, 1) LMN_B2_QSTEP_CASE(1, 0, 1, 1) LMN_B2_QSTEP_CASE(0, 1, 1, 1) LMN_B2_QSTEP_CASE(1, 1, 1, 1)
+}
+// ZM: bit 2i = x_i is zero, bit 2i+1 = y_i is zero.  Entered and left at priority HI like b2_half.
+template <int LO, int HI, unsigned ZM>
+__device__ __forceinline__ void b2_half_z(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t& b0, uint32_t& b1,
+                                          uint32_t& b2, uint32_t& b3, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                          uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3, uint32_t x0, uint32_t y0,
+                                          uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+  if constexpr (ZM == 0u) {
+    b2_half<LO, HI>(a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3, x0, y0, x1, y1, x2, y2, x3, y3);
+  } else {
+    constexpr unsigned ZX = (ZM & 1u) | (ZM >> 1 & 2u) | (ZM >> 2 & 4u) | (ZM >> 3 & 8u);
+    constexpr unsigned ZY = (ZM >> 1 & 1u) | (ZM >> 2 & 2u) | (ZM >> 3 & 4u) | (ZM >> 4 & 8u);
+    // (a zero word's operand: the lane's own a_i - a register that is live anyway)
+    b2_qstep_z<LO, HI, ZX, true>(a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3, (ZX & 1u) ? a0 : x0,
+                                 (ZX & 2u) ? a1 : x1, (ZX & 4u) ? a2 : x2, (ZX & 8u) ? a3 : x3);
+    b2_qstep_z<LO, HI, ZY, false>(a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3, (ZY & 1u) ? a0 : y0,
+                                  (ZY & 2u) ? a1 : y1, (ZY & 4u) ? a2 : y2, (ZY & 8u) ? a3 : y3);
+  }
+}
+#define LMN_B2_ZW(s) ((s) >= NZ ? 0u : m[(s) < NZ ? (s) : 0])
+#define LMN_B2_ZM(s0, s1, s2, s3, s4, s5, s6, s7)                                                                      \
+  (((s0) >= NZ ? 1u : 0u) | ((s1) >= NZ ? 2u : 0u) | ((s2) >= NZ ? 4u : 0u) | ((s3) >= NZ ? 8u : 0u) |                 \
+   ((s4) >= NZ ? 16u : 0u) | ((s5) >= NZ ? 32u : 0u) | ((s6) >= NZ ? 64u : 0u) | ((s7) >= NZ ? 128u : 0u))
+#define LMN_B2_HALF_Z(A0, A1, A2, A3, B0, B1, B2, B3, C0, C1, C2, C3, D0, D1, D2, D3, s0, s1, s2, s3, s4, s5, s6, s7)   \
+  b2_half_z<LO, HI, LMN_B2_ZM(s0, s1, s2, s3, s4, s5, s6, s7)>(A0, A1, A2, A3, B0, B1, B2, B3, C0, C1, C2, C3, D0, D1, \
+                                                               D2, D3, LMN_B2_ZW(s0), LMN_B2_ZW(s1), LMN_B2_ZW(s2),   \
+                                                               LMN_B2_ZW(s3), LMN_B2_ZW(s4), LMN_B2_ZW(s5),           \
+                                                               LMN_B2_ZW(s6), LMN_B2_ZW(s7));
+#define LMN_B2_ROUND_Z(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                            \
+  LMN_B2_HALF_Z(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, s0, s1, s2, s3, s4, s5, s6, s7)   \
+  LMN_B2_HALF_Z(v0, v1, v2, v3, v5, v6, v7, v4, v10, v11, v8, v9, v15, v12, v13, v14, s8, s9, s10, s11, s12, s13, s14, s15)
+#endif
+
+template <int NZ, int LO = 0, int HI = LMN_B2_PRIO_HI>
+LMN_HD void b2_compress_fresh_nz(uint32_t out[8], const uint32_t m[16], uint32_t t0) {
+  static_assert(NZ >= 1 && NZ <= 16, "number of leading message words that may be non-zero");
+#ifdef LMN_B2_HAVE_FRESH
+  if constexpr (NZ == 16) {
+    b2_compress_fresh<LO, HI>(out, m, t0);
+  } else {
+    uint32_t v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;
+    if constexpr (NZ >= 8) {
+      b2_half_first<LO, HI>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, m[0], m[1], m[2], m[3],
+                            m[4], m[5], m[6], m[7], 0x510E527Fu ^ t0);
+    } else {
+      // column step of round 0 from the constant initial state: the columns whose two words are zero fold to constants
+      v0 = 0x6A09E667u ^ 0x01010020u; v1 = 0xBB67AE85u; v2 = 0x3C6EF372u; v3 = 0xA54FF53Au;
+      v4 = 0x510E527Fu; v5 = 0x9B05688Cu; v6 = 0x1F83D9ABu; v7 = 0x5BE0CD19u;
+      v8 = 0x6A09E667u; v9 = 0xBB67AE85u; v10 = 0x3C6EF372u; v11 = 0xA54FF53Au;
+      v12 = 0x510E527Fu ^ t0; v13 = 0x9B05688Cu; v14 = 0x1F83D9ABu ^ 0xffffffffu; v15 = 0x5BE0CD19u;
+      LMN_B2_G(v0, v4, v8, v12, LMN_B2_ZW(0), LMN_B2_ZW(1))
+      LMN_B2_G(v1, v5, v9, v13, LMN_B2_ZW(2), LMN_B2_ZW(3))
+      LMN_B2_G(v2, v6, v10, v14, LMN_B2_ZW(4), LMN_B2_ZW(5))
+      LMN_B2_G(v3, v7, v11, v15, LMN_B2_ZW(6), LMN_B2_ZW(7))
+      LMN_B2_ENTER
+    }
+    LMN_B2_HALF_Z(v0, v1, v2, v3, v5, v6, v7, v4, v10, v11, v8, v9, v15, v12, v13, v14, 8, 9, 10, 11, 12, 13, 14, 15)
+    LMN_B2_ROUND_Z(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    LMN_B2_ROUND_Z(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    LMN_B2_ROUND_Z(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    LMN_B2_ROUND_Z(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    LMN_B2_ROUND_Z(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    LMN_B2_ROUND_Z(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    LMN_B2_ROUND_Z(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    LMN_B2_ROUND_Z(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    LMN_B2_ROUND_Z(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    LMN_B2_LEAVE
+    out[0] = (0x6A09E667u ^ 0x01010020u) ^ v0 ^ v8;
+    out[1] = 0xBB67AE85u ^ v1 ^ v9;
+    out[2] = 0x3C6EF372u ^ v2 ^ v10;
+    out[3] = 0xA54FF53Au ^ v3 ^ v11;
+    out[4] = 0x510E527Fu ^ v4 ^ v12;
+    out[5] = 0x9B05688Cu ^ v5 ^ v13;
+    out[6] = 0x1F83D9ABu ^ v6 ^ v14;
+    out[7] = 0x5BE0CD19u ^ v7 ^ v15;
+  }
+#else
+  b2_compress_fresh<LO, HI>(out, m, t0);   // (host / emulation: the caller's zero words are read)
+#endif
+}
+
 // Two independent compressions interleaved statement by statement: 8 independent dependency chains per
 // half-round instead of 4, which keeps the VALU issuing when only ~2 waves share a SIMD.
 #define LMN_B2_G2(a, b, c, d, x, y, A, B, C, D, X, Y) \

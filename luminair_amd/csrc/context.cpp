@@ -313,6 +313,9 @@ void Context::ensure_twiddles(int M) {
 void Context::ensure_twiddles(int M) {
   if (M <= tw_max_log_) return;
   if (M > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
+  // the tables are rebuilt from here on: a build that throws midway (allocation, upload) must not leave the old size in
+  // place, or a later smaller proof would take the early return above and launch with freed / null table pointers
+  tw_max_log_ = 0;
   for (void* p : tw_allocs_) lmn_dev_free(p);
   tw_allocs_.clear();
   twY_.assign(M + 1, nullptr);

@@ -130,8 +130,8 @@ LMN_D void merkle_hash_below(const MerkleSegs& sg, int ncols, uint32_t size, int
     ml[k] = k < 8 ? m[k] : 0u;
     mr[k] = k < 8 ? m[8 + k] : 0u;
   }
-  b2_compress_fresh(hl, ml, 4u * (uint32_t)below_ncols);
-  b2_compress_fresh(hr, mr, 4u * (uint32_t)below_ncols);
+  b2_compress_fresh_nz<8>(hl, ml, 4u * (uint32_t)below_ncols);
+  b2_compress_fresh_nz<8>(hr, mr, 4u * (uint32_t)below_ncols);
   uint32_t m2[16];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -320,15 +320,16 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
     merkle_load_first(prev, sg, ncols, size, i, m);
   }
 }
-template <int MODE>
+// NZ (MODE 1): the leaf has at most NZ columns - message words NZ..15 are zero at compile time (b2_compress_fresh_nz)
+template <int MODE, int NZ = 16>
 LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
                             uint32_t i, uint32_t m[16], uint32_t h[8], const MerkleFold& fold = MerkleFold{}) {
   if (MODE == 4) {
     merkle_hash_below(sg, ncols, size, fold.below_ncols, i, m, h);
   } else if (MODE == 3) {
-    b2_compress_fresh(h, m, 16u);
+    b2_compress_fresh_nz<4>(h, m, 16u);
   } else if (MODE == 1) {
-    b2_compress_fresh(h, m, 4u * (uint32_t)ncols);
+    b2_compress_fresh_nz<NZ>(h, m, 4u * (uint32_t)ncols);
   } else if (MODE == 2) {
     b2_compress_fresh(h, m, 64u);
   } else {
@@ -336,7 +337,7 @@ LMN_D void merkle_hash_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
   }
 }
 
-template <int MODE>
+template <int MODE, int NZ = 16>
 LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int ncols, uint32_t size,
                           MerkleLevels outs, int sub, int nfused, MerkleFold fold) {
   // Wave-cooperative subtree: in batch j lane l hashes start node W0 + 64*j + l (coalesced column
@@ -366,7 +367,7 @@ LMN_KERNEL k_merkle_fused(const uint32_t* __restrict__ prev, MerkleSegs sg, int 
     const uint32_t node = W0 + 64u * j + lane;
     cur_idx = node;
     if (j + 1 < per) merkle_load_mode<MODE, ZT>(prev, sg, ncols, size, node + 64u, mn, fold);
-    merkle_hash_mode<MODE>(prev, sg, ncols, size, node, mc, cur, fold);
+    merkle_hash_mode<MODE, NZ>(prev, sg, ncols, size, node, mc, cur, fold);
     if (outs.p[0]) store_hash(outs.p[0] + (uint64_t)node * 8, cur);
   };
   for (uint32_t j = 0; j < per; j += 2) {
@@ -583,9 +584,19 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
   } else if (fold) {
     if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
     LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
-  } else if (!prev && ncols <= 16 && sg.n[0] == ncols)
-    LMN_LAUNCH(k_merkle_fused<1>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
-  else if (prev && ncols == 0)
+  } else if (!prev && ncols <= 16 && sg.n[0] == ncols) {
+    // the leaf's zero message words are compile-time zeros of the instantiation (blake2s.h b2_compress_fresh_nz)
+    if (ncols <= 4)
+      LMN_LAUNCH((k_merkle_fused<1, 4>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    else if (ncols <= 8)
+      LMN_LAUNCH((k_merkle_fused<1, 8>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    else if (ncols <= 12)
+      LMN_LAUNCH((k_merkle_fused<1, 12>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    else if (ncols <= 15)
+      LMN_LAUNCH((k_merkle_fused<1, 15>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    else
+      LMN_LAUNCH((k_merkle_fused<1, 16>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+  } else if (prev && ncols == 0)
     LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
   else
     LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
@@ -905,7 +916,7 @@ LMN_KERNEL k_fri_tail(DevChannel* ch, const FriTailLayer* __restrict__ layers, i
       shv[MERKLE_SMALL_BLOCK + i] = mine.b;
       shv[2 * MERKLE_SMALL_BLOCK + i] = mine.c;
       shv[3 * MERKLE_SMALL_BLOCK + i] = mine.d;
-      b2_compress_fresh(cur, m, 16u);
+      b2_compress_fresh_nz<4>(cur, m, 16u);
       store_hash(ly.merkle[L] + (uint64_t)i * 8, cur);
 #pragma unroll
       for (int k = 0; k < 8; ++k) sh[k * MERKLE_SMALL_BLOCK + i] = cur[k];   // word-major (merkle_lds_level)

@@ -12,7 +12,8 @@ namespace lmn {
 void Context::plan_fri_layout(ProofRun& r, int ls0, int smallest_quot_log) {
   ProofRun::FriPlan& fp = r.fri;
   const int lb = r.lb;
-  fp.last_size_log = std::min((int)cfg.log_last_layer + lb, ls0 - 1);   // (a trace smaller than the configured last layer stops at its first line)
+  fp.last_size_log = (int)cfg.log_last_layer + lb;   // <= ls0 - 1: run_setup refuses a trace smaller than the last layer
+  if (fp.last_size_log > ls0 - 1) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "FRI: first line layer smaller than the last layer");
   fp.max_layers = ls0 + 1;
   const size_t root_words = (size_t)fp.max_layers * 8, alpha_words = (size_t)fp.max_layers * 4;
   const size_t last_words = 4ull << fp.last_size_log;

@@ -46,7 +46,11 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
       if (std::uncaught_exceptions() <= pending) return;
       c->grp_pin_ = c->grp_dev_ = nullptr;
       c->grp_cap_ = c->grp_off_ = 0;
-#if !defined(LMN_BATCH) && !defined(LMN_EMU)
+#if defined(LMN_BATCH) && !defined(LMN_EMU)
+      // decided at run time: the batch library also exports the solo entry points (lmn_prove / lmn_prove_submit), whose
+      // threads are outside any lock-step group and must drain like the main library's
+      if (tls_batch_group == nullptr) (void)hipStreamSynchronize(c->stream_);
+#elif !defined(LMN_EMU)
       (void)hipStreamSynchronize(c->stream_);
 #endif
     }
@@ -120,6 +124,11 @@ void Context::run_setup(ProofRun& r) {
     int ls = 0;
     while ((1ull << ls) < size) ++ls;
     if (ls + lb + 2 > MAX_LOG - 2) throw LmnError(LMN_ERR_INVALID_ARGUMENT, "trace too large");
+    // A column of 2^(ls + lb) evaluations joins the FRI line layer of 2^(ls + lb - 1); stwo's commit loop ends at the
+    // last layer of 2^(log_last_layer + lb) values and asserts that every column has been consumed by then: a table
+    // of 2^log_last_layer rows or fewer cannot be proved under this PcsConfig (the reference panics)
+    if (ls <= (int)cfg.log_last_layer)
+      throw LmnError(LMN_ERR_INVALID_ARGUMENT, "a table needs more than 2^log_last_layer rows (after padding)");
     infos.push_back({sp, tb.n_rows, ls, tb.rows, (tb.flags & LMN_TABLE_ROWS_ON_DEVICE) != 0});
     max_log = std::max(max_log, ls);
     uint64_t cells = (uint64_t)(sp->n_cols + 4 * sp->n_rel) << ls;

@@ -260,8 +260,19 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     }
     if (!ok) {
       if (code == LMN_ERR_INVALID_LOGUP) throw LmnError(LMN_ERR_INVALID_LOGUP, what);
-      fail(what);
+      ::lmn::fail(what);
     }
+  };
+  // a structural stop (the replay cannot go on): in diagnose mode it is recorded as a failed LMN_CHECK_SHAPE before the
+  // throw, so that a plain config or shape mismatch is not read as a transcript-encoding disagreement (pinning.py)
+  auto fail = [&](const std::string& what) {
+    if (rep) {
+      rep->checks_run |= LMN_CHECK_SHAPE;
+      rep->checks_passed &= ~LMN_CHECK_SHAPE;
+      rep->checks_failed |= LMN_CHECK_SHAPE;
+      if (!rep->first_failure[0]) snprintf(rep->first_failure, sizeof rep->first_failure, "%s", what.c_str());
+    }
+    ::lmn::fail(what);
   };
   auto step = [&](uint32_t id, uint32_t index, const Channel& ch) {
     if (!rep || rep->n_steps >= LMN_MAX_TRANSCRIPT_STEPS) return;
@@ -270,7 +281,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
     st.index = index;
     memcpy(st.digest, ch.digest().w, 32);
   };
-  if (expect.log_blowup < 1 || expect.log_blowup > 3 || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
+  if (expect.log_blowup < 1 || expect.log_blowup > 3 /* what the prover accepts (context.cpp); oracle/verifier.py alike */ || expect.n_queries == 0 || expect.n_queries > 1024 || expect.log_last_layer > 10 ||
       expect.pow_bits > 40)
     throw LmnError(LMN_ERR_INVALID_ARGUMENT, "bad expected PCS config");
   const int n_slots = claim_slots(variant);
@@ -429,7 +440,7 @@ void verify_proof(const uint8_t* data, size_t len, const lmn_config& expect, con
   if (p.last_layer_coeffs.size() != (size_t)1 << p.log_last_layer) fail("last layer degree");
   ch.mix_felts(p.last_layer_coeffs);
   step(LMN_STEP_FRI_LAST_LAYER, 0, ch);
-  if (rep) rep->checks_passed |= LMN_CHECK_SHAPE;   // every shape the transcript depends on was as the claim implies
+  if (rep && !(rep->checks_failed & LMN_CHECK_SHAPE)) rep->checks_passed |= LMN_CHECK_SHAPE;   // every shape the transcript depends on was as the claim implies
   check(LMN_CHECK_POW, ch.verify_pow_nonce(p.pow_bits, p.proof_of_work), "ProofOfWork");
   ch.mix_u64(p.proof_of_work);
   step(LMN_STEP_POW_NONCE, 0, ch);

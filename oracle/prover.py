@@ -558,6 +558,9 @@ def prove(tables: Sequence[Tuple[int, np.ndarray]], config: PcsConfig = PcsConfi
     qi = 1
     inner = []
     last_size = 1 << (config.log_last_layer + lb)
+    if K.secure_len(layer) < last_size:
+        # stwo's commit_last_layer asserts len == last_layer_domain_size: the reference panics here
+        raise ProvingError("FRI: first line layer smaller than the last layer (largest table < 2^log_last_layer rows)")
     while K.secure_len(layer) > last_size:
         mt = K.secure_merkle([layer])
         channel.mix_root(mt.root())

@@ -116,7 +116,7 @@ def verify(proof: LuminairProof, variant: ProtocolVariant = ProtocolVariant.KAT,
         raise VerificationError("expected 4 commitments")
     if (s.pow_bits, s.log_blowup, s.log_last_layer, s.n_queries) != tuple(config):
         raise VerificationError("proof was made for a different PCS config than the verifier's")
-    if not (0 < s.n_queries <= 1024) or s.log_last_layer > 10 or not (1 <= s.log_blowup <= 4):
+    if not (0 < s.n_queries <= 1024) or s.log_last_layer > 10 or not (1 <= s.log_blowup <= 3):
         raise VerificationError("bad PCS config")
     if s.last_layer_log_size != s.log_last_layer:
         raise VerificationError("last layer degree bound")

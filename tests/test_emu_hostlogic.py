@@ -369,6 +369,31 @@ def test_emu_non_default_pcs_config_matches_oracle(root, pow_bits, log_last_laye
             lib.verify(got, backend.VARIANT_KAT)           # the default verifier expects PcsConfig::default()
 
 
+def test_emu_trace_smaller_than_the_last_fri_layer_is_refused(root):
+    """a 16-row table under log_last_layer = 10 has a first line layer (2^5) below the configured last layer
+    (2^11), and a 2^10-row table's columns would join a line layer below the last one: stwo's FRI commit asserts both and
+    the reference panics; the library refuses such a pie up front (the plan and the loop used to disagree about a
+    clamped size) and the oracle raises too."""
+    from oracle.prover import PcsConfig, ProvingError
+    lib = backend.Library(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
+    cfg = lib.default_config()
+    cfg.log_last_layer = 10
+    ctx = backend.Context(0, cfg, lib)
+    tabs = syn.simple_example()
+    for bad in (tabs, syn.config2_add_only(1 << 10, 3)):
+        with pytest.raises(backend.LuminairBackendError) as e:
+            ctx.prove_tables([(k, r, len(r)) for k, r in bad])
+        assert e.value.code == backend.ERR_INVALID_ARGUMENT
+        with pytest.raises(ProvingError):
+            oracle_prove([(k, r.astype(np.uint64)) for k, r in bad], PcsConfig(log_last_layer=10))
+    # the context stays usable, and the smallest admissible table (2^11 rows: its columns join the last layer) proves
+    tabs_ok = syn.config2_add_only(1 << 11, 3)
+    got = ctx.prove_tables([(k, r, len(r)) for k, r in tabs_ok])
+    ctx.close()
+    assert got == to_bincode(oracle_prove([(k, r.astype(np.uint64)) for k, r in tabs_ok], PcsConfig(log_last_layer=10)))
+    lib.verify(got, backend.VARIANT_KAT, config=cfg)
+
+
 def test_emu_prove_submit_wait(root):
     """`lmn_prove_submit` / `lmn_prove_wait`: the asynchronous form for single-threaded callers (the reference's
     `prove` is a plain function call, prover.rs:28) - same bytes and same error codes as `lmn_prove`, one outstanding
