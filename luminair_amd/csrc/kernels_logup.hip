@@ -18,10 +18,10 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
     QM31 den[K], pre[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      QM31 d = q_from_m(a.val[j][r]);
+      QM31 d = q_from_m(ld_ub(a.val[j], r));   // (uniform column bases + the row as a 32-bit lane offset: kernels_common.h)
       // relation elements: kernel arguments, or the device-resident draws (a.d_elems is launch-uniform)
       const QM31 ez = a.d_elems ? a.d_elems->z[a.es[j]] : a.z[j];
-      if (a.id[j]) d = q_add(d, q_mul_m(a.d_elems ? a.d_elems->alpha[a.es[j]] : a.alpha[j], a.id[j][r]));
+      if (a.id[j]) d = q_add(d, q_mul_m(a.d_elems ? a.d_elems->alpha[a.es[j]] : a.alpha[j], ld_ub(a.id[j], r)));
       d = q_sub(d, ez);
       den[j] = d;
       pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
@@ -35,15 +35,15 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      uint32_t mlt = a.mult[j][r];
+      uint32_t mlt = ld_ub(a.mult[j], r);
       if (a.neg[j]) mlt = m_neg(mlt);
       S = q_add(S, q_mul_m(invs[j], mlt));
       if (j < K - 1) {
-        uint32_t* o = a.inter + (uint64_t)(4 * j) * a.n + r;
-        o[0] = S.a;
-        o[(uint64_t)a.n] = S.b;
-        o[(uint64_t)2 * a.n] = S.c;
-        o[(uint64_t)3 * a.n] = S.d;
+        uint32_t* o = a.inter + (uint64_t)(4 * j) * a.n;
+        st_ub(o, r, S.a);
+        st_ub(o + (uint64_t)a.n, r, S.b);
+        st_ub(o + (uint64_t)2 * a.n, r, S.c);
+        st_ub(o + (uint64_t)3 * a.n, r, S.d);
       }
     }
     a.last_tmp[r] = S;

@@ -55,7 +55,6 @@ LMN_D const uint32_t* merkle_col_ptr(const MerkleSegs& sg, int c, uint64_t size)
   if (c < n2) return sg.base[2] + (uint64_t)(c - n1) * size;
   return sg.base[3] + (uint64_t)(c - n2) * size;
 }
-
 // First 16 message words of start-level node i: the two child hashes when the level has a `prev`
 // layer, else its first 16 columns (zero padded).  Split from the hashing so that callers can issue the
 // loads of the next node before compressing the current one.
@@ -109,12 +108,10 @@ LMN_D void merkle_hash_start(const uint32_t* __restrict__ prev, const MerkleSegs
 // MerkleFold::below: raw words of leaves 2i (m[0..7]) and 2i+1 (m[8..15]) of the level under the start level
 LMN_D void merkle_load_below(const uint32_t* __restrict__ below, int below_ncols, uint32_t size, uint32_t i, uint32_t m[16]) {
   const uint64_t L = 2ull * size;
-  const uint32_t* __restrict__ bp = below + 2ull * i;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < below_ncols) {
-      m[k] = bp[(uint64_t)k * L];
-      m[8 + k] = bp[(uint64_t)k * L + 1];
+      ld_ub_pair(below + (uint64_t)k * L, i, m[k], m[8 + k]);   // leaves 2i and 2i+1 of column k: one 8-byte access
     } else {
       m[k] = 0u;
       m[8 + k] = 0u;
@@ -271,25 +268,29 @@ template <int MODE, bool ZT = false>
 LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs& sg, int ncols, uint32_t size,
                             uint32_t i, uint32_t m[16], const MerkleFold& fold = MerkleFold{}) {
   if (MODE == 3) {
-    // leaf i of a FRI layer = fold of the pair (2i, 2i+1) of the previous layer (same arithmetic as k_fold)
+    // leaf i of a FRI layer = fold of the pair (2i, 2i+1) of the previous layer (same arithmetic as k_fold); the layer's
+    // coordinate columns are block-uniform bases, the pair is one 8-byte buffer access per coordinate (kernels_common.h)
     const uint64_t L = 2ull * size;
-    const uint32_t* __restrict__ sp = fold.src + 2ull * i;
-    const QM31 a{sp[0], sp[L], sp[2 * L], sp[3 * L]};
-    const QM31 b{sp[1], sp[L + 1], sp[2 * L + 1], sp[3 * L + 1]};
+    QM31 a, b;
+    ld_ub_pair(fold.src, i, a.a, b.a);
+    ld_ub_pair(fold.src + L, i, a.b, b.b);
+    ld_ub_pair(fold.src + 2 * L, i, a.c, b.c);
+    ld_ub_pair(fold.src + 3 * L, i, a.d, b.d);
     const QM31 alpha = *fold.alpha;
-    QM31 r = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), fold.itw[i])));
+    QM31 r = q_add(q_add(a, b), q_mul(alpha, q_mul_m(q_sub(a, b), ld_ub(fold.itw, i))));
     if (fold.src2) {   // block-uniform: a quotient column joins this layer (k_fold with accumulate = 1)
-      const uint32_t* __restrict__ sq = fold.src2 + 2ull * i;
-      const QM31 c{sq[0], sq[L], sq[2 * L], sq[3 * L]};
-      const QM31 d{sq[1], sq[L + 1], sq[2 * L + 1], sq[3 * L + 1]};
-      const QM31 rc = q_add(q_add(c, d), q_mul(alpha, q_mul_m(q_sub(c, d), fold.itw2[i])));
+      QM31 c, d;
+      ld_ub_pair(fold.src2, i, c.a, d.a);
+      ld_ub_pair(fold.src2 + L, i, c.b, d.b);
+      ld_ub_pair(fold.src2 + 2 * L, i, c.c, d.c);
+      ld_ub_pair(fold.src2 + 3 * L, i, c.d, d.d);
+      const QM31 rc = q_add(q_add(c, d), q_mul(alpha, q_mul_m(q_sub(c, d), ld_ub(fold.itw2, i))));
       r = q_add(q_mul(r, q_mul(alpha, alpha)), rc);
     }
-    uint32_t* __restrict__ o = fold.dst + i;
-    o[0] = r.a;
-    o[(uint64_t)size] = r.b;
-    o[2ull * size] = r.c;
-    o[3ull * size] = r.d;
+    st_ub(fold.dst, i, r.a);
+    st_ub(fold.dst + (uint64_t)size, i, r.b);
+    st_ub(fold.dst + 2ull * size, i, r.c);
+    st_ub(fold.dst + 3ull * size, i, r.d);
     m[0] = r.a;
     m[1] = r.b;
     m[2] = r.c;
@@ -299,11 +300,11 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
       for (int k = 4; k < 16; ++k) m[k] = 0u;
     }
   } else if (MODE == 1) {
-    const uint32_t* __restrict__ base = sg.base[0] + i;
+    const uint32_t* __restrict__ base = sg.base[0];   // block-uniform column bases + the leaf as a 32-bit lane offset
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       if (k < ncols)
-        m[k] = base[(uint64_t)k * size];
+        m[k] = ld_col(base, k, size, i);
       else if (!ZT)
         m[k] = 0u;
     }

@@ -69,7 +69,7 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const CompEl
   QM31 prev = q_zero();
 #pragma unroll
   for (int j = 0; j < NREL; ++j) {
-    QM31 cur = load_secure(a.inter + (uint64_t)(4 * j) * a.stride, a.stride, t);
+    QM31 cur = load_secure_ub(a.inter + (uint64_t)(4 * j) * a.stride, a.stride, t);
     QM31 den = rc[j] == 1   ? q_sub(q_from_m(val[j]), ce.z2)
                : rc[j] == 2 ? q_sub(q_add_m(q_mul_m(ce.alpha2, id[j]), val[j]), ce.z2)
                             : q_sub(q_add_m(q_mul_m(ce.alpha, id[j]), val[j]), ce.z);
@@ -78,7 +78,7 @@ LMN_D void logup_constraints(ConsAcc& ca, const CompositionArgs& a, const CompEl
       diff = q_sub(cur, prev);
     } else {
       uint32_t ps = prev_row_storage(s, a.eval_log, a.log_size);
-      QM31 pr = load_secure(a.prev_last, E, ps);
+      QM31 pr = load_secure_ub(a.prev_last, E, ps);
       diff = q_add(q_sub(q_sub(cur, pr), prev), a.claimed_shift[1]);
     }
     ca.add_q(q_sub_m(q_mul(diff, den), neg ? m_neg(mult[j]) : mult[j]));
@@ -96,9 +96,9 @@ LMN_KERNEL k_composition(CompositionArgs a) {
   ConsAcc ca{qacc_zero(), a.d_coeff ? a.d_coeff : a.coeff, 0};
   const CompElems ce = a.d_elems ? CompElems{a.d_elems->z[0], a.d_elems->alpha[0], a.d_elems->z[a.es2], a.d_elems->alpha[a.es2]}
                                  : CompElems{a.z, a.alpha, a.z2, a.alpha2};
-  const uint32_t* __restrict__ mn = a.main + t;
+  const uint32_t* __restrict__ mn = a.main;   // wave-uniform column bases, the row as a 32-bit lane offset (ld_ub)
   const uint64_t cstride = a.stride;
-#define LMN_COL(k) mn[(uint64_t)(k) * cstride]
+#define LMN_COL(k) ld_col(mn, (k), cstride, t)
   if (KIND == 0 || KIND == 1) {
     // Add (15 cols) / Mul (16 cols: rem inserted at 12)
     constexpr bool mul = KIND == 1;
@@ -181,13 +181,13 @@ LMN_KERNEL k_composition(CompositionArgs a) {
     logup_constraints<7>(ca, a, ce, rm, rv, ri, rc, false, s, t, E);
   } else if (KIND == 14) {
     // RangeCheckLookup: multiplicity column + preprocessed LUT column, relation (-multiplicity, [lut])
-    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {0u};
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {ld_ub(a.pre, t)}, ri[1] = {0u};
     const int rc[1] = {1};
     logup_constraints<1>(ca, a, ce, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 4) {
     // SinLookup / Exp2Lookup / Log2Lookup (lookups/sin/component.rs:40-59): multiplicity column + the two
     // preprocessed LUT columns, relation (-multiplicity, [lut_0, lut_1])
-    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {a.pre[t]}, ri[1] = {a.pre2[t]};
+    const uint32_t rm[1] = {LMN_COL(0)}, rv[1] = {ld_ub(a.pre, t)}, ri[1] = {ld_ub(a.pre2, t)};
     const int rc[1] = {2};
     logup_constraints<1>(ca, a, ce, rm, rv, ri, rc, true, s, t, E);
   } else if (KIND == 3) {
@@ -246,17 +246,16 @@ LMN_KERNEL k_composition(CompositionArgs a) {
   }
 #undef LMN_COL
   QM31 r = q_mul_m(qacc_reduce(ca.acc), a.zinv[(s >> a.log_size) & 1u]);
-  uint32_t* o = a.out + s;
   if (a.accumulate) {
-    r.a = m_add(r.a, o[0]);
-    r.b = m_add(r.b, o[E]);
-    r.c = m_add(r.c, o[2 * E]);
-    r.d = m_add(r.d, o[3 * E]);
+    r.a = m_add(r.a, ld_ub(a.out, s));
+    r.b = m_add(r.b, ld_ub(a.out + E, s));
+    r.c = m_add(r.c, ld_ub(a.out + 2 * E, s));
+    r.d = m_add(r.d, ld_ub(a.out + 3 * E, s));
   }
-  o[0] = r.a;
-  o[E] = r.b;
-  o[2 * E] = r.c;
-  o[3 * E] = r.d;
+  st_ub(a.out, s, r.a);
+  st_ub(a.out + E, s, r.b);
+  st_ub(a.out + 2 * E, s, r.c);
+  st_ub(a.out + 3 * E, s, r.d);
 }
 
 void launch_composition(const CompositionArgs& a, lmn_stream_t s) {
@@ -357,7 +356,7 @@ LMN_KERNEL k_eval_at_point(const EvalJob* __restrict__ jobs, const QM31* __restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t lo = threadIdx.x + (uint32_t)k * TPB;
-      cv[hh][k] = (hh < hpc && lo < lo_n) ? cp[lo] : 0u;
+      cv[hh][k] = (hh < hpc && lo < lo_n) ? ld_ub(cp, lo) : 0u;   // (block-uniform run of coefficients: kernels_common.h)
     }
   }
 #pragma unroll
@@ -493,12 +492,24 @@ LMN_KERNEL k_quotients_occ(QuotientArgs a) { quotients_body<NB>(a); }
 template <int NB>
 LMN_D void quotients_body(const QuotientArgs& a) {
   constexpr int QUOT_ROWS = quot_rows<NB>();
+#if defined(LMN_QUOT_TAB_LDS) || defined(LMN_EMU) || !defined(__HIP_DEVICE_COMPILE__)
   // (column pointer, alpha^k * c) table staged once per block in LDS: the per-column loop then
   // reads wave-uniform LDS words instead of chasing pointers through global memory
   LMN_SHARED QuotEntry tab[QUOT_MAX_ENTRIES];
   const int nent = a.batch_start[NB];
   for (int e = threadIdx.x; e < nent; e += blockDim.x) tab[e] = a.entries[e];
   __syncthreads();
+#define LMN_QCOL(e, row) tab[e].col[row]
+#else
+#define LMN_QCOL(e, row) ld_ub(tab[e].col, row)
+  // The (column pointer, alpha^k * c) table is read through the SCALAR cache (constant address space: nothing writes it
+  // during the launch): a column's base address and its coefficient arrive in SGPRs, so the column load takes an SGPR
+  // base + the row as a 32-bit lane offset (no 64-bit vector address per load, one v_lshl_add_u64 of ~10 instructions per
+  // column and row before) and the multiply-accumulates take the coefficient as their scalar operand; the LDS copy of
+  // the table (a ds_read_b64 + ds_read_b128 per column and row group) is gone.
+  typedef const QuotEntry __attribute__((address_space(4))) * ConstTab;
+  const ConstTab tab = (ConstTab)(uintptr_t)a.entries;
+#endif
   const uint32_t Q = (1u << a.log_rows) / QUOT_ROWS;
   const uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x;  // row inside the block handled by this launch
   if (s0 >= Q) return;
@@ -540,8 +551,8 @@ LMN_D void quotients_body(const QuotientArgs& a) {
       const int k1 = a.batch_start[b + 1];
       int kk = a.batch_start[b];
       for (; kk + 6 <= k1; kk += 6) {
-        uint32_t f0 = tab[kk].col[s], f1 = tab[kk + 1].col[s], f2 = tab[kk + 2].col[s];
-        uint32_t f3 = tab[kk + 3].col[s], f4 = tab[kk + 4].col[s], f5 = tab[kk + 5].col[s];
+        uint32_t f0 = LMN_QCOL(kk, s), f1 = LMN_QCOL(kk + 1, s), f2 = LMN_QCOL(kk + 2, s);
+        uint32_t f3 = LMN_QCOL(kk + 3, s), f4 = LMN_QCOL(kk + 4, s), f5 = LMN_QCOL(kk + 5, s);
         LMN_QPHASE_PORT0();
         qacc_mad(acc, tab[kk].c, f0);
         qacc_mad(acc, tab[kk + 1].c, f1);
@@ -556,7 +567,7 @@ LMN_D void quotients_body(const QuotientArgs& a) {
         qacc_fold(acc);
       }
       for (; kk < k1; ++kk) {
-        qacc_mad(acc, tab[kk].c, tab[kk].col[s]);
+        qacc_mad(acc, tab[kk].c, LMN_QCOL(kk, s));
         qacc_fold(acc);
       }
       QM31 num = qacc_reduce(acc);
@@ -570,6 +581,7 @@ LMN_D void quotients_body(const QuotientArgs& a) {
     o[2ull * a.out_stride] = row.c;
     o[3ull * a.out_stride] = row.d;
   }
+#undef LMN_QCOL
 }
 
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {

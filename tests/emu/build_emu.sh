@@ -1,10 +1,21 @@
 #!/bin/bash
 # Builds the TEST-ONLY emulation library (same sources, LMN_EMU): tests/emu/libluminair_emu.so
+#   build_emu.sh            the plain build the CPU suite loads
+#   build_emu.sh asan       libluminair_emu_asan.so: -fsanitize=address,undefined (load with LD_PRELOAD=libasan.so)
+#   build_emu.sh tsan       libluminair_emu_tsan.so: -fsanitize=thread           (load with LD_PRELOAD=libtsan.so)
+# (tests/test_sanitizers.py drives the sanitizer builds; emu_runtime.cpp announces its fiber switches to them)
 set -e
 cd "$(dirname "$0")"
 SRC=../../luminair_amd/csrc
-g++ -std=c++20 -O2 -g -fPIC -shared -DLMN_EMU -Wall -Wno-unused-function -Wno-unknown-pragmas \
-  -x c++ $SRC/kernels_trace.hip -x c++ $SRC/kernels_fft.hip -x c++ $SRC/kernels_merkle.hip -x c++ $SRC/kernels_logup.hip -x c++ $SRC/kernels_quotient.hip -x c++ $SRC/fft_fixed.hip -x c++ $SRC/components.cpp -x c++ $SRC/context.cpp -x c++ $SRC/trace_gen.cpp -x c++ $SRC/commit.cpp -x c++ $SRC/oods.cpp -x c++ $SRC/decommit.cpp -x c++ $SRC/quotients.cpp -x c++ $SRC/prove.cpp -x c++ $SRC/phase_trace.cpp -x c++ $SRC/phase_logup.cpp -x c++ $SRC/phase_composition.cpp -x c++ $SRC/phase_oods.cpp -x c++ $SRC/phase_fri.cpp -x c++ $SRC/phase_decommit.cpp -x c++ $SRC/shard.cpp -x c++ $SRC/ops.cpp -x c++ $SRC/verifier.cpp -x c++ $SRC/capi.cpp -x c++ $SRC/level2.cpp -x c++ emu_runtime.cpp \
-  -o libluminair_emu.so
-g++ -std=c++17 -O2 -fPIC -shared -Wall stub_rccl.cpp -o libstub_rccl.so -lrt
-echo built tests/emu/libluminair_emu.so
+case "${1:-}" in
+  asan) OPT="-O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined"; OUT=libluminair_emu_asan.so ;;
+  tsan) OPT="-O1 -g -fno-omit-frame-pointer -fsanitize=thread"; OUT=libluminair_emu_tsan.so ;;
+  "") OPT="-O2 -g"; OUT=libluminair_emu.so ;;
+  *) echo "usage: build_emu.sh [asan|tsan]"; exit 2 ;;
+esac
+UNITS="kernels_trace.hip kernels_fft.hip kernels_merkle.hip kernels_logup.hip kernels_quotient.hip fft_fixed.hip components.cpp context.cpp trace_gen.cpp commit.cpp oods.cpp decommit.cpp quotients.cpp prove.cpp phase_trace.cpp phase_logup.cpp phase_composition.cpp phase_oods.cpp phase_fri.cpp phase_decommit.cpp shard.cpp ops.cpp verifier.cpp capi.cpp level2.cpp"
+ARGS=""
+for u in $UNITS; do ARGS="$ARGS -x c++ $SRC/$u"; done
+g++ -std=c++20 $OPT -fPIC -shared -DLMN_EMU -Wall -Wno-unused-function -Wno-unknown-pragmas $ARGS -x c++ emu_runtime.cpp -o $OUT
+[ -z "${1:-}" ] && g++ -std=c++17 -O2 -fPIC -shared -Wall stub_rccl.cpp -o libstub_rccl.so -lrt
+echo built tests/emu/$OUT

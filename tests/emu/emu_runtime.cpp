@@ -3,7 +3,19 @@
 // against the oracle on a machine without a GPU.  Never linked into the product library.
 #include <ucontext.h>
 
+#include <mutex>
 #include <vector>
+
+// Sanitizer builds (tests/emu/build_emu.sh asan | tsan): the sanitizers must be told about every stack switch, or
+// AddressSanitizer reads a fiber's frames as overflows of the thread's stack and ThreadSanitizer its shadow stack as corrupt
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define LMN_EMU_ASAN 1
+#endif
+#if defined(__SANITIZE_THREAD__)
+#include <sanitizer/tsan_interface.h>
+#define LMN_EMU_TSAN 1
+#endif
 
 #include "../../luminair_amd/csrc/platform.h"
 
@@ -18,23 +30,72 @@ struct Fiber {
   ucontext_t ctx;
   bool done;
   uint3e tid;
+#ifdef LMN_EMU_ASAN
+  void* fake_stack = nullptr;
+#endif
+#ifdef LMN_EMU_TSAN
+  void* tsan_fiber = nullptr;
+#endif
 };
 ucontext_t g_main;
 std::vector<Fiber> g_fibers;
 std::vector<unsigned char> g_stacks;
 const std::function<void()>* g_body = nullptr;
 int g_cur = -1;
+#ifdef LMN_EMU_ASAN
+void* g_main_fake = nullptr;
+const void* g_main_bottom = nullptr;
+size_t g_main_size = 0;
+#endif
+#ifdef LMN_EMU_TSAN
+void* g_main_tsan = nullptr;
+#endif
+
+// fiber -> scheduler (`last`: the fiber never runs again)
+void to_main(Fiber& f, bool last) {
+#ifdef LMN_EMU_ASAN
+  __sanitizer_start_switch_fiber(last ? nullptr : &f.fake_stack, g_main_bottom, g_main_size);
+#endif
+#ifdef LMN_EMU_TSAN
+  __tsan_switch_to_fiber(g_main_tsan, 0);
+#endif
+  swapcontext(&f.ctx, &g_main);
+#ifdef LMN_EMU_ASAN
+  __sanitizer_finish_switch_fiber(f.fake_stack, &g_main_bottom, &g_main_size);
+#endif
+}
+// scheduler -> fiber
+void to_fiber(Fiber& f, void* stack, size_t stack_bytes) {
+#ifdef LMN_EMU_ASAN
+  __sanitizer_start_switch_fiber(&g_main_fake, stack, stack_bytes);
+#endif
+#ifdef LMN_EMU_TSAN
+  __tsan_switch_to_fiber(f.tsan_fiber, 0);
+#endif
+  swapcontext(&g_main, &f.ctx);
+#ifdef LMN_EMU_ASAN
+  __sanitizer_finish_switch_fiber(g_main_fake, nullptr, nullptr);
+#endif
+}
 
 void trampoline() {
+#ifdef LMN_EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_main_bottom, &g_main_size);
+#endif
   (*g_body)();
   g_fibers[g_cur].done = true;
-  swapcontext(&g_fibers[g_cur].ctx, &g_main);
+  to_main(g_fibers[g_cur], true);
 }
 }  // namespace
 
-void lmn_emu_syncthreads() { swapcontext(&g_fibers[g_cur].ctx, &g_main); }
+void lmn_emu_syncthreads() { to_main(g_fibers[g_cur], false); }
 
 void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem) {
+  // one emulated launch at a time in the process (the fibers, their stacks and the kernels' `static` shared arrays are
+  // global): contexts driven from several host threads run their HOST code concurrently - which is what the thread
+  // sanitizer build is for - and take turns on the "device"
+  static std::mutex device_mu;
+  std::lock_guard<std::mutex> device_lock(device_mu);
   const unsigned nthreads = block.x * block.y * block.z;
   if (g_fibers.size() < nthreads) g_fibers.resize(nthreads);
   if (g_stacks.size() < (size_t)nthreads * kStack) g_stacks.resize((size_t)nthreads * kStack);
@@ -59,6 +120,11 @@ void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_
               f.done = false;
               f.tid = {tx, ty, tz};
               makecontext(&f.ctx, trampoline, 0);
+#ifdef LMN_EMU_TSAN
+              if (!g_main_tsan) g_main_tsan = __tsan_get_current_fiber();
+              if (f.tsan_fiber) __tsan_destroy_fiber(f.tsan_fiber);
+              f.tsan_fiber = __tsan_create_fiber(0);
+#endif
             }
         unsigned remaining = nthreads;
         while (remaining) {
@@ -67,7 +133,7 @@ void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_
             if (f.done) continue;
             g_cur = (int)i;
             threadIdx = f.tid;
-            swapcontext(&g_main, &f.ctx);
+            to_fiber(f, g_stacks.data() + (size_t)i * kStack, kStack);
             if (f.done) --remaining;
           }
         }

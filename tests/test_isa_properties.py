@@ -102,10 +102,65 @@ def test_blake2s_half_rounds_are_issued_in_priority_phases(device_asm):
     """k_merkle_fused<1>: at least two whole compressions (40 half rounds) written as class-grouped runs - four add3,
     [prio 0] four xor, [prio 3] four alignbit, [prio 0] eight plain, [prio 3] eight first-port, ..."""
     ks = _kernels(device_asm)
-    name, = _find(ks, "k_merkle_fusedILi1E")
+    name, = _find(ks, "k_merkle_fusedILi1ELi16E")
     seq = _classes(ks[name][0])
     half = "SSSS0ffff3SSSS0ffffffff3SSSSSSSS0ffff3SSSS0ffffffff3SSSS"
     assert seq.count(half) >= 40, seq.count(half)
+
+
+def _count(body, op):
+    return len(re.findall(r"^\s*" + op + r"\b", body, re.M))
+
+
+def test_leaf_compressions_skip_the_first_port_additions_of_zero_message_words(device_asm):
+    """blake2s.h b2_compress_fresh_nz: a leaf of NZ < 16 columns (and every FRI layer's 4-word leaf) adds its zero message
+    words with two-operand v_add_u32 in the low-priority phase instead of v_add3_u32 on the first issue port.  A fused
+    launch holds two leaf and two node compressions as straight-line code: 4 x 160 message additions in the 16-column
+    instantiation; 120 of a 4-column leaf's 160 are zero words, 40 of a 12-column leaf's, 10 of a 15-column leaf's."""
+    ks = _kernels(device_asm)
+    add3 = {}
+    for nz in (4, 8, 12, 15, 16):
+        name, = _find(ks, "k_merkle_fusedILi1ELi%dE" % nz)
+        body, md = ks[name]
+        add3[nz] = _count(body, "v_add3_u32")
+        assert md["vgpr_spill"] == 0 and md["sgpr_spill"] == 0, (name, md)
+        # the phase structure survives: every half round still switches priority around its rotations
+        assert _count(body, "s_setprio") >= 600, (name, _count(body, "s_setprio"))
+    assert add3[16] >= 640, add3
+    assert add3[16] - add3[4] >= 2 * 115, add3      # two leaf compressions x (120 zero-word additions - the folded first half round's)
+    assert add3[16] - add3[12] >= 2 * 38, add3
+    assert add3[16] - add3[15] >= 2 * 9, add3
+    assert add3[4] < add3[8] < add3[12] < add3[15] < add3[16], add3
+    fri, = _find(ks, "k_merkle_fusedILi3E")
+    assert add3[16] - _count(ks[fri][0], "v_add3_u32") >= 2 * 115, fri
+
+
+def _addr64(body):
+    """v_lshl_add_u64 with an SGPR operand: a 64-bit vector address formed from a uniform base (the other v_lshl_add_u64
+    are the 64-bit accumulations of the lazy M31 dot products)"""
+    return len(re.findall(r"v_lshl_add_u64 v\[\d+:\d+\], (?:s\[\d+:\d+\], \d+, v\[\d+:\d+\]|v\[\d+:\d+\], \d+, s\[\d+:\d+\])", body))
+
+
+def test_column_loads_of_the_qm31_and_leaf_kernels_take_uniform_bases_from_sgprs(device_asm):
+    """kernels_common.h ld_ub / ld_col: the column loads of k_composition, k_eval_at_point, k_logup_fracs, the FRI quotient
+    kernels and the Merkle leaf loads are raw buffer accesses (SGPR resource + one 32-bit lane offset) - no 64-bit vector
+    address per load (27 of k_composition<0>'s 862 vector instructions, 32 of k_eval_at_point's 919, one per column and row
+    in k_quotients before) - and building the resources does not spill SGPRs in the hot instantiations."""
+    ks = _kernels(device_asm)
+    for part, max_addr in (("k_compositionILi0E", 0), ("k_compositionILi1E", 0), ("k_eval_at_point", 0), ("k_logup_fracsILi3E", 2),
+                           ("k_merkle_fusedILi1ELi15E", 6), ("k_merkle_fusedILi1ELi12E", 6), ("k_merkle_fusedILi3E", 6)):
+        name, = _find(ks, part)
+        body, md = ks[name]
+        assert _addr64(body) <= max_addr, (part, _addr64(body))
+        assert _count(body, "buffer_load_dword(x2)?") >= 9, (part, _count(body, "buffer_load_dword(x2)?"))
+        assert md["sgpr_spill"] == 0 and md["vgpr_spill"] == 0, (part, md)
+    # the FRI quotient kernels read their (column, coefficient) table through the scalar cache: no LDS copy, the column
+    # loop's loads take their base from SGPRs
+    for part in ("k_quotients_occILi1E", "k_quotients_occILi2E"):
+        name, = _find(ks, part)
+        body, md = ks[name]
+        assert _count(body, "ds_read_b(64|128)") == 0 and _count(body, "s_load_dwordx4") >= 6, part
+        assert _count(body, "buffer_load_dword") >= 12 and md["vgpr"] <= 64 and md["vgpr_spill"] == 0, (part, md)
 
 
 def test_butterfly_layers_are_issued_in_priority_phases(device_asm):
@@ -151,7 +206,7 @@ def test_merkle_kernel_has_no_constant_moves_in_front_of_its_compressions(device
     and the zero message words are set once per kernel - at most ~25 v_mov per compression site remain (round 3: 46,
     16 of them state constants and 16 zeroed message words in front of every leaf)."""
     ks = _kernels(device_asm)
-    name, = _find(ks, "k_merkle_fusedILi1E")
+    name, = _find(ks, "k_merkle_fusedILi1ELi16E")
     body = ks[name][0]
     movs = len(re.findall(r"^\s*v_mov_b32", body, re.M))
     sites = len(re.findall(r"^\s*v_alignbit_b32", body, re.M)) / 320.0      # 320 rotations per compression
