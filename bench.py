@@ -45,8 +45,10 @@ def parse_args(argv=None):
     ap.add_argument("--shard-proof", action="store_true",
                     help="latency of ONE proof sharded over the --gpus ranks (lmn_ctx_set_shard_rccl) instead of "
                          "proofs/s of independent proofs; --shard-workload picks the pie")
-    ap.add_argument("--shard-workload", default="config5", choices=["config5", "config2a", "config3"],
-                    help="config5: 256 x (Mul + SumReduce + Add), 2^24 rows; config2a: Add 2^log-rows; config3: 2^22 rows")
+    ap.add_argument("--shard-workload", default="config5",
+                    choices=["config5", "config2a", "config3", "config4", "config_5", "config_2a", "config_3", "config_4"],
+                    help="config5: 256 x (Mul + SumReduce + Add), 2^24 rows; config2a: Add 2^log-rows; config3: 2^22 rows; "
+                         "config4: the 2->64->64->1 MLP shape with its exp2 LUT")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--emu-library", default=None,
                     help="TEST ONLY: path of the host-emulation build (tests/emu): exercises the rank launch / barrier / "
@@ -124,7 +126,7 @@ def cpu_baseline(sample_log, full_log):
     res = dict(runs[best])
     res["host_physical_cores"] = phys
     res["by_threads"] = {str(t): {"value": r["value"], "sample": r["sample"],
-                                  "port_scalar_value": r.get("port_scalar", {}).get("value"),
+                                  "port_scalar_value": r.get("port_scalar", {}).get("value"), "memory_policy": r.get("memory_policy"),
                                   "reference_shape_32x32_add_ms": r["reference_shape_32x32_add_ms"]} for t, r in runs.items()}
     return res
 
@@ -185,55 +187,75 @@ def solo_latency(ctx, tables, n=9, luts=None):
 
 
 def shard_workload(name, log_rows):
+    """(tables, description, protocol variant, LUT settings) of a sharded-proof workload"""
     from luminair_amd import synthetic as syn
-    if name == "config5":
-        return syn.config5_linear_layers(), "BASELINE config 5: 256 x (Mul + SumReduce + Add), Mul 2^23 + SumReduce 2^23 + Add 2^15 rows"
-    if name == "config3":
-        return syn.config3_mixed(), "BASELINE config 3: Add 2^21 + Mul 2^20 + Recip 2^20 rows"
-    return syn.config2_add_only(1 << log_rows, 42), "BASELINE config 2a: Add 2^%d rows" % log_rows
+    from luminair_amd import backend as _bk
+    if name in ("config5", "config_5"):
+        return (syn.config5_linear_layers(), "BASELINE config 5: 256 x (Mul + SumReduce + Add), Mul 2^23 + SumReduce 2^23 + Add 2^15 rows",
+                _bk.VARIANT_KAT, None)
+    if name in ("config3", "config_3"):
+        return syn.config3_mixed(), "BASELINE config 3: Add 2^21 + Mul 2^20 + Recip 2^20 rows", _bk.VARIANT_KAT, None
+    if name in ("config4", "config_4"):
+        tabs4, luts4 = syn.config4_black_scholes_shape()
+        return tabs4, "BASELINE config 4 (2->64->64->1 tanh MLP shape, all tables <= 2^13 rows)", _bk.VARIANT_PINNED, luts4
+    return syn.config2_add_only(1 << log_rows, 42), "BASELINE config 2a: Add 2^%d rows" % log_rows, _bk.VARIANT_KAT, None
 
 
 def shard_proof_main(args, rank, local_rank, world):
     """ONE proof sharded over the ranks: every rank holds the same tables, evaluates / hashes /
     folds only its row blocks, the library's own RCCL communicator carries the all-gathers on the prover's stream.
-    A step = one whole sharded proof; value = proofs/s of that single stream of proofs (1 / latency)."""
+    A step = one whole sharded proof; value = proofs/s of that single stream of proofs (1 / latency).
+    Also the child process `bench.py --gpus N` (N > 1) starts per rank for its `sharded_proof` sub-results: a transport
+    that hangs or crashes takes this process down, not the one that holds the headline.  Every rank prints ONE JSON line
+    (rank 0 the result, the others their verdict)."""
     import hashlib
     import torch
     import torch.distributed as dist
     import luminair_amd
+    from luminair_amd import backend as _bk
     from luminair_amd.sharded import shard_context
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("RANK", str(rank))
     os.environ.setdefault("WORLD_SIZE", str(world))
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
-    prover = luminair_amd.Prover(local_rank)
-    tabs, what = shard_workload(args.shard_workload, args.log_rows)        # identical on every rank (fixed seed)
-    bufs = [(k, prover.ctx.upload(r), len(r)) for k, r in tabs]
-    plain = prover.ctx.prove_tables(bufs)                                   # unsharded reference bytes (+ context setup)
-    plain_ms = solo_latency(prover.ctx, bufs, 5) if rank == 0 else None
+    emu = args.emu_library is not None
+    has_cuda = torch.cuda.is_available() and not emu
+    if has_cuda:
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl" if has_cuda else "gloo", rank=rank, world_size=world)
+    tdev = "cuda" if has_cuda else "cpu"
+    tabs, what, variant, luts = shard_workload(args.shard_workload, args.log_rows)   # identical on every rank (fixed seed)
+    prover = luminair_amd.Prover(local_rank if has_cuda else 0, library=_bk.Library(args.emu_library) if emu else None,
+                                 protocol_variant=variant)
+    bufs = [(k, r if emu else prover.ctx.upload(r), len(r)) for k, r in tabs]
+    plain = prover.ctx.prove_tables(bufs, luts)                             # unsharded reference bytes (+ context setup)
+    plain_ms = solo_latency(prover.ctx, bufs, 3 if emu else 5, luts)        # unsharded, every rank on its own GPU
     shard_context(prover.ctx)
     out = {}
 
     def step():
-        out["proof"] = prover.ctx.prove_tables(bufs)
+        out["proof"] = prover.ctx.prove_tables(bufs, luts)
 
     def barrier():
-        dist.barrier(device_ids=[local_rank])
+        if has_cuda:
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
 
-    steps = min(args.steps, 32)
-    elapsed = timed_region(step, steps, min(args.warmup, 4), barrier, torch.cuda.synchronize)
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    steps = 2 if emu else min(args.steps, 32)
+    warm = 1 if emu else min(args.warmup, 4)
+    elapsed = timed_region(step, steps, warm, barrier, torch.cuda.synchronize if has_cuda else (lambda: None))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     tmax = float(t.item())
-    same = torch.tensor([1 if out["proof"] == plain else 0], device="cuda")
+    same_here = out["proof"] == plain
+    same = torch.tensor([1 if same_here else 0], device=tdev)
     dist.all_reduce(same, op=dist.ReduceOp.MIN)
     if rank == 0:
         rows = sum(n for _, _, n in bufs)
         print(json.dumps({
             "metric": "sharded-proof latency (one proof over all GPUs)", "value": steps / tmax, "unit": "proofs/s",
-            "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 4), "ms_per_step": 1e3 * tmax / steps,
+            "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * tmax / steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 (M31/QM31 field arithmetic)", "data": "synthetic",
             "config": {"workload": what + "; ONE proof sharded into row blocks over %d rank(s), RCCL all-gathers of subtree "
@@ -243,12 +265,16 @@ def shard_proof_main(args, rank, local_rank, world):
             "prove_latency_ms": 1e3 * tmax / steps, "unsharded_latency_ms_rank0": plain_ms,
             "rows_per_s": rows * steps / tmax,
             "bytes_identical_to_unsharded_proof_on_every_rank": bool(int(same.item())),
-        }))
+        }), flush=True)
+    else:
+        print(json.dumps({"rank": rank, "bytes_identical_to_unsharded_proof": bool(same_here)}), flush=True)
     prover.ctx.clear_shard()
     for _, b, _ in bufs:
-        b.free()
+        if hasattr(b, "free"):
+            b.free()
+    prover.ctx.close()
     dist.destroy_process_group()
-    return 0 if int(same.item()) else 1
+    return 0 if int(same.item()) else 3   # 3: the sharded proof's bytes differ on some rank (a parity failure)
 
 
 def self_launch(args, argv):
@@ -270,6 +296,30 @@ def self_launch(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     cmd += list(argv if argv is not None else sys.argv[1:])
     return subprocess.run(cmd, env=dict(os.environ, LMN_BENCH_SELF_LAUNCHED="1")).returncode
+
+
+def finalize_line(line):
+    """Key order of the printed line.  The driver keeps the contract keys, `config`, `roofline` and `cpu_baseline` whole and
+    only the NAMES of the other keys, and its log keeps the line's tail: the reference's own calling convention (`prove(pie)`
+    takes HOST rows, crates/prover/src/prover.rs:28-31,70) is therefore reported twice - as flat keys right behind the
+    headline's latency and inside `config.reference_calling_convention` - next to the device-resident headline.  Never `value`."""
+    hr = line.get("host_rows") if isinstance(line.get("host_rows"), dict) else {}
+    hp = line.get("host_rows_pinned") if isinstance(line.get("host_rows_pinned"), dict) else {}
+    tg = line.get("device_trace_generation") if isinstance(line.get("device_trace_generation"), dict) else {}
+    flat = {"host_rows_proofs_per_s": hr.get("value"), "host_rows_prove_latency_ms": hr.get("prove_latency_ms"),
+            "host_rows_pinned_proofs_per_s": hp.get("value"), "host_rows_pinned_prove_latency_ms": hp.get("prove_latency_ms")}
+    if hr or hp:
+        line["config"]["reference_calling_convention"] = dict(
+            flat, note="trace rows handed over as HOST buffers per proof (60 MiB over PCIe), what prove(pie) of the reference "
+                       "takes; the headline `value` has the rows resident in HBM, which is what the recommended binding "
+                       "(INTEGRATION.md: process_trace -> lmn_trace_*) produces",
+            device_trace_generation_ms=tg.get("ms"))
+    out = {}
+    for k, v in line.items():
+        out[k] = v
+        if k == "prove_latency_p95_ms" and (hr or hp):
+            out.update(flat)
+    return out
 
 
 def main(argv=None):
@@ -635,10 +685,14 @@ def main(argv=None):
     if trace_gen:
         line["device_trace_generation"] = trace_gen
     if use_dist and not args.no_extras and os.environ.get("LMN_BENCH_SHARDED_EXTRA", "1") != "0":
-        # Sub-result at N > 1: latency of ONE 2^log_rows-row Add proof sharded over all N GPUs (the library's own RCCL
-        # communicator on the prover stream), next to the solo latency above.  A watchdog makes sure the headline
-        # line is printed even if the multi-GPU transport misbehaves on this node.
-        import threading
+        # Sub-results at N > 1: latency of ONE proof sharded over all N GPUs (the library's own RCCL communicator on the
+        # prover stream), next to its unsharded latency.  Every rank runs them in a CHILD process (`bench.py --shard-proof`,
+        # its own rendezvous on a fresh port): RCCL with more than one rank first runs on the driver's node, and a transport
+        # that hangs or crashes there must not take the process that holds the headline with it.  A child that does not
+        # finish within LMN_BENCH_SHARDED_TIMEOUT (300 s) is killed; the line says what happened in `warnings`, a proof
+        # whose BYTES differ is an error (non-zero exit).  Still ONE JSON line on stdout.
+        import socket
+        import subprocess
 
         def dump_rccl_logs():
             import glob
@@ -651,86 +705,71 @@ def main(argv=None):
                 if txt:
                     sys.stderr.write("---- RCCL warnings (%s)\n%s\n" % (pth, txt[-4000:]))
 
-        def give_up():
-            # a multi-GPU transport that hangs on this node is an infrastructure problem, not a rejected proof: the
-            # headline (independent proofs, measured above) is still printed and the exit status stays 0; the line
-            # says what happened in `warnings`
-            dump_rccl_logs()
-            if rank == 0:
-                line.setdefault("sharded_proof", {})["error"] = "timed out (watchdog)"
-                line["errors"] = errors
-                line["warnings"] = ["sharded_proof: no result within %s s (watchdog)"
-                                    % os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "300")]
-                print(json.dumps(line), flush=True)
-            os._exit(1 if errors else 0)
-        dog = threading.Timer(float(os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "300")), give_up)
-        dog.daemon = True
-        dog.start()
-
-        def run_sharded(stabs, what, variant, luts=None, n_sh=16):
-            from luminair_amd.sharded import shard_context
-            sp = mk_prover(protocol_variant=variant)
-            sb = [(k, sp.ctx.upload(r), len(r)) for k, r in stabs]          # the same tables on every rank
-            try:
-                want = sp.ctx.prove_tables(sb, luts)
-                solo = solo_latency(sp.ctx, sb, 5, luts)                    # unsharded, every rank on its own GPU
-                shard_context(sp.ctx)
-                got = sp.ctx.prove_tables(sb, luts)
-                n_sh = 2 if emu else n_sh
-                el = timed_region(lambda: sp.ctx.prove_tables(sb, luts), n_sh, 1 if emu else 2, barrier,
-                                  torch.cuda.synchronize if has_cuda else (lambda: None))
-                tmax = reduce_max(el)
-                same = torch.tensor([1 if got == want else 0], device=tdev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                sp.ctx.clear_shard()
-            finally:
-                for _, b_, _ in sb:
-                    b_.free()
-                sp.ctx.close()
-            if not int(same.item()):
-                raise RuntimeError("sharded proof bytes differ from the unsharded proof on some rank")
-            sharded_ms = 1e3 * tmax / n_sh
-            return {"workload": "ONE proof of %s sharded into row blocks over %d GPUs" % (what, world),
-                    "prove_latency_ms": sharded_ms, "solo_unsharded_latency_ms": solo,
-                    "speedup_over_one_gpu": solo / sharded_ms,
-                    "sharding_wins": bool(sharded_ms < solo),
-                    "bytes_identical_to_unsharded_proof": True, "scaling": "strong"}
-
         def sharded_workloads():
             """config 2a always; the config BASELINE.json names for this GPU count next to it: config 4 (black-scholes
             MLP shape, every table <= 2^13 rows: latency-bound, sharding is expected to LOSE and the line says so) at
             4 GPUs, config 5 (2^24 rows) at 8"""
-            w = [("config_2a", syn.config2_add_only(1 << args.log_rows, 42), "BASELINE config 2a (Add 2^%d rows)" % args.log_rows,
-                  _bk.VARIANT_KAT, None, 16)]
+            w = [("config_2a", "BASELINE config 2a (Add 2^%d rows)" % args.log_rows, 16)]
             if emu:
                 return w
             if world == 4:
-                tabs4, luts4 = syn.config4_black_scholes_shape()
-                w.append(("config_4", tabs4, "BASELINE config 4 (2->64->64->1 tanh MLP shape, all tables <= 2^13 rows)",
-                          _bk.VARIANT_PINNED, luts4, 16))
+                w.append(("config_4", "BASELINE config 4 (2->64->64->1 tanh MLP shape, all tables <= 2^13 rows)", 16))
             if world == 8:
-                w.append(("config_5", syn.config5_linear_layers(), "BASELINE config 5 (256 x (Mul + SumReduce + Add), 2^24 rows)",
-                          _bk.VARIANT_KAT, None, 4))
+                w.append(("config_5", "BASELINE config 5 (256 x (Mul + SumReduce + Add), 2^24 rows)", 4))
             return w
-        def run_sharded_classified(*a):
-            # a proof that comes out DIFFERENT is a parity failure (errors, non-zero exit); a transport that cannot be
-            # set up on this node (RCCL initialisation, peer access) is reported in `warnings` like the watchdog case -
-            # the multi-rank RCCL path cannot be exercised on the one-GPU development boxes (DESIGN.md section 6)
+
+        def run_sharded_child(name, what, n_sh):
+            port = [0]
+            if rank == 0:
+                sock = socket.socket()
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+                sock.close()
+            dist.broadcast_object_list(port, src=0)
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "GROUP_", "ROLE_"))}
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), RANK=str(rank), LOCAL_RANK=str(local_rank),
+                       WORLD_SIZE=str(world), LMN_BENCH_AFFINITY="0")
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--shard-proof", "--shard-workload", name,
+                   "--log-rows", str(args.log_rows), "--steps", str(n_sh), "--warmup", "2"]
+            if emu:
+                cmd += ["--emu-library", args.emu_library]
+            limit = float(os.environ.get("LMN_BENCH_SHARDED_TIMEOUT", "300"))
+            verdict = {"rc": None, "timed_out": False, "stdout": "", "stderr": ""}
             try:
-                return run_sharded(*a)
-            except RuntimeError as e:
-                rejected = getattr(e, "code", 0) in (_bk.ERR_EMPTY_TRACE, _bk.ERR_MAIN_TRACE, _bk.ERR_INTERACTION_TRACE,
-                                                     _bk.ERR_CONSTRAINTS, _bk.ERR_VERIFICATION, _bk.ERR_INVALID_LOGUP)
-                if "bytes differ" in str(e) or rejected:      # a valid proof request rejected, or different bytes
-                    raise
-                line.setdefault("warnings", []).append("sharded_proof: %s: %s" % (type(e).__name__, e))
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+                verdict.update(rc=r.returncode, stdout=r.stdout, stderr=r.stderr)
+            except subprocess.TimeoutExpired as e:
+                verdict.update(timed_out=True, stdout=(e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                               stderr=(e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))
+            # every rank's verdict reaches rank 0 (the children of the other ranks print only their own)
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, {"rank": rank, "rc": verdict["rc"], "timed_out": verdict["timed_out"],
+                                              "stderr_tail": verdict["stderr"][-1500:]})
+            if rank != 0:
+                return None
+            bad = [v for v in verdicts if v["timed_out"] or v["rc"] != 0]
+            if any(v["rc"] == 3 for v in verdicts):      # shard_proof_main: different bytes on some rank
+                raise RuntimeError("sharded proof bytes differ from the unsharded proof on some rank")
+            if bad:
                 dump_rccl_logs()
-                return {"error": "%s: %s" % (type(e).__name__, e)}
+                why = "timed out after %.0f s (killed)" % limit if any(v["timed_out"] for v in bad) else \
+                    "child exit codes %s: %s" % ([v["rc"] for v in verdicts], bad[0]["stderr_tail"].strip().splitlines()[-1:] or "")
+                line.setdefault("warnings", []).append("sharded_proof.%s: %s" % (name, why))
+                return {"error": why}
+            res = json.loads(verdict["stdout"].strip().splitlines()[-1])
+            if not res.get("bytes_identical_to_unsharded_proof_on_every_rank"):
+                raise RuntimeError("sharded proof bytes differ from the unsharded proof on some rank")
+            sharded_ms, solo = res["prove_latency_ms"], res["unsharded_latency_ms_rank0"]
+            return {"workload": "ONE proof of %s sharded into row blocks over %d GPUs" % (what, world),
+                    "prove_latency_ms": sharded_ms, "solo_unsharded_latency_ms": solo,
+                    "speedup_over_one_gpu": solo / sharded_ms, "sharding_wins": bool(sharded_ms < solo),
+                    "bytes_identical_to_unsharded_proof": True, "scaling": "strong",
+                    "isolated_in_child_process": True, "proof_sha256": res["config"]["proof_sha256"]}
         line["sharded_proof"] = {}
-        for name, stabs, what, variant, luts, n_sh in sharded_workloads():
-            line["sharded_proof"][name] = sub_result("sharded_proof." + name,
-                                                     lambda: run_sharded_classified(stabs, what, variant, luts, n_sh))
-        dog.cancel()
+        for name, what, n_sh in sharded_workloads():
+            got = sub_result("sharded_proof." + name, lambda: run_sharded_child(name, what, n_sh))
+            if rank == 0:
+                line["sharded_proof"][name] = got
     if rank == 0 and not args.no_cpu_baseline and not emu:   # also on N > 1 lines: rank 0 times it once, after its GPU work
         line["cpu_baseline"] = sub_result("cpu_baseline",
                                           lambda: cpu_baseline(min(args.cpu_sample_log, args.log_rows), args.log_rows))
@@ -743,7 +782,7 @@ def main(argv=None):
             errors.append("a sub-result failed on another rank")
     line["errors"] = errors
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(finalize_line(line)), flush=True)
     for pl in pools:
         pl.shutdown()
     for bl in bufs:

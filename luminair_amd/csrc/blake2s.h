@@ -34,7 +34,7 @@ LMN_HD uint32_t b2_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); 
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU) && !defined(LMN_B2_NO_PRIO)
 // gfx950 issue order for one half round (four independent quarter rounds), written out as instructions.
-// Measured (profiles/r3_valu_coissue.txt, tools/microbench_reconcile.hip `prio`): a SIMD issues up to two VALU
+// Measured (profiles/ceilings/valu_coissue_two_ports.txt, tools/microbench_reconcile.hip `prio`): a SIMD issues up to two VALU
 // instructions per 4-cycle slot from two different waves, but v_add3_u32 / v_alignbit_b32 (and every other three-operand
 // or multiplier op) can only take the first of the two ports, and the arbiter hands that port to the OLDEST wave whatever
 // it is about to issue - so co-resident waves that execute a quarter round as the compiler schedules it run at 0.25

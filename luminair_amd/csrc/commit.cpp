@@ -161,7 +161,7 @@ void Context::build_merkle_levels(std::vector<uint32_t*>& layers, int max_log,
 void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted, DevChannel* ch, QM31* alpha_out,
                            uint32_t* root_copy, bool sharded, const MerkleFold* fold, const ChanStep* step) {
   if (fold && sharded) throw LmnError(LMN_ERR_INTERNAL, "merkle: folded leaf levels are not sharded");
-  if (step && (sharded || !ch || cols_sorted.empty())) throw LmnError(LMN_ERR_INTERNAL, "merkle: a transcript step needs an unsharded tree and a channel");
+  if (step && (!ch || cols_sorted.empty())) throw LmnError(LMN_ERR_INTERNAL, "merkle: a transcript step needs a tree and a channel");
   m.max_log = cols_sorted.empty() ? 0 : cols_sorted[0].log;
   m.layers.assign(m.max_log + 1, nullptr);
   m.cuts.clear();
@@ -199,8 +199,20 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
   for (int l = 1; l <= loc_log; ++l) m.layers[l + g] = loc[l];
   m.layers[g] = level_g;
   gather_columns(level_g, 0, 1, 8);
+  // the transcript step that consumes the root (a commitment phase's ChanStep, or a FRI layer's mix_root + draw) runs behind
+  // the gather on every rank alike: inside the launch that hashes the top g levels, or as a launch of its own
+  const ChanStep* d_step = nullptr;
+  if (step) {
+    check_chan_step(*step);
+    ChanStep* p = (ChanStep*)pin_alloc(sizeof(ChanStep));
+    *p = *step;
+    d_step = p;
+  }
   if (g == 0) {
-    if (ch) launch_chan_mix_root_draw(ch, level_g, alpha_out, root_copy, stream_);
+    if (ch && step)
+      launch_chan_step(ch, d_step, step->kind, level_g, stream_);
+    else if (ch)
+      launch_chan_mix_root_draw(ch, level_g, alpha_out, root_copy, stream_);
     return;
   }
   for (int l = g - 1; l >= 0; --l) m.layers[l] = arena_.alloc_words((size_t)8 << l);
@@ -208,7 +220,8 @@ void Context::build_merkle(DevMerkle& m, const std::vector<ColRef>& cols_sorted,
   for (int l = 0; l <= g - 1; ++l) outs.p[l] = m.layers[g - 1 - l];
   MerkleSegs none{};
   StageTimer t(this, g_log(this), stream_, C_MERKLE);
-  launch_merkle_small(level_g, none, 0, 1u << (g - 1), outs, g - 1, ch, alpha_out, root_copy, stream_);
+  launch_merkle_small(level_g, none, 0, 1u << (g - 1), outs, g - 1, ch, alpha_out, root_copy, stream_, d_step,
+                      step ? step->kind : 0);
   timings.merkle_launches++;
   timings.merkle_compressions += (1ull << g) - 1;
 }

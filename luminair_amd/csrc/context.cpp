@@ -225,12 +225,13 @@ void Context::download(const void* device, void* host, size_t bytes) {
 //   Y[m][h] = y(half_coset_m.at(bitrev(h, m-1))), h < 2^(m-1)      (layer 0 of domain m)
 //   X[k][h] = x(half_coset_k.at(bitrev(h, k-2))), h < 2^(k-2)      (layer 1 of domain k)
 // Layer i >= 1 of domain m is X[m-i+1] (doubling a canonic half coset gives the next smaller one).
-#if !defined(LMN_EMU) && !defined(LMN_BATCH)
+#if !defined(LMN_BATCH)
 // Twiddle tables are a function of the domain size alone: one set per device, built on the device (k_twiddles) and shared by
 // every context of the process.  The registry holds weak references - the last context that goes away frees the tables -
 // and a context that needs a larger domain than the current set builds a new one (the contexts still using the old one
-// keep it alive).  The batch library's members run in lock-step (no member may skip launches another one makes) and the
-// emulation build has no device: both keep one host-built set per context (below).
+// keep it alive).  The batch library's members run in lock-step (no member may skip launches another one makes): it keeps
+// one host-built set per context (below).  The emulation build shares the registry code, so that the thread sanitizer
+// run of the CPU suite sees contexts of several host threads racing for it (tests/test_sanitizers.py).
 namespace {
 struct TwiddleSet {
   int device = 0, max_log = 0;
@@ -238,8 +239,12 @@ struct TwiddleSet {
   std::vector<uint32_t*> Y, X, iY, iX, Y2, X2, iY2, iX2;
   ~TwiddleSet() {
     if (slab) {
+#ifdef LMN_EMU
+      lmn_dev_free(slab);
+#else
       (void)hipSetDevice(device);
       (void)hipFree(slab);
+#endif
     }
   }
 };

@@ -16,5 +16,10 @@ bool launch_fft_fixed_pass(bool inverse, uint32_t* data, uint64_t col_stride, co
 // 2^log_n-point columns: coeffs hold the output of the inverse low pass, lde receives both halves.  false: unsupported size.
 bool launch_interp_extend_fixed(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, uint64_t lde_stride, int log_n,
                                 const TwPtrs& itw, const TwPtrs& tw_ext, int ncols, lmn_stream_t s);
+// The AoS -> SoA transpose (padding rows, canonical-word check: launch_transpose_pad's contract) fused into the first pass
+// of the interpolation of 2^log_n-row columns: `rows` = the table's n_rows x ncols words; coeffs receives what
+// launch_fft_fixed_pass(inverse, lo 0, 12 layers) would have produced from the transposed columns.  false: not applicable.
+bool launch_fft_rows_fixed(uint32_t* coeffs, uint64_t col_stride, const uint32_t* rows, uint64_t n_rows, int ncols, int log_n,
+                           const PadRow& pad, uint32_t* bad_flag, uint32_t bad_value, const TwPtrs& itw, lmn_stream_t s);
 
 }  // namespace lmn

@@ -229,9 +229,11 @@ struct FxShape {
 // ZX (forward, the tile's top stage, from global memory): the source holds only the lower half of the rows - the
 // coefficients of a polynomial of half the domain's size (PolyOps::evaluate onto the blown-up domain): the upper half
 // reads as zero, the top layer's butterflies are copies.
+// tid: the lane's index inside the NT lanes that work on this tile (threadIdx.x, or its low bits when a block runs several
+// tiles side by side: k_fft_rows_fx)
 template <int R, bool INV, int P, class S, bool FG, bool TG, bool KEEP, bool ZX = false>
 LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, const uint32_t* tsrc,
-                    int lo, uint32_t H, const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep) {
+                    int lo, uint32_t H, const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep, uint32_t tid) {
   constexpr int TB = S::TB, CB = S::CB, RBITS = S::RBITS;
   constexpr bool LO0 = S::LO0;
   constexpr uint32_t NG = 1u << (TB - R);
@@ -242,7 +244,7 @@ LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, con
   static_assert(NG >= NT && P >= CB && P + R <= TB, "stage outside the tile");
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const uint32_t g = threadIdx.x + (uint32_t)it * NT;
+    const uint32_t g = tid + (uint32_t)it * NT;
     const uint32_t e0 = ((g >> P) << (P + R)) | (g & ((1u << P) - 1u));
     const uint32_t mhigh = e0 >> (P + R);     // row bits above the stage (0 in the tile's top stage: uniform twiddles)
     uint32_t t2[(1 << R) - 1];
@@ -308,17 +310,19 @@ LMN_D void fx_stage(const uint32_t* sm_in, uint32_t* sm_out, uint32_t* tdst, con
 
 // The stages of one tile in execution order (inverse: ascending layers; forward: descending), a barrier after each.
 // FG0: the first stage reads global memory (else sm_first); TGL: the last stage writes global memory.
+// tid / active: see fx_stage; a lane group without a tile (active = false, block-group-uniform) only keeps the barriers.
 template <class S, bool INV, int STEP, bool FG0, bool TGL, bool KEEPL, bool ZX0 = false>
 LMN_D void fx_steps(const uint32_t* sm_first, uint32_t* sm, uint32_t* tdst, const uint32_t* tsrc, int lo, uint32_t H,
-                    const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep) {
+                    const uint32_t* const (&twd)[MAX_LOG], uint32_t scale_log, uint32_t* keep, uint32_t tid, bool active = true) {
   constexpr int k = INV ? STEP : S::NST - 1 - STEP;
   constexpr bool fg = FG0 && STEP == 0;
   constexpr bool tg = TGL && STEP == S::NST - 1;
-  fx_stage<S::R(k), INV, S::CB + S::F(k), S, fg, tg, (tg && KEEPL), (ZX0 && STEP == 0)>(STEP == 0 ? sm_first : sm, sm, tdst, tsrc,
-                                                                                         lo, H, twd, scale_log, keep);
+  if (active)
+    fx_stage<S::R(k), INV, S::CB + S::F(k), S, fg, tg, (tg && KEEPL), (ZX0 && STEP == 0)>(STEP == 0 ? sm_first : sm, sm, tdst, tsrc,
+                                                                                           lo, H, twd, scale_log, keep, tid);
   __syncthreads();
   if constexpr (STEP + 1 < S::NST)
-    fx_steps<S, INV, STEP + 1, FG0, TGL, KEEPL, ZX0>(sm_first, sm, tdst, tsrc, lo, H, twd, scale_log, keep);
+    fx_steps<S, INV, STEP + 1, FG0, TGL, KEEPL, ZX0>(sm_first, sm, tdst, tsrc, lo, H, twd, scale_log, keep, tid, active);
 }
 
 struct TwD {   // kernel argument: the doubled tables only
@@ -349,7 +353,7 @@ k_fft_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_
     if (c >= ncols) break;
     uint32_t* col = data + (uint64_t)c * col_stride + base;
     const uint32_t* scol = src + (uint64_t)c * src_stride + base;
-    fx_steps<S, INV, 0, true, true, false, ZX>(sm, sm, col, scol, lo, H, tw.l, scale_log, nullptr);
+    fx_steps<S, INV, 0, true, true, false, ZX>(sm, sm, col, scol, lo, H, tw.l, scale_log, nullptr, threadIdx.x);
   }
 }
 
@@ -370,9 +374,105 @@ k_fft_interp_extend_fx(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, u
   const uint64_t n_words = 1ull << (LO + RBITS);
   uint32_t* ccol = coeffs + (uint64_t)blockIdx.y * coeff_stride + base;
   uint32_t* lcol = lde + (uint64_t)blockIdx.y * lde_stride + base;
-  fx_steps<S, true, 0, true, true, true>(B, B, ccol, ccol, LO, 0u, itw.l, scale_log, A);
+  fx_steps<S, true, 0, true, true, true>(B, B, ccol, ccol, LO, 0u, itw.l, scale_log, A, threadIdx.x);
   for (uint32_t h = 0; h < 2; ++h)
-    fx_steps<S, false, 0, false, true, false>(A, B, lcol + h * n_words, nullptr, LO, h, tw.l, 0u, nullptr);
+    fx_steps<S, false, 0, false, true, false>(A, B, lcol + h * n_words, nullptr, LO, h, tw.l, 0u, nullptr, threadIdx.x);
+}
+
+// =============================================================================================
+// a3 + a4 fused: the AoS -> SoA transpose of `write_trace` (add/witness.rs:33-108, air/src/utils.rs:59-64) inside the first
+// pass of the interpolation.  A workgroup owns rows [tile * 4096, +4096) of up to ROWS_FX_COLS consecutive columns: it reads
+// its share of the table's rows (coalesced: ROWS_FX_COLS consecutive words of every row), pads beyond the table's last row,
+// rejects non-canonical words, parks the values column-major in LDS - where k_transpose_pad would have written them to
+// HBM and the first inverse pass read them back (2 x 4 bytes per cell, 120 MB of a 2^20-row Add proof's 3.6 GB) - and
+// runs the contiguous tile's 12 inverse layers on them in place, four columns side by side (one FxShape<12, 0, true> lane
+// group of 256 each).  Output: what k_fft_fx<true, 12, 0, true> leaves in `coeffs`.
+// =============================================================================================
+// COLS columns per workgroup (COLS x 4225 words of LDS: 135 KB for 8, 68 KB - two workgroups per CU, one loading while
+// the other transforms - for 4), COLS / 2 tiles transformed side by side.  The column groups of a row tile read the
+// same rows: the (tile, group) order puts them on the same XCD back to back (workgroup b runs on XCD b mod 8), so that the
+// second group's rows come out of that XCD's L2.
+template <int COLS>
+LMN_KERNEL LMN_BOUNDS((COLS / 2) * 256)
+k_fft_rows_fx(uint32_t* coeffs, uint64_t col_stride, const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, PadRow pad,
+              uint32_t* __restrict__ bad_flag, uint32_t bad_value, TwD itw, uint32_t n_groups) {
+  using S = FxShape<12, 0, true>;
+  constexpr uint32_t NT = (uint32_t)S::NT, TILE = 1u << 12, GROUPS = COLS / 2;
+  static_assert(NT == 256, "one lane group per tile");
+  LMN_DYN_SMEM(uint32_t, sm);
+  // workgroup b: XCD x = b mod 8, s = b / 8 its position in that XCD's queue -> tile (s / n_groups) * 8 + x, group s mod n_groups
+  uint32_t tile = blockIdx.x / n_groups, ygrp = blockIdx.x % n_groups;
+  if ((gridDim.x & 7u) == 0u && ((gridDim.x / n_groups) & 7u) == 0u) {
+    const uint32_t x = blockIdx.x & 7u, sq = blockIdx.x >> 3;
+    tile = (sq / n_groups) * 8u + x;
+    ygrp = sq % n_groups;
+  }
+  const int c0 = (int)ygrp * COLS;
+  const int ncb = ncols - c0 < COLS ? ncols - c0 : COLS;
+  const uint64_t row0 = (uint64_t)tile << 12;
+  // ---- load: lane -> (row, column of the group), the column index fastest: a wave reads 64 / COLS rows x COLS consecutive words
+  {
+    constexpr int BATCH = 8;
+    constexpr uint32_t CELLS = TILE * COLS, STEP = GROUPS * NT;
+    for (uint32_t k0 = threadIdx.x; k0 < CELLS; k0 += BATCH * STEP) {
+      uint32_t v[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const uint32_t k = k0 + (uint32_t)j * STEP;
+        const uint32_t r = k / COLS, c = k % COLS;
+        const uint64_t gr = row0 + r;
+        v[j] = 0u;
+        if ((int)c < ncb) v[j] = gr < n_rows ? rows[gr * (uint64_t)ncols + (uint32_t)c0 + c] : pad.v[(uint32_t)c0 + c];
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const uint32_t k = k0 + (uint32_t)j * STEP;
+        const uint32_t r = k / COLS, c = k % COLS;
+        if (v[j] >= P31) *bad_flag = bad_value;   // the boundary takes raw u32 words: reject non-canonical M31 values
+        if ((int)c < ncb) sm[c * S::LDS_WORDS + fx_pad(r)] = v[j];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 12 inverse layers per column, in place in its LDS tile; the last stage writes the column's tile to `coeffs`
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU)
+  const uint32_t grp = __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // wave-uniform: the column's base stays in SGPRs
+#else
+  const uint32_t grp = threadIdx.x / NT;
+#endif
+  const uint32_t tid = threadIdx.x % NT;
+  for (int round = 0; round * (int)GROUPS < COLS; ++round) {
+    const int cl = round * (int)GROUPS + (int)grp;
+    const bool active = cl < ncb;
+    uint32_t* t = sm + (uint32_t)(active ? cl : 0) * S::LDS_WORDS;
+    uint32_t* col = coeffs + (uint64_t)(c0 + (active ? cl : 0)) * col_stride + row0;
+    fx_steps<S, true, 0, false, true, false>(t, t, col, nullptr, 0, tile, itw.l, 0u, nullptr, tid, active);
+  }
+}
+
+template <int COLS>
+static void launch_rows_fx(uint32_t* coeffs, uint64_t col_stride, const uint32_t* rows, uint64_t n_rows, int ncols, int log_n,
+                           const PadRow& pad, uint32_t* bad_flag, uint32_t bad_value, const TwPtrs& itw, lmn_stream_t s) {
+  using S = FxShape<12, 0, true>;
+  const size_t smem = (size_t)4 * COLS * S::LDS_WORDS;
+  const uint32_t n_groups = (uint32_t)((ncols + COLS - 1) / COLS);
+#if !defined(LMN_EMU) && !defined(LMN_BATCH)
+  if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_rows_fx<COLS>, 160 * 1024);
+#endif
+  LMN_LAUNCH((k_fft_rows_fx<COLS>), dim3((1u << (log_n - 12)) * n_groups), dim3((COLS / 2) * 256), smem, s, coeffs, col_stride,
+             rows, n_rows, ncols, pad, bad_flag, bad_value, doubled(itw), n_groups);
+}
+
+bool launch_fft_rows_fixed(uint32_t* coeffs, uint64_t col_stride, const uint32_t* rows, uint64_t n_rows, int ncols, int log_n,
+                           const PadRow& pad, uint32_t* bad_flag, uint32_t bad_value, const TwPtrs& itw, lmn_stream_t s) {
+  static const bool off = getenv("LMN_NO_FFT_FIXED") != nullptr;
+  if (off || !itw.d[0] || log_n < 13 || ncols < 1 || ncols > 32) return false;
+  const int cols = getenv("LMN_ROWS_FX_COLS") ? atoi(getenv("LMN_ROWS_FX_COLS")) : 8;
+  if (cols == 4)
+    launch_rows_fx<4>(coeffs, col_stride, rows, n_rows, ncols, log_n, pad, bad_flag, bad_value, itw, s);
+  else
+    launch_rows_fx<8>(coeffs, col_stride, rows, n_rows, ncols, log_n, pad, bad_flag, bad_value, itw, s);
+  return true;
 }
 
 template <bool INV, int RBITS, int CB, bool LO0, bool ZX = false>

@@ -40,6 +40,12 @@ int launch_fft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t
 bool fft_interp_extend_supported(int log_n);
 int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
                          uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s);
+// The same from the table's AoS rows (transpose fused into the inverse low pass; launch_transpose_pad's padding and
+// canonical-word check included).  false: not applicable to this size / build (transpose first, then launch_interp_extend).
+struct PadRow;
+bool launch_interp_extend_rows(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* rows, uint64_t n_rows, const PadRow& pad,
+                               uint32_t* bad_flag, uint32_t bad_value, uint32_t* lde, uint64_t lde_stride, int ncols, int log_n,
+                               const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s);
 // forward transform restricted to block `block` of 2^log_blocks equal row blocks of the 2^log_n domain (tw = the
 // twiddles of the whole domain); dst receives 2^(log_n - log_blocks) words per column
 int launch_fft_block(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int log_src, int ncols,
@@ -157,7 +163,8 @@ constexpr int MERKLE_MAX_SEG = 4;
 // Experiment builds only (-DLMN_ABLATE, tools/build_variants.sh): env LMN_ABLATE is a mask of kernel families whose
 // launches are skipped, to read a family's MARGINAL cost under concurrent load off the change in proofs/s (the proofs
 // are garbage; the prover's OODS self-check is off in such a build).  1 merkle_fused, 2 transforms, 4 FRI quotients,
-// 8 constraint quotients, 16 OODS evaluation, 32 logup.
+// 8 constraint quotients, 16 OODS evaluation, 32 logup; traffic experiments (round 6): 64 the transpose launch, 128 the
+// composition tree's leaf loads served from a 16 KB stand-in.
 #ifdef LMN_ABLATE
 inline unsigned ablate_mask() {
   static const unsigned m = getenv("LMN_ABLATE") ? (unsigned)atoi(getenv("LMN_ABLATE")) : 0u;
@@ -306,6 +313,13 @@ struct LogupArgs {
   QM31 z[LOGUP_MAX_REL], alpha[LOGUP_MAX_REL];  // element set of each relation (used when d_elems is null)
   const DevElems* d_elems;     // device-resident draws (ChanStep kind 1): relation j uses set es[j]
   int es[LOGUP_MAX_REL];
+  // rows != nullptr: the component's evaluations were never stored column-major (the transpose ran inside the
+  // interpolation): the relation's cells are read from the table's rows - row r at rows + r * row_words, columns
+  // vcol / icol (-1: none) / mcol - and from the padding row's values beyond n_real
+  const uint32_t* rows;
+  uint32_t row_words, n_real;
+  int vcol[LOGUP_MAX_REL], icol[LOGUP_MAX_REL], mcol[LOGUP_MAX_REL];
+  uint32_t pad_val[LOGUP_MAX_REL], pad_id[LOGUP_MAX_REL], pad_mult[LOGUP_MAX_REL];
   uint32_t* inter;             // interaction eval columns (4k columns, stride n)
   QM31* last_tmp;              // S_{k-1} per row (AoS), n entries
   uint32_t* partials;          // per-block partial sums, 4 words each

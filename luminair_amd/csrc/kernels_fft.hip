@@ -485,12 +485,10 @@ bool fft_interp_extend_supported(int log_n) {
   static const bool off = getenv("LMN_NO_FFT_FUSION") != nullptr;
   return !off && log_n > FFT_LOW_BITS && log_n - FFT_LOW_BITS <= FFT_HIGH_BITS - 1;
 }
-int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
-                         uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
-  if (LMN_ABLATED(2u)) return 3;
-  if (!fft_interp_extend_supported(log_n)) throw LmnError(-100, "interp_extend: unsupported size");
+// the fused strided pass on coefficients that have been through the inverse low pass, then the forward low pass
+static void interp_extend_tail(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, uint64_t lde_stride, int ncols, int log_n,
+                               const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
   const FftPass low{0, FFT_LOW_BITS, 0};
-  launch_staged_pass<true>(coeffs, coeff_stride, evals, evals_stride, 1ull << log_n, low, log_n, itw, 1u, ncols, s);
   FftStagePlan pl{};
   pl.lo = FFT_LOW_BITS;
   pl.hi = log_n;
@@ -509,7 +507,29 @@ int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t
     LMN_LAUNCH(k_fft_interp_extend, dim3(tiles, (unsigned)((ncols + cpb - 1) / cpb)), dim3(threads), smem, s, coeffs,
                coeff_stride, coeffs, coeff_stride, lde, lde_stride, pl, itw, tw_ext, inv_pow2(log_n), ncols, cpb);
   launch_staged_pass<false>(lde, lde_stride, lde, lde_stride, 2ull << log_n, low, log_n + 1, tw_ext, 1u, ncols, s);
+}
+
+int launch_interp_extend(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* evals, uint64_t evals_stride, uint32_t* lde,
+                         uint64_t lde_stride, int ncols, int log_n, const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
+  if (LMN_ABLATED(2u)) return 3;
+  if (!fft_interp_extend_supported(log_n)) throw LmnError(-100, "interp_extend: unsupported size");
+  const FftPass low{0, FFT_LOW_BITS, 0};
+  launch_staged_pass<true>(coeffs, coeff_stride, evals, evals_stride, 1ull << log_n, low, log_n, itw, 1u, ncols, s);
+  interp_extend_tail(coeffs, coeff_stride, lde, lde_stride, ncols, log_n, itw, tw_ext, s);
   return 3;
+}
+
+// launch_interp_extend whose evaluations are still the table's AoS ROWS: the transpose happens inside the inverse low pass
+// (fft_fixed.hip k_fft_rows_fx).  false: this size / build has no such pass - transpose, then launch_interp_extend.
+bool launch_interp_extend_rows(uint32_t* coeffs, uint64_t coeff_stride, const uint32_t* rows, uint64_t n_rows, const PadRow& pad,
+                               uint32_t* bad_flag, uint32_t bad_value, uint32_t* lde, uint64_t lde_stride, int ncols, int log_n,
+                               const TwPtrs& itw, const TwPtrs& tw_ext, lmn_stream_t s) {
+  static_assert(FFT_LOW_BITS == 12, "k_fft_rows_fx is the 12-layer contiguous pass");
+  if (!fft_interp_extend_supported(log_n)) return false;
+  if (LMN_ABLATED(2u)) return true;
+  if (!launch_fft_rows_fixed(coeffs, coeff_stride, rows, n_rows, ncols, log_n, pad, bad_flag, bad_value, itw, s)) return false;
+  interp_extend_tail(coeffs, coeff_stride, lde, lde_stride, ncols, log_n, itw, tw_ext, s);
+  return true;
 }
 
 int launch_ifft(uint32_t* dst, uint64_t dst_stride, const uint32_t* src, uint64_t src_stride, int ncols, int log_n,

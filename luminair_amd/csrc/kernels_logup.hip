@@ -16,12 +16,26 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
   QM31 S = q_zero();
   if (r < a.n) {
     QM31 den[K], pre[K];
+    // the row's cells: column-major evaluations, or - a.rows - the table's own rows (launch-uniform choice)
+    const bool aos = a.rows != nullptr, real = r < a.n_real;
+    const uint32_t* __restrict__ rowp = a.rows + (uint64_t)(real ? r : 0u) * a.row_words;
+    uint32_t mults[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      QM31 d = q_from_m(ld_ub(a.val[j], r));   // (uniform column bases + the row as a 32-bit lane offset: kernels_common.h)
+      uint32_t vj, ij = 0u;
+      if (aos) {
+        vj = real ? rowp[a.vcol[j]] : a.pad_val[j];
+        if (a.icol[j] >= 0) ij = real ? rowp[a.icol[j]] : a.pad_id[j];
+        mults[j] = real ? rowp[a.mcol[j]] : a.pad_mult[j];
+      } else {
+        vj = ld_ub(a.val[j], r);   // (uniform column bases + the row as a 32-bit lane offset: kernels_common.h)
+        if (a.id[j]) ij = ld_ub(a.id[j], r);
+        mults[j] = ld_ub(a.mult[j], r);
+      }
+      QM31 d = q_from_m(vj);
       // relation elements: kernel arguments, or the device-resident draws (a.d_elems is launch-uniform)
       const QM31 ez = a.d_elems ? a.d_elems->z[a.es[j]] : a.z[j];
-      if (a.id[j]) d = q_add(d, q_mul_m(a.d_elems ? a.d_elems->alpha[a.es[j]] : a.alpha[j], ld_ub(a.id[j], r)));
+      if (aos ? a.icol[j] >= 0 : a.id[j] != nullptr) d = q_add(d, q_mul_m(a.d_elems ? a.d_elems->alpha[a.es[j]] : a.alpha[j], ij));
       d = q_sub(d, ez);
       den[j] = d;
       pre[j] = j == 0 ? d : q_mul(pre[j - 1], d);
@@ -35,7 +49,7 @@ LMN_KERNEL k_logup_fracs(LogupArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      uint32_t mlt = ld_ub(a.mult[j], r);
+      uint32_t mlt = mults[j];
       if (a.neg[j]) mlt = m_neg(mlt);
       S = q_add(S, q_mul_m(invs[j], mlt));
       if (j < K - 1) {

@@ -149,7 +149,7 @@ LMN_D void store_hash(uint32_t* __restrict__ o, const uint32_t h[8]) {
 // of the 4x4 state (a, b, c, d = rows), so the four G functions of a half-round run on four lanes; the
 // diagonal step rotates rows b, c, d by 1, 2, 3 lanes with DPP quad_perm.  Message words are fetched from
 // LDS by per-lane sigma offsets.  ~400 issue slots instead of ~1000: single-hash latency 0.93 us vs 2.0 us
-// on MI355X (tools/microbench4.hip) - used where a level is too narrow to fill lanes anyway.
+// on MI355X (round 2's single-hash microbenchmark, docs/HISTORY.md) - used where a level is too narrow to fill lanes anyway.
 // Returns words q and 4+q of the digest.  Must be executed by all four lanes of the quad.
 // WS = 0: the 16 message words are contiguous at msg; WS > 0: the two child hashes live in a word-major node array
 // (word k of node j at base[k * WS + j]): message word w = msg[(w & 7) * WS + (w >> 3)] with msg = base + 2 * parent.
@@ -301,6 +301,11 @@ LMN_D void merkle_load_mode(const uint32_t* __restrict__ prev, const MerkleSegs&
     }
   } else if (MODE == 1) {
     const uint32_t* __restrict__ base = sg.base[0];   // block-uniform column bases + the leaf as a 32-bit lane offset
+#ifdef LMN_ABLATE
+    // experiment build, mask 128: the 4-column leaves of the composition tree read a 16 KB stand-in that stays in L2 (garbage
+    // hashes): the upper bound of what feeding those leaves from the last forward pass's LDS tile could save
+    if (fold.below_ncols == -128) i &= 4095u;
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       if (k < ncols)
@@ -587,8 +592,11 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
     LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
   } else if (!prev && ncols <= 16 && sg.n[0] == ncols) {
     // the leaf's zero message words are compile-time zeros of the instantiation (blake2s.h b2_compress_fresh_nz)
-    if (ncols <= 4)
-      LMN_LAUNCH((k_merkle_fused<1, 4>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    if (ncols <= 4) {
+      MerkleFold leaf4 = none;
+      if (LMN_ABLATED(128u)) leaf4.below_ncols = -128;
+      LMN_LAUNCH((k_merkle_fused<1, 4>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, leaf4);
+    }
     else if (ncols <= 8)
       LMN_LAUNCH((k_merkle_fused<1, 8>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
     else if (ncols <= 12)

@@ -39,12 +39,19 @@ void Context::run_composition(ProofRun& r) {
         // The constraints are evaluated on the domain of log size log_size + 1 (max_constraint_log_degree_bound,
         // add/component.rs:33-35).  At blow-up 2 that IS the committed LDE; at larger blow-ups it is not (canonic cosets of
         // different sizes are disjoint), so the component's columns are evaluated there from their coefficients.
+        // (a sharded proof evaluates its own row block only; blow-ups above 2 keep every column's coefficients on every rank:
+        // shard_a2a_columns)
         auto on_eval_domain = [&](const uint32_t* coeffs, int ncols) {
-          uint32_t* ev = arena_.alloc_words((size_t)ncols * E);
+          const uint64_t rows = E >> sg;
+          uint32_t* ev = arena_.alloc_words((size_t)ncols * rows);
           StageTimer t(this, log, stream_, C_FFT);
-          timings.fft_launches += launch_fft(ev, E, coeffs, 1ull << ci.log_size, ci.log_size, ncols, e, tw(e), stream_);
-          timings.fft_bytes += (uint64_t)ncols * (4ull << ci.log_size) + (uint64_t)ncols * 4ull * E;
-          timings.fft_butterflies += (uint64_t)ncols * (E / 2) * (uint64_t)e;
+          if (sg == 0)
+            timings.fft_launches += launch_fft(ev, E, coeffs, 1ull << ci.log_size, ci.log_size, ncols, e, tw(e), stream_);
+          else
+            timings.fft_launches += launch_fft_block(ev, rows, coeffs, 1ull << ci.log_size, ci.log_size, ncols, e, sg,
+                                                     shard_.rank, tw(e), stream_);
+          timings.fft_bytes += (uint64_t)ncols * (4ull << ci.log_size) + (uint64_t)ncols * 4ull * rows;
+          timings.fft_butterflies += (uint64_t)ncols * (rows / 2) * (uint64_t)e;
           return (const uint32_t*)ev;
         };
         a.main = on_eval_domain(tree1.cols[ci.main_start].coeffs, ci.spec->n_cols);

@@ -106,10 +106,10 @@ void Context::run_decommit(ProofRun& r) {
       for (auto& e : entries) e.dst_off += mine * out_words;
       // the entry table is read once, one entry per lane: the kernel takes it straight from pinned host memory
       GatherEntry* d_e = (GatherEntry*)pin_alloc((entries.size() + 1) * sizeof(GatherEntry));
-      memcpy(d_e, entries.data(), entries.size() * sizeof(GatherEntry));
+      if (!entries.empty()) memcpy(d_e, entries.data(), entries.size() * sizeof(GatherEntry));
       if (!hs.jobs.empty() && sh) throw LmnError(LMN_ERR_INTERNAL, "sharded proofs keep whole trees");
       MerkleRecompute* d_j = (MerkleRecompute*)pin_alloc((hs.jobs.size() + 1) * sizeof(MerkleRecompute));
-      memcpy(d_j, hs.jobs.data(), hs.jobs.size() * sizeof(MerkleRecompute));
+      if (!hs.jobs.empty()) memcpy(d_j, hs.jobs.data(), hs.jobs.size() * sizeof(MerkleRecompute));   // (memcpy from a null vector: UB even for 0 bytes)
       // an unsharded proof's gather writes straight to page-locked memory: nothing to download behind it
       uint32_t* d_o = sh ? arena_.alloc_words((size_t)slots * out_words) : (uint32_t*)result_block((size_t)out_words * 4);
       hm.mark("decommit planned");

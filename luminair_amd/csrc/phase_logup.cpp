@@ -38,6 +38,8 @@ void Context::run_interaction(ProofRun& r) {
           a.neg[j] = sp->rel_neg[j];
           a.z[j] = elems.z[es];
           a.alpha[j] = elems.alpha[es];
+          a.es[j] = es;
+          a.d_elems = d_elems;
         }
         a.inter = iblk;
         a.last_tmp = last_full + row0;
@@ -78,9 +80,23 @@ void Context::run_interaction(ProofRun& r) {
         auto column = [&](int idx) -> const uint32_t* {
           return sp->rel_pre[j] ? pre_evals[ci.pre_idx[idx]] : ci.trace_evals + (uint64_t)idx * n;
         };
-        a.val[j] = column(sp->rel_val[j]);
-        a.id[j] = sp->rel_id[j] >= 0 ? column(sp->rel_id[j]) : nullptr;
-        a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * n;
+        if (!ci.trace_evals) {
+          // the transpose ran inside the interpolation (run_main_trace): the cells come from the table's rows
+          if (sp->rel_pre[j]) throw LmnError(LMN_ERR_INTERNAL, "logup: a preprocessed relation of a table without column-major evaluations");
+          a.rows = ci.rows_dev;
+          a.row_words = (uint32_t)sp->n_cols;
+          a.n_real = (uint32_t)ci.rows_n;
+          a.vcol[j] = sp->rel_val[j];
+          a.icol[j] = sp->rel_id[j];
+          a.mcol[j] = sp->rel_mult[j];
+          a.pad_val[j] = ci.pad.v[sp->rel_val[j]];
+          a.pad_id[j] = sp->rel_id[j] >= 0 ? ci.pad.v[sp->rel_id[j]] : 0u;
+          a.pad_mult[j] = ci.pad.v[sp->rel_mult[j]];
+        } else {
+          a.val[j] = column(sp->rel_val[j]);
+          a.id[j] = sp->rel_id[j] >= 0 ? column(sp->rel_id[j]) : nullptr;
+          a.mult[j] = ci.trace_evals + (uint64_t)sp->rel_mult[j] * n;
+        }
         a.neg[j] = sp->rel_neg[j];
         a.z[j] = elems.z[es];
         a.alpha[j] = elems.alpha[es];

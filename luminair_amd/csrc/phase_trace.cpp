@@ -107,12 +107,30 @@ void Context::run_main_trace(ProofRun& r) {
         if (up1 > up0) lmn_h2d(stg, ti.rows + up0 * ti.spec->n_cols, (up1 - up0) * ti.spec->n_cols * 4, stream_);
         d_rows = stg - up0 * ti.spec->n_cols;   // indexed by table row: only rows [up0, up1) are ever read
       }
-      uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * nb);
       PadRow pad{};
       if (ti.spec->is_last_col >= 0) pad.v[ti.spec->is_last_col] = 1u;
       for (int k = 0; k < ti.spec->n_pad; ++k) pad.v[ti.spec->pad_col[k]] = ti.spec->pad_val[k];
-      launch_transpose_pad_rows(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, nb, blk0, nb, pad, d_bad, stream_, bad_mark);
-      inst[t].trace_evals = evals;
+      inst[t].rows_dev = d_rows;
+      inst[t].rows_n = ti.n_rows;
+      inst[t].pad = pad;
+      // LMN_ROWS_FUSION=1 (a switch, off by default): big unsharded tables get no transpose launch - the first pass of the
+      // interpolation reads the rows itself (fft_fixed.hip k_fft_rows_fx) and nothing is stored column-major before it;
+      // logup fractions then read the table's rows.  Measured (docs/HISTORY.md, round 6): skipping the transpose outright is
+      // worth 5 % proofs/s, but the pass that absorbs it costs what the two launches cost (54 us against 27 + 27 solo;
+      // +0.4 % under load: inside the noise) - byte-identical proofs, kept for the next idea.  Components with
+      // preprocessed (LUT) columns keep the plain path; LMN_ROWS_FUSION_MIN_LOG (default 18) lowers the size threshold.
+      const char* fmin = getenv("LMN_ROWS_FUSION_MIN_LOG");
+      const char* fon = getenv("LMN_ROWS_FUSION");
+      const bool try_fused = fon && atoi(fon) != 0 && !shard_.active && lb == 1 && ti.spec->n_pre == 0 &&
+                             fft_interp_extend_supported(ti.log_size) && ti.log_size >= (fmin ? std::max(13, atoi(fmin)) : 18) &&
+                             getenv("LMN_NO_FFT_FIXED") == nullptr;
+      if (try_fused) {
+        inst[t].trace_evals = nullptr;
+      } else {
+        uint32_t* evals = arena_.alloc_words((size_t)ti.spec->n_cols * nb);
+        launch_transpose_pad_rows(d_rows, ti.n_rows, ti.spec->n_cols, ti.log_size, evals, nb, blk0, nb, pad, d_bad, stream_, bad_mark);
+        inst[t].trace_evals = evals;
+      }
       inst[t].rows_sharded = rows_front;
       any_rows_front = any_rows_front || rows_front;
       proof.claim[ti.spec->kind] = ti.log_size;
@@ -125,7 +143,26 @@ void Context::run_main_trace(ProofRun& r) {
       uint64_t n = 1ull << ci.log_size;
       int nc = ci.spec->n_cols;
       uint32_t* coeffs = arena_.alloc_words((size_t)nc * n);
-      const CommitOut co = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size, -1, ci.rows_sharded);
+      CommitOut co;
+      bool fused = false;
+      if (!ci.trace_evals) {
+        uint32_t* lde = arena_.alloc_words((size_t)nc * 2 * n);
+        {
+          StageTimer t(this, log, stream_, C_FFT);
+          fused = launch_interp_extend_rows(coeffs, n, ci.rows_dev, ci.rows_n, ci.pad, d_bad, bad_mark, lde, 2 * n, nc, ci.log_size,
+                                            itw(ci.log_size), tw(ci.log_size + 1), stream_);
+        }
+        if (fused) {
+          timings.fft_launches += 3;
+          timings.fft_bytes += (uint64_t)nc * 20ull * n;                         // as interpolate_for_commit counts the two transforms
+          timings.fft_butterflies += (uint64_t)nc * (n / 2) * (uint64_t)ci.log_size + (uint64_t)nc * n * (uint64_t)ci.log_size;
+          co.lde = lde;
+          co.stride = 2 * n;
+        } else {
+          throw LmnError(LMN_ERR_INTERNAL, "main trace: no row pass for a size run_main_trace had chosen it for");
+        }
+      }
+      if (!fused) co = interpolate_for_commit(coeffs, ci.trace_evals, nc, ci.log_size, -1, ci.rows_sharded);
       ci.main_start = off;
       off += nc;
       for (int c = 0; c < nc; ++c)

@@ -78,11 +78,10 @@ std::vector<uint8_t> Context::prove(const lmn_table* tables, size_t n_tables, co
   } cut_scope{merkle_cut_};
   merkle_cut_ = !shard_.active && getenv("LMN_MERKLE_FULL") == nullptr;
 
-  if (shard_.active && cfg.log_blowup != 1)
-    throw LmnError(LMN_ERR_INVALID_ARGUMENT, "sharded proofs support log_blowup = 1 only");
-  // Device-resident Fiat-Shamir of the commitment phases: unsharded proofs (a sharded proof exchanges data at the same
-  // points anyway); LMN_HOST_FS=1 keeps the transcript on the host (round 1-4 behaviour, for A/B measurements)
-  r.dev_fs = !shard_.active && getenv("LMN_HOST_FS") == nullptr;
+  // Device-resident Fiat-Shamir of the commitment phases - sharded proofs included since round 6 (every rank runs the same
+  // steps behind the all-gather of the subtree roots); LMN_HOST_FS=1 keeps the transcript on the host (round 1-4
+  // behaviour, for A/B measurements)
+  r.dev_fs = getenv("LMN_HOST_FS") == nullptr;
   run_setup(r);               // prove.cpp: validate the tables, size the arena, twiddles, transcript
   run_preprocessed(r);        // phase_trace.cpp: tree 0 (LUT columns)                      prover.rs:54-59
   run_main_trace(r);          // phase_trace.cpp: transpose + commit, claim mixed           prover.rs:70-179

@@ -67,6 +67,11 @@ struct Instance {
   const QM31* d_claimed_shift = nullptr;  // device [claimed, shift] (prover only)
   uint32_t* trace_evals = nullptr;        // device, n_cols x 2^log_size (prover only)
   bool rows_sharded = false;              // sharded proofs: trace_evals holds this rank's block of 2^(log_size - g) rows only
+  // trace_evals == nullptr: the evaluations were never stored column-major (the transpose ran inside the interpolation,
+  // fft_fixed.hip k_fft_rows_fx): readers take them from the table's rows on the device, padded beyond rows_n
+  const uint32_t* rows_dev = nullptr;
+  uint64_t rows_n = 0;
+  PadRow pad{};
   int pre_idx[2] = {-1, -1};    // tree-0 column indices of the component's preprocessed columns
 };
 // sum_k c_k(oods)/Z_k(oods) * alpha^(N-1-k) from the sampled mask values

@@ -21,7 +21,7 @@ from typing import Dict, Optional
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 # ALU ceilings measured on MI355X with both VALU issue ports in use (tools/microbench_reconcile.hip `prio` / `bfly`,
-# profiles/r3_valu_coissue.txt)
+# profiles/ceilings/valu_coissue_two_ports.txt)
 BLAKE2S_PEAK_GCOMP = 63.8    # G compressions/s chip-wide: 1024 SIMDs x 2.235 GHz x 0.425 instr/clk x 64 lanes / 976 instr
 BUTTERFLY_PEAK_G = 4800.0    # G M31 butterflies/s chip-wide: 0.035 butterflies/clk/SIMD x 2.08 GHz x 1024 SIMDs x 64 lanes
 # architectural issue bound: 256 CUs x 4 SIMDs, 64 lanes, 2 ports x 1 wave-instruction / 4 clk, 2.4 GHz
@@ -41,16 +41,34 @@ KERNEL_FAMILIES = {
 }
 
 
+PMC_ROUND = "r6"   # the round whose tree the committed counter summary must describe
+
+
 def load_pmc(root: str):
-    """(per-kernel PMC summary, its path under profiles/) - the newest committed rocprofv3 counter summary."""
-    for cand in ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
-        pth = os.path.join(root, "profiles", cand)
-        if os.path.exists(pth):
-            try:
-                with open(pth) as f:
-                    return json.load(f)["kernels"], "profiles/" + cand
-            except (OSError, ValueError, KeyError):
-                continue
+    """(per-kernel PMC summary, its description) - the rocprofv3 counter summary committed for THIS round's tree
+    (profiles/<PMC_ROUND>_pmc_summary.json).  If it is absent the newest older summary is still used - the counters of the
+    Merkle and transform kernels move little between rounds - but never silently: the description (which becomes the
+    line's `traffic_source`) names the round the figures come from and says STALE, and a warning goes to stderr."""
+    import glob
+    import re
+    import sys
+    cur = os.path.join(root, "profiles", "%s_pmc_summary.json" % PMC_ROUND)
+    older = sorted((p_ for p_ in glob.glob(os.path.join(root, "profiles", "r*_pmc_summary.json")) if p_ != cur),
+                   key=lambda p_: int(re.search(r"r(\d+)_pmc_summary", p_).group(1)), reverse=True)
+    for pth in [cur] + older:
+        if not os.path.exists(pth):
+            continue
+        try:
+            with open(pth) as f:
+                kernels = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        name = "profiles/" + os.path.basename(pth)
+        if pth != cur:
+            sys.stderr.write("bench.py: WARNING: %s is missing; `traffic` comes from the STALE counter summary %s\n"
+                             % (os.path.relpath(cur, root), name))
+            name += " [STALE: counters of an earlier round's tree, this round's summary (%s) is missing]" % os.path.basename(cur)
+        return kernels, name
     return {}, None
 
 

@@ -121,7 +121,7 @@ void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_
               f.tid = {tx, ty, tz};
               makecontext(&f.ctx, trampoline, 0);
 #ifdef LMN_EMU_TSAN
-              if (!g_main_tsan) g_main_tsan = __tsan_get_current_fiber();
+              g_main_tsan = __tsan_get_current_fiber();   // the launching thread's own context (launches take turns)
               if (f.tsan_fiber) __tsan_destroy_fiber(f.tsan_fiber);
               f.tsan_fiber = __tsan_create_fiber(0);
 #endif

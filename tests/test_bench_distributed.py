@@ -92,6 +92,21 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert line["value"] > 0 and abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4 / 1e3)) < 1e-6 * line["value"]
 
 
+def test_bench_headline_survives_a_sharded_sub_result_that_never_finishes(monkeypatch):
+    """The `sharded_proof` sub-results run in a child process per rank (RCCL with more than one rank first runs on the
+    driver's node: a hang or a crash there must not cost the N-GPU throughput line).  A child that does not finish within
+    LMN_BENCH_SHARDED_TIMEOUT is killed: the ONE JSON line still appears, carries the headline, says what happened in
+    `warnings`, and the exit status stays 0 (an infrastructure problem, not a rejected proof)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "tests", "emu", "libluminair_emu.so")
+    monkeypatch.setenv("LMN_BENCH_SHARDED_TIMEOUT", "0.2")        # no python child gets as far as `import torch` in 0.2 s
+    r, line = _run_bench(["--gpus", "2", "--emu-library", emu, "--log-rows", "5", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["errors"] == []
+    assert "error" in line["sharded_proof"]["config_2a"] and "timed out" in line["warnings"][0]
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """On a box with fewer than N GPUs `--gpus N` fails loudly instead of benchmarking one GPU as N = 1."""
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0

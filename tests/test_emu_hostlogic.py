@@ -82,6 +82,33 @@ def test_emu_trees_stored_without_their_register_levels(emu_ctx, name, tabs, mon
     assert emu_ctx.prove_tables([(k, r, len(r)) for k, r in tabs]) == want
 
 
+@pytest.mark.parametrize("cols", ["8", "4"])
+def test_emu_transpose_inside_the_interpolation(emu_ctx, cols, monkeypatch):
+    """LMN_ROWS_FUSION=1 (a switch; on the GPU from 2^18 rows): no transpose launch and no column-major evaluations in memory -
+    the first inverse pass reads the table's rows itself (k_fft_rows_fx, 8 or 4 columns per workgroup), pads, checks
+    canonicity, and the logup fractions read the rows.  Same bytes as the oracle for ragged, mixed-size and 16-column
+    tables; the rejections of the transpose still happen."""
+    monkeypatch.setenv("LMN_ROWS_FUSION", "1")
+    monkeypatch.setenv("LMN_ROWS_FUSION_MIN_LOG", "13")
+    monkeypatch.setenv("LMN_ROWS_FX_COLS", cols)
+    for name, tabs in (("chain-5000 (2^13 rows, ragged)", syn.chain_graph(5000, 4)),
+                       ("mixed 2^13 + 2^10", [(0, syn.chain_graph(5000, 4)[0][1]), (1, syn.chain_graph(1000, 5)[1][1])]),
+                       ("mul-only 2^13 (16 columns)", syn.config2_mul_only(1 << 13, 3))):
+        got, want = _both(emu_ctx, tabs)
+        assert got == want, name
+        assert emu_ctx.timings()["transpose_ms"] >= 0
+    bad = syn.config2_add_only(1 << 13, 9)[0][1].copy()
+    bad[5000, 9] = 0x7fffffff
+    with pytest.raises(backend.LuminairBackendError) as e:
+        emu_ctx.prove_tables([(0, bad, len(bad))])
+    assert e.value.code == backend.ERR_INVALID_ARGUMENT
+    bad[5000, 9] = 5
+    bad[3, 11] ^= 1
+    with pytest.raises(backend.LuminairBackendError) as e:
+        emu_ctx.prove_tables([(0, bad, len(bad))])
+    assert e.value.code == backend.ERR_CONSTRAINTS
+
+
 def test_emu_error_codes(emu_ctx):
     with pytest.raises(backend.LuminairBackendError) as e:
         emu_ctx.prove_tables([(0, np.zeros((0, 15), np.uint32), 0)])

@@ -66,6 +66,20 @@ def test_gpu_full_size_2_20_equals_c_oracle_bytes(gpu_prover, c_oracle):
     assert got == want
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cols", ["8", "4"])
+def test_gpu_transpose_inside_the_interpolation_switch(gpu_prover, c_oracle, cols, monkeypatch):
+    """LMN_ROWS_FUSION=1 (off by default, docs/HISTORY.md round 6): k_fft_rows_fx instead of k_transpose_pad + the plain first
+    inverse pass, logup fractions from the table's rows: config 2a at full size and a ragged mixed pie, byte-for-byte."""
+    from oracle.proof import to_bincode
+    from oracle.prover import prove
+    monkeypatch.setenv("LMN_ROWS_FUSION", "1")
+    monkeypatch.setenv("LMN_ROWS_FX_COLS", cols)
+    for tabs in (syn.config2_add_only(1 << 20, 42), syn.config3_mixed(19, 18, 18, 8),
+                 [(0, syn.chain_graph(300000, 4)[0][1]), (1, syn.chain_graph(70000, 5)[1][1])]):
+        assert _gpu_bytes(gpu_prover, tabs) == to_bincode(prove(tabs, kernels=c_oracle))
+
+
 def test_gpu_config3_mixed_2_20_total_rows_equals_c_oracle_bytes(gpu_prover, c_oracle):
     """Add 2^19 + Mul 2^18 + Recip 2^18 rows (config 3's shape at 1/4 scale), byte-for-byte."""
     from oracle.proof import to_bincode

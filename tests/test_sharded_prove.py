@@ -41,6 +41,11 @@ def _cases():
         # PcsConfig other than the default: (pow_bits, log_last_layer, n_queries)
         ("chain, 20 queries, last layer 2^3 coefficients", syn.chain_graph(300, 3), None, False, (10, 3, 20)),
         ("2a-small, 1 query, last layer 2^5 coefficients", syn.config2_add_only(300, 2), None, False, (0, 5, 1)),
+        # blow-up 4 and 8 (round 6): the committed LDE is not the constraint domain - every rank evaluates its row block of
+        # a component's columns there from the coefficients, which every rank keeps (no column-parallel stage A)
+        ("chain, blow-up 4", syn.chain_graph(300, 4), None, False, (5, 0, 3, 2)),
+        ("mixed sizes, blow-up 8, last layer 2^2", [(0, syn.chain_graph(64, 4)[0][1]), (1, syn.chain_graph(500, 5)[1][1])], None, False,
+         (5, 2, 4, 3)),
     ]
 
 
@@ -69,7 +74,9 @@ def _make_ctx(pinned, pcs=None):
     if pinned:
         cfg.protocol_variant = backend.VARIANT_PINNED
     if pcs:
-        cfg.pow_bits, cfg.log_last_layer, cfg.n_queries = pcs
+        cfg.pow_bits, cfg.log_last_layer, cfg.n_queries = pcs[:3]
+        if len(pcs) > 3:
+            cfg.log_blowup = pcs[3]
     return backend.Context(0, cfg, lib)
 
 
@@ -108,8 +115,10 @@ def _worker(rank, world, port, fri_min_log, a2a, q, rows=False):
         ctx.close()
         stats = []
         proofs = _prove_all(make, stats)
-        # the exchange mode under test really ran: every proof used the all-to-all (two per interaction run: rows + halo), or none did
-        assert all((c > 0) == bool(a2a) for c, _, _ in stats), stats
+        # the exchange mode under test really ran: every proof used the all-to-all (two per interaction run: rows + halo), or
+        # none did (blow-ups above 2 never do: their columns' coefficients stay on every rank)
+        blowup2 = [len(c) <= 4 or len(c[4]) <= 3 or c[4][3] == 1 for c in _cases()]
+        assert all((c > 0) == (bool(a2a) and b2) for (c, _, _), b2 in zip(stats, blowup2)), stats
         assert all(g > 0 for _, _, g in stats)
         q.put((rank, proofs))
     finally:

@@ -2,8 +2,8 @@
 """Per-kernel VALU issue from a rocprofv3 --pmc pass holding SQ_ACTIVE_INST_VALU (wave-instructions issued, summed over
 the chip), SQ_WAVE_CYCLES (quad-cycle units) and GRBM_GUI_ACTIVE (summed over 8 XCDs).  "1-port cyc" = instructions x 4
 cycles / 1024 SIMDs: the time the launch would need if every instruction took a whole issue slot (the pre-co-issue model,
-profiles/r3_valu_issue_reconciled.txt); instr/clk/SIMD above 0.25 means both issue ports were used
-(profiles/r3_valu_coissue.txt).
+profiles/ceilings/valu_issue_reconciled.txt); instr/clk/SIMD above 0.25 means both issue ports were used
+(profiles/ceilings/valu_coissue_two_ports.txt).
 Usage: valu_summary.py <counter_collection.csv> <n_proofs>"""
 import csv, sys
 from collections import defaultdict
