@@ -393,6 +393,14 @@ struct QuotEntry {
   const uint32_t* col;         // column of 2^log_size words
   QM31 c;                      // alpha^k * c for this (batch, column) sample
 };
+// Per sample batch b (the columns sampled at one point p_b): A = sum_k alpha^k a_k, B = sum_k alpha^k b_k of the batch's
+// line coefficients, batch_coeff = alpha^|batch|, and the point's coordinates split into their CM31 halves
+// (x = prx + u pix, y = pry + u piy).  In device memory: uploaded by the host, or - unsharded proofs - written by
+// k_quot_prepare behind the point evaluations, so that no host round trip stands in front of the quotient kernels.
+struct QuotDev {
+  QM31 A[QUOT_MAX_BATCH], B[QUOT_MAX_BATCH], batch_coeff[QUOT_MAX_BATCH];
+  CM31 prx[QUOT_MAX_BATCH], pry[QUOT_MAX_BATCH], pix[QUOT_MAX_BATCH], piy[QUOT_MAX_BATCH];
+};
 struct QuotientArgs {
   int log_size;                // log size of the whole LDE domain
   // rows [row0, row0 + 2^log_rows) are computed; entries[].col and out hold exactly those rows
@@ -402,13 +410,47 @@ struct QuotientArgs {
   int nbatch;
   int batch_start[QUOT_MAX_BATCH + 1];  // range into entries
   const QuotEntry* entries;    // device
-  QM31 A[QUOT_MAX_BATCH], B[QUOT_MAX_BATCH], batch_coeff[QUOT_MAX_BATCH];
-  CM31 prx[QUOT_MAX_BATCH], pry[QUOT_MAX_BATCH], pix[QUOT_MAX_BATCH], piy[QUOT_MAX_BATCH];
+  const QuotDev* dev;          // device: the batches' line sums, powers and sample points (uploaded, or written by k_quot_prepare)
   const uint32_t* tw_y;        // layer-0 twiddles of the domain (y at storage 2h)
   const uint32_t* tw_x;        // layer-1 twiddles (x at storage 4h)
   uint32_t* out;               // 4 coordinate columns
 };
 void launch_quotients(const QuotientArgs& a, lmn_stream_t s);
+
+// ---- a9: the transcript step and the tables in front of the FRI quotient kernels, on the device (unsharded proofs).
+// Behind the point evaluations one workgroup mixes the sampled values into the device-resident channel
+// (Channel::mix_felts: one Blake2s over digest || values, quad-cooperative), draws the quotient randomness alpha, and
+// writes what QuotientOps::accumulate_quotients' host side (quotients.cpp make_quotient_args) would have uploaded: per LDE
+// size the (column, alpha^k * c_k) entries and the batches' QuotDev.  The host enqueues the quotient kernels and the whole
+// FRI commit loop without waiting for the sampled values; it replays this step (and checks the composition identity) when
+// the FRI results arrive.
+constexpr int QUOT_PREP_MAX_SIZES = 8;
+constexpr int QUOT_PREP_MAX_SAMPLES = 496;   // 8 + 4 x 496 message words = 125 Blake2s blocks
+struct QuotPrepEntry {
+  const uint32_t* col;         // the column's LDE on the device
+  uint32_t sample;             // index of its sampled value (sampled_values order)
+  uint16_t size, batch;        // LDE size (index into QuotPrepPlan::size) and sample batch inside it
+};
+struct QuotPrepSize {
+  int n_entries, n_batch;
+  int batch_start[QUOT_MAX_BATCH + 1];   // into this size's entries
+  int point[QUOT_MAX_BATCH];             // sample point of each batch (row of `maps`)
+  uint32_t first_entry, pad_;            // the size's first entry in the plan's list
+  QuotEntry* entries_out;                // device, n_entries
+  QuotDev* dev_out;                      // device
+};
+struct QuotPrepPlan {
+  int n_sizes, n_samples, n_maps, n_entries;
+  QuotPrepSize size[QUOT_PREP_MAX_SIZES];
+  const QuotPrepEntry* entries;          // page-locked, n_entries (sizes in order, batches in order inside a size)
+  const QM31* vals;                      // device: the sampled values (k_eval_reduce)
+  QM31* vals_host;                       // page-locked: n_samples values + the drawn alpha, for the host's replay
+  const QM31* maps;                      // device: per sample point y, x, pi(x), ... (ChanStep kind 3), n_maps apart
+  const uint32_t* copy_src;              // also copies copy_words words from page-locked to device memory (the FRI tail's table)
+  uint32_t* copy_dst;
+  uint32_t copy_words, pad_;
+};
+void launch_quot_prepare(DevChannel* ch, const QuotPrepPlan* plan /* device-visible */, lmn_stream_t s);
 
 // ---- a9: FRI folds.  Secure columns are 4 coordinate arrays at stride = length.
 // alpha is read from device memory (written by the device-resident channel).

@@ -202,6 +202,43 @@ LMN_D void b2_quad_parent(const uint32_t* msg, uint32_t q, uint32_t& o_lo, uint3
 #undef LMN_B2_QW
 }
 
+// The same for ANY block of a hash in progress: lane q of the quad holds words q and 4 + q of the chaining value
+// (hl, hh: updated); t0 = bytes hashed so far including this block, f0 = the finalisation word (0xffffffff on the last block).
+LMN_D void b2_quad_compress(const uint32_t* msg, uint32_t q, uint32_t& hl, uint32_t& hh, uint32_t t0, uint32_t f0) {
+  const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+  uint32_t a = hl, b = hh, c = iv_lo, d = iv_hi ^ (q == 0 ? t0 : q == 2 ? f0 : 0u);
+  const uint32_t sh8 = 8u * q;
+#define LMN_B2_QUAD_ROUND(...)                                            \
+  {                                                                       \
+    const uint64_t S = LMN_B2_SIGMA_PACK(__VA_ARGS__);                    \
+    const uint32_t lo = (uint32_t)(S >> sh8), hi = (uint32_t)(S >> (32u + sh8)); \
+    const uint32_t x0 = msg[lo & 15u], y0 = msg[(lo >> 4) & 15u];         \
+    const uint32_t x1 = msg[hi & 15u], y1 = msg[(hi >> 4) & 15u];         \
+    LMN_B2_G(a, b, c, d, x0, y0)                                          \
+    b = lmn_quad_perm(b, 0x39);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x93);                                           \
+    LMN_B2_G(a, b, c, d, x1, y1)                                          \
+    b = lmn_quad_perm(b, 0x93);                                           \
+    c = lmn_quad_perm(c, 0x4E);                                           \
+    d = lmn_quad_perm(d, 0x39);                                           \
+  }
+  LMN_B2_QUAD_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  LMN_B2_QUAD_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+  LMN_B2_QUAD_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+  LMN_B2_QUAD_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+  LMN_B2_QUAD_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+  LMN_B2_QUAD_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+  LMN_B2_QUAD_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+  LMN_B2_QUAD_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+  LMN_B2_QUAD_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+  LMN_B2_QUAD_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef LMN_B2_QUAD_ROUND
+  hl ^= a ^ c;
+  hh ^= b ^ d;
+}
+
 // One level of an in-LDS Merkle climb.  The block's nodes live WORD-MAJOR in sh (word k of node j at sh[k * BLOCK + j]:
 // lanes that walk nodes touch consecutive banks - the node-major form, 8 or 16 words per lane, put a whole wave on two
 // banks): the children of this block's `n_par` parents are nodes 0 .. 2 * n_par - 1, parent j replaces node j and is
@@ -831,6 +868,116 @@ LMN_D void chan_step_root_oods(uint32_t* scr, DevChannel* ch, uint32_t dg, uint3
   for (uint32_t k = tid; k < (uint32_t)(sizeof(DevReport) / 4); k += blockDim.x) st.rep_host[k] = rw[k];
   if (tid < copy_words) copy_dst[tid] = copy_word;
   for (uint32_t k = tid + blockDim.x; k < copy_words; k += blockDim.x) copy_dst[k] = copy_src[k];
+}
+
+// =============================================================================================
+// The step in front of the FRI quotient kernels (kernels.h QuotPrepPlan): mix_felts(sampled values), alpha = draw_felt(),
+// the quotient tables of every LDE size.  One workgroup; block-uniform control flow.
+// =============================================================================================
+constexpr int QUOT_PREP_PLAN_WORDS = (int)(sizeof(QuotPrepPlan) / 4);
+static_assert(sizeof(QuotPrepPlan) % 8 == 0, "the plan is fetched word by word");
+LMN_KERNEL k_quot_prepare(DevChannel* ch, const QuotPrepPlan* __restrict__ plan_g) {
+  LMN_SERIAL_KERNEL();
+  LMN_SHARED alignas(16) uint32_t sh_plan[QUOT_PREP_PLAN_WORDS];
+  LMN_SHARED uint32_t W[8 + 4 * QUOT_PREP_MAX_SAMPLES + 16];   // digest || values, zero-padded to whole blocks
+  LMN_SHARED uint32_t scr[32];                                   // msg 16 | drawn words 8 | alpha 4
+  LMN_SHARED QM31 sa[QUOT_MAX_ENTRIES], sb[QUOT_MAX_ENTRIES];
+  const uint32_t tid = threadIdx.x, q = tid & 3u;
+  for (uint32_t k = tid; k < (uint32_t)QUOT_PREP_PLAN_WORDS; k += blockDim.x) sh_plan[k] = reinterpret_cast<const uint32_t*>(plan_g)[k];
+  const uint32_t dgw = tid < 8u ? ch->digest[tid] : 0u;
+  const uint32_t variant = ch->variant;
+  __syncthreads();
+  const QuotPrepPlan& plan = *reinterpret_cast<const QuotPrepPlan*>(sh_plan);
+  const uint32_t n_val_words = 4u * (uint32_t)plan.n_samples, total_words = 8u + n_val_words;
+  const uint32_t n_blocks = (total_words + 15u) / 16u;
+  if (tid < 8u) W[tid] = dgw;
+  for (uint32_t k = tid; k < n_blocks * 16u - 8u; k += blockDim.x) {
+    uint32_t w = 0u;
+    if (k < n_val_words) {
+      w = reinterpret_cast<const uint32_t*>(plan.vals)[k];
+      reinterpret_cast<uint32_t*>(plan.vals_host)[k] = w;   // the host's copy of the sampled values (page-locked memory)
+    }
+    W[8u + k] = w;
+  }
+  __syncthreads();
+  // ---- Channel::mix_felts: digest <- Blake2s(digest || values)
+  uint32_t* msg = scr;
+#ifdef LMN_EMU
+  if (tid == 0u) {
+    uint32_t h[8];
+    b2_init(h);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const bool last = b + 1u == n_blocks;
+      b2_compress(h, W + 16u * b, last ? 4u * total_words : 64u * (b + 1u), last ? 0xffffffffu : 0u);
+    }
+    for (int k = 0; k < 8; ++k) msg[k] = h[k];
+  }
+#else
+  if (tid < 64u) {
+    uint32_t hl = q == 0 ? (0x6A09E667u ^ 0x01010020u) : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+    uint32_t hh = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const bool last = b + 1u == n_blocks;
+      b2_quad_compress(W + 16u * b, q, hl, hh, last ? 4u * total_words : 64u * (b + 1u), last ? 0xffffffffu : 0u);
+    }
+    if (tid < 4u) {
+      msg[q] = hl;
+      msg[4u + q] = hh;
+    }
+  }
+#endif
+  __syncthreads();
+  // ---- alpha = draw_felt(); the channel goes on into the FRI commit loop
+  uint32_t n_sent = 0u, f[8];
+  qchan_draw_felts8(msg, scr + 16, n_sent, variant == 0u ? 64u : 37u, f);
+  const QM31 alpha{f[0], f[1], f[2], f[3]};
+  qchan_store(ch, msg, n_sent, variant);
+  if (tid == 0u) plan.vals_host[plan.n_samples] = alpha;
+  // ---- one lane per (column, sample): alpha^(k+1) times the line through (p.y, v) and (conj p.y, conj v)
+  for (uint32_t e = tid; e < (uint32_t)plan.n_entries; e += blockDim.x) {
+    const QuotPrepEntry en = plan.entries[e];
+    const QuotPrepSize& sz = plan.size[en.size];
+    const uint32_t local = e - sz.first_entry;
+    const uint32_t k = local - (uint32_t)sz.batch_start[en.batch];
+    const QM31 power = q_pow(alpha, (uint64_t)k + 1u);
+    const uint32_t* vw = W + 8u + 4u * en.sample;
+    const QM31 val{vw[0], vw[1], vw[2], vw[3]};
+    const QM31 py = plan.maps[(size_t)sz.point[en.batch] * (size_t)plan.n_maps];
+    const QM31 la = q_sub(q_conj(val), val);
+    const QM31 lc = q_sub(q_conj(py), py);
+    const QM31 lbb = q_sub(q_mul(val, lc), q_mul(la, py));
+    sz.entries_out[local] = QuotEntry{en.col, q_mul(power, lc)};
+    sa[e] = q_mul(power, la);
+    sb[e] = q_mul(power, lbb);
+  }
+  __syncthreads();
+  // ---- one lane per (size, batch): the batch's sums, its power of alpha, its point
+  if (tid < (uint32_t)plan.n_sizes * (uint32_t)QUOT_MAX_BATCH) {
+    const QuotPrepSize& sz = plan.size[tid / QUOT_MAX_BATCH];
+    const int b = (int)(tid % QUOT_MAX_BATCH);
+    if (b < sz.n_batch) {
+      QM31 A = q_zero(), B = q_zero();
+      for (int i = sz.batch_start[b]; i < sz.batch_start[b + 1]; ++i) {
+        A = q_add(A, sa[sz.first_entry + (uint32_t)i]);
+        B = q_add(B, sb[sz.first_entry + (uint32_t)i]);
+      }
+      const QM31* mp = plan.maps + (size_t)sz.point[b] * (size_t)plan.n_maps;
+      const QM31 py = mp[0], px = mp[1];
+      QuotDev* d = sz.dev_out;
+      d->A[b] = A;
+      d->B[b] = B;
+      d->batch_coeff[b] = q_pow(alpha, (uint64_t)(sz.batch_start[b + 1] - sz.batch_start[b]));
+      d->prx[b] = CM31{px.a, px.b};
+      d->pix[b] = CM31{px.c, px.d};
+      d->pry[b] = CM31{py.a, py.b};
+      d->piy[b] = CM31{py.c, py.d};
+    }
+  }
+  for (uint32_t k = tid; k < plan.copy_words; k += blockDim.x) plan.copy_dst[k] = plan.copy_src[k];
+}
+void launch_quot_prepare(DevChannel* ch, const QuotPrepPlan* plan, lmn_stream_t s) {
+  if (!ch || !plan) throw LmnError(-100, "quot_prepare: no channel / plan");
+  LMN_LAUNCH(k_quot_prepare, dim3(1), dim3(TPB), 0, s, ch, plan);
 }
 
 // root_word: lanes 0..7 hold the root's words; dg / variant: the channel as the caller fetched it at its start (kind 1

@@ -510,6 +510,12 @@ LMN_D void quotients_body(const QuotientArgs& a) {
   typedef const QuotEntry __attribute__((address_space(4))) * ConstTab;
   const ConstTab tab = (ConstTab)(uintptr_t)a.entries;
 #endif
+#if defined(LMN_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+  const QuotDev& qd = *a.dev;
+#else
+  // (the same for the batches' sums and points: written before this launch, never during it)
+  const QuotDev __attribute__((address_space(4)))& qd = *(const QuotDev __attribute__((address_space(4)))*)(uintptr_t)a.dev;
+#endif
   const uint32_t Q = (1u << a.log_rows) / QUOT_ROWS;
   const uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x;  // row inside the block handled by this launch
   if (s0 >= Q) return;
@@ -525,9 +531,9 @@ LMN_D void quotients_body(const QuotientArgs& a) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int e = k * NB + b;
-      CM31 dx{m_sub(a.prx[b].a, x), a.prx[b].b};
-      CM31 dy{m_sub(a.pry[b].a, y), a.pry[b].b};
-      den[e] = c_sub(c_mul(dx, a.piy[b]), c_mul(dy, a.pix[b]));
+      CM31 dx{m_sub(qd.prx[b].a, x), qd.prx[b].b};
+      CM31 dy{m_sub(qd.pry[b].a, y), qd.pry[b].b};
+      den[e] = c_sub(c_mul(dx, CM31{qd.piy[b].a, qd.piy[b].b}), c_mul(dy, CM31{qd.pix[b].a, qd.pix[b].b}));
       nrm[e] = c_norm(den[e]);
       pre[e] = e == 0 ? nrm[e] : m_mul(pre[e - 1], nrm[e]);
     }
@@ -571,9 +577,11 @@ LMN_D void quotients_body(const QuotientArgs& a) {
         qacc_fold(acc);
       }
       QM31 num = qacc_reduce(acc);
-      num = q_sub(num, q_add(q_mul_m(a.A[b], ys[k]), a.B[b]));
+      num = q_sub(num, q_add(q_mul_m(QM31{qd.A[b].a, qd.A[b].b, qd.A[b].c, qd.A[b].d}, ys[k]),
+                             QM31{qd.B[b].a, qd.B[b].b, qd.B[b].c, qd.B[b].d}));
       const QM31 term = q_mul_c(num, dinv[k * NB + b]);
-      row = b == 0 ? term : q_add(q_mul(row, a.batch_coeff[b]), term);  // no 0 * coeff product for the first batch
+      row = b == 0 ? term   // no 0 * coeff product for the first batch
+                   : q_add(q_mul(row, QM31{qd.batch_coeff[b].a, qd.batch_coeff[b].b, qd.batch_coeff[b].c, qd.batch_coeff[b].d}), term);
     }
     uint32_t* o = a.out + s;
     o[0] = row.a;
@@ -588,6 +596,7 @@ void launch_quotients(const QuotientArgs& a, lmn_stream_t s) {
   if (LMN_ABLATED(4u)) return;
   if (a.nbatch < 1 || a.nbatch > QUOT_MAX_BATCH) throw LmnError(-100, "quotients: bad batch count");
   if (a.batch_start[a.nbatch] > QUOT_MAX_ENTRIES) throw LmnError(-100, "quotients: too many column samples");
+  if (!a.dev || !a.entries) throw LmnError(-100, "quotients: no batch table");
   if (a.log_size < 2 || a.log_rows < 2 || a.log_rows > a.log_size || (a.row0 & ((1u << a.log_rows) - 1u)) ||
       a.out_stride < (1ull << a.log_rows))
     throw LmnError(-100, "quotients: bad row block");

@@ -109,18 +109,155 @@ void Context::plan_oods_step(ProofRun& r, ChanStep& step) {
   step.copy_words = (uint32_t)(bytes / 4);
 }
 
+void Context::set_sample_points(ProofRun& r, QM31 tt) {
+  QM31 t2 = q_sqr(tt);
+  QM31 tinv = q_inv(q_add_m(t2, 1u));
+  r.oods = QPt{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
+  r.points.assign(1, r.oods);
+  for (size_t p = 1; p < r.neg_step.size(); ++p) r.points.push_back(qpt_add_m(r.oods, r.neg_step[p]));
+}
+
+// stwo::prover::prove's sanity check: the composition polynomial's OODS value must match the AIR at the sampled values
+void Context::check_composition_identity(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
+  QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha, cfg.protocol_variant);
+  if (!q_eq(lhs, rhs) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
+}
+
+// The quotient kernels' tables without the host (kernels.h QuotPrepPlan): the sample batches of every LDE size are a
+// function of the trees' layout alone (ColumnSampleBatch::new_vec groups by point in first-appearance order, as
+// make_quotient_args does); what depends on the sampled values and on the randomness is computed by k_quot_prepare.
+void Context::enqueue_quotient_tables(ProofRun& r, const QM31* d_vals) {
+  LMN_RUN_ALIASES(r);
+  ProofRun::FriPlan& fp = r.fri;
+  struct Col {
+    const uint32_t* lde;
+    int lde_log;
+    std::vector<std::pair<int, uint32_t>> samples;   // (point, index of the sampled value)
+  };
+  std::vector<Col> flat;
+  uint32_t n_samples = 0;
+  for (int t = 0; t < 4; ++t)
+    for (size_t c = 0; c < trees[t]->cols.size(); ++c) {
+      Col f{trees[t]->cols[c].lde, trees[t]->cols[c].log_size + lb, {}};
+      for (size_t p = 0; p < spoints[t][c].size(); ++p) f.samples.push_back({spoints[t][c][p], n_samples++});
+      flat.push_back(f);
+    }
+  std::set<int, std::greater<int>> size_set;
+  for (auto& f : flat) size_set.insert(f.lde_log);
+  sizes.assign(size_set.begin(), size_set.end());
+  QuotPrepPlan* plan = (QuotPrepPlan*)pin_alloc(sizeof(QuotPrepPlan));
+  memset(plan, 0, sizeof *plan);
+  QuotPrepEntry* entries = (QuotPrepEntry*)pin_alloc((size_t)std::max<uint32_t>(n_samples, 1) * sizeof(QuotPrepEntry));
+  plan->n_sizes = (int)sizes.size();
+  plan->n_samples = (int)n_samples;
+  plan->n_maps = std::max(r.comp_log, EVAL_LB);
+  plan->entries = entries;
+  plan->vals = d_vals;
+  QM31* h_vals = (QM31*)result_block(((size_t)n_samples + 1) * sizeof(QM31));
+  plan->vals_host = h_vals;
+  r.h_vals = h_vals;
+  plan->maps = r.d_maps;
+  uint32_t at = 0;
+  for (size_t si = 0; si < sizes.size(); ++si) {
+    const int ls = sizes[si];
+    QuotPrepSize& sz = plan->size[si];
+    std::vector<int> batch_point;
+    std::vector<std::vector<std::pair<const uint32_t*, uint32_t>>> batch_cols;
+    for (auto& f : flat)
+      if (f.lde_log == ls)
+        for (auto& sm : f.samples) {
+          size_t b = 0;
+          while (b < batch_point.size() && batch_point[b] != sm.first) ++b;
+          if (b == batch_point.size()) {
+            batch_point.push_back(sm.first);
+            batch_cols.emplace_back();
+          }
+          batch_cols[b].push_back({f.lde, sm.second});
+        }
+    if (batch_point.size() > (size_t)QUOT_MAX_BATCH) throw LmnError(LMN_ERR_INTERNAL, "too many sample batches");
+    sz.n_batch = (int)batch_point.size();
+    sz.first_entry = at;
+    int local = 0;
+    for (size_t b = 0; b < batch_point.size(); ++b) {
+      sz.batch_start[b] = local;
+      sz.point[b] = batch_point[b];
+      for (auto& cv : batch_cols[b]) {
+        entries[at++] = QuotPrepEntry{cv.first, cv.second, (uint16_t)si, (uint16_t)b};
+        ++local;
+      }
+    }
+    sz.batch_start[batch_point.size()] = local;
+    sz.n_entries = local;
+    if (local > QUOT_MAX_ENTRIES) throw LmnError(LMN_ERR_INTERNAL, "too many column samples");
+    sz.entries_out = (QuotEntry*)arena_.alloc_bytes((size_t)std::max(local, 1) * sizeof(QuotEntry));
+    sz.dev_out = (QuotDev*)arena_.alloc_bytes(sizeof(QuotDev));
+    QuotientArgs a{};
+    a.log_size = ls;
+    a.nbatch = sz.n_batch;
+    for (int b = 0; b <= sz.n_batch; ++b) a.batch_start[b] = sz.batch_start[b];
+    a.entries = sz.entries_out;
+    a.dev = sz.dev_out;
+    a.tw_y = twY_[ls];
+    a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
+    a.row0 = 0;
+    a.log_rows = ls;
+    a.out_stride = 1ull << ls;
+    a.out = arena_.alloc_words(4ull << ls);
+    r.qargs.push_back(a);
+    quots.push_back({ls, a.out, false});
+  }
+  plan->n_entries = (int)at;
+  // the FRI loop's channel is the device's own from here on; the tail's layer table rides along (page-locked -> device)
+  if (fp.planned_ls0 != quots[0].log) plan_fri_layout(r, quots[0].log, quots.back().log);
+  fp.d_chan = r.d_chan;
+  fp.d_tail = nullptr;
+  if (!fp.tail_table.empty()) {
+    const size_t bytes = fp.tail_table.size() * sizeof(FriTailLayer);
+    static_assert(sizeof(FriTailLayer) % 4 == 0, "the tail's table is copied word by word");
+    FriTailLayer* pinned = (FriTailLayer*)pin_alloc(bytes);
+    memcpy(pinned, fp.tail_table.data(), bytes);
+    fp.d_tail = (FriTailLayer*)arena_.alloc_bytes(bytes);
+    plan->copy_src = reinterpret_cast<const uint32_t*>(pinned);
+    plan->copy_dst = reinterpret_cast<uint32_t*>(fp.d_tail);
+    plan->copy_words = (uint32_t)(bytes / 4);
+  }
+  launch_quot_prepare(r.d_chan, plan, stream_);
+}
+
+// The wait for the FRI results is over (run_fri_commit) and the host has not replayed anything yet: roots, relation
+// elements, claimed sums, composition randomness, OODS point (replay_device_transcript), then the sampled values, the
+// composition identity and the quotient randomness - every draw checked against the device's.
+void Context::finish_oods_on_host(ProofRun& r) {
+  LMN_RUN_ALIASES(r);
+  replay_device_transcript(r, [&](QM31 tt) { set_sample_points(r, tt); });
+  size_t k = 0;
+  sampled.assign(4, {});
+  std::vector<QM31> flat;
+  for (int t = 0; t < 4; ++t) {
+    sampled[t].resize(trees[t]->cols.size());
+    for (size_t c = 0; c < trees[t]->cols.size(); ++c)
+      for (size_t p = 0; p < spoints[t][c].size(); ++p) {
+        sampled[t][c].push_back(r.h_vals[k]);
+        flat.push_back(r.h_vals[k++]);
+      }
+  }
+  proof.sampled_values = sampled;
+  channel.mix_felts(flat);
+  check_composition_identity(r);
+  quot_alpha = channel.draw_felt();
+  if (!q_eq(quot_alpha, r.h_vals[k]))
+    throw LmnError(LMN_ERR_INTERNAL, "device/host transcript divergence at the quotient randomness");
+  hm.mark("replay: sampled values, composition identity, quotient randomness");
+}
+
 void Context::run_oods(ProofRun& r) {
   LMN_RUN_ALIASES(r);
   plan_sample_points(r);
   std::map<int, int>& prev_point_of_log = r.prev_point_of_log;
   const std::vector<Pt>& neg_step = r.neg_step;
-  auto set_points = [&](QM31 tt) {
-    QM31 t2 = q_sqr(tt);
-    QM31 tinv = q_inv(q_add_m(t2, 1u));
-    oods = QPt{q_mul(q_sub(q_one(), t2), tinv), q_mul(q_add(tt, tt), tinv)};
-    points.assign(1, oods);
-    for (size_t p = 1; p < neg_step.size(); ++p) points.push_back(qpt_add_m(oods, neg_step[p]));
-  };
+  auto set_points = [&](QM31 tt) { set_sample_points(r, tt); };
   if (!r.dev_fs) set_points(channel.draw_felt());   // (device-resident transcript: run_composition's plan_oods_step)
   plan_eval_jobs(r);   // (device-resident transcript: already made by plan_oods_step)
   sampled.assign(4, {});
@@ -134,6 +271,27 @@ void Context::run_oods(ProofRun& r) {
         hi = std::max(hi, c.log_size + lb);
       }
     if (hi > 0) plan_fri_layout(r, hi, lo);
+  }
+  // unsharded proofs with the device-resident transcript do not wait here: the sampled values stay on the device, where
+  // k_quot_prepare makes the transcript step and the quotient kernels' tables (LMN_HOST_QUOT=1: the wait of round 5)
+  r.quot_dev = r.dev_fs && !shard_.active && getenv("LMN_HOST_QUOT") == nullptr && r.eval_jobs.size() <= (size_t)QUOT_PREP_MAX_SAMPLES &&
+               r.eval_jobs.size() <= (size_t)QUOT_MAX_ENTRIES && !r.eval_jobs.empty();
+  if (r.quot_dev) {
+    std::set<int> lde_sizes;
+    for (int t = 0; t < 4; ++t)
+      for (auto& c : trees[t]->cols) lde_sizes.insert(c.log_size + lb);
+    r.quot_dev = lde_sizes.size() <= (size_t)QUOT_PREP_MAX_SIZES;
+  }
+  if (r.quot_dev) {
+    const QM31* d_vals = nullptr;
+    {
+      StageTimer st(this, log, stream_, C_OODS);
+      eval_at_points(r.eval_jobs, points, comp_log, false, r.d_maps, (int)neg_step.size(), r.d_eval_jobs, &d_vals);
+    }
+    StageTimer st(this, log, stream_, C_QUOT);
+    enqueue_quotient_tables(r, d_vals);
+    hm.mark("oods + quotient tables enqueued (device transcript)");
+    return;
   }
   {
     StageTimer st(this, log, stream_, C_OODS);
@@ -156,16 +314,20 @@ void Context::run_oods(ProofRun& r) {
         for (auto& v : c) flat.push_back(v);
     channel.mix_felts(flat);
   }
-  // sanity check of stwo::prover::prove: composition OODS eval must match the AIR at the samples
-  {
-    QM31 lhs = q_from_partial_evals(sampled[3][0][0], sampled[3][1][0], sampled[3][2][0], sampled[3][3][0]);
-    QM31 rhs = eval_composition_at_point(inst, sampled, oods, elems, comp_alpha, cfg.protocol_variant);
-    if (!q_eq(lhs, rhs) && !LMN_ABLATED(~0u)) throw LmnError(LMN_ERR_CONSTRAINTS, "ProverError(ConstraintsNotSatisfied)");
-  }
+  check_composition_identity(r);
 }
 
 void Context::run_quotients(ProofRun& r) {
   LMN_RUN_ALIASES(r);
+  if (r.quot_dev) {   // tables, randomness and the FRI loop's channel are the device's (enqueue_quotient_tables)
+    sh = false;
+    g = 0;
+    fri_T = std::max(shard_.fri_min_log, (int)cfg.log_last_layer + lb);
+    StageTimer st(this, log, stream_, C_QUOT);
+    for (auto& a : r.qargs) launch_quotients(a, stream_);
+    hm.mark("quotients enqueued");
+    return;
+  }
   // ---- FRI quotients, one secure column per LDE size (descending)
   quot_alpha = channel.draw_felt();
   hm.mark("sampled mixed, oods check, alpha drawn");
@@ -199,7 +361,7 @@ void Context::run_quotients(ProofRun& r) {
     // (each transfer is a blit launch of ~5 us in the proof's one stream)
     size_t n_samples = 0;
     for (auto& f : flat) n_samples += f.samples.size();
-    stage_group_begin(n_samples * sizeof(QuotEntry) + 64 * sizes.size() + 4096);
+    stage_group_begin(n_samples * sizeof(QuotEntry) + (64 + sizeof(QuotDev)) * sizes.size() + 4096);
     std::vector<QuotientArgs> qargs;
     for (int ls : sizes) {
       std::vector<const uint32_t*> ptrs;

@@ -111,9 +111,11 @@ inline void lmn_sync(lmn_stream_t s) {
   // Mode 0 polls.  A proof that has the GPU to itself never waits longer than about a millisecond, and polling is what keeps
   // its latency low; under concurrent load every wait lasts several milliseconds (the GPU is shared), eight polling contexts
   // kept eight CPUs busy, and N ranks in one CPU-limited container starved each other's launch threads
-  // (tools/host_cpu_per_proof.py).  So a wait that outlasts LMN_SPIN_US (default 1200 us) goes on in 50 us sleeps, and a
-  // thread whose recent waits did so starts sleeping after 100 us already; a few short waits bring it back to polling.
-  static const long spin_us = getenv("LMN_SPIN_US") ? atol(getenv("LMN_SPIN_US")) : 1200;
+  // (tools/host_cpu_per_proof.py).  So a wait that outlasts LMN_SPIN_US goes on in 50 us sleeps, and a thread whose recent
+  // waits did so starts sleeping after 100 us already; a few short waits bring it back to polling.  Default 3000 us since
+  // round 6 (1200 before): with the quotient step on the device a solo 2^20-row proof has ONE wait of 2 ms in front of its
+  // decommitment instead of three below a millisecond - at 1200 us it went to sleep in it and woke up 50 - 100 us late.
+  static const long spin_us = getenv("LMN_SPIN_US") ? atol(getenv("LMN_SPIN_US")) : 3000;
   static thread_local int long_waits = 0;   // 0 .. 8: how many of the recent waits on this thread outlasted spin_us
   const long limit_us = long_waits >= 2 ? 100 : spin_us;
   const auto t_start = std::chrono::steady_clock::now();

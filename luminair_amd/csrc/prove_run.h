@@ -60,6 +60,12 @@ struct ProofRun {
   std::vector<EvalJob> eval_jobs;        // one per (column, sample point), sampled_values order (plan_eval_jobs)
   EvalJob* d_eval_jobs = nullptr;        // device copy made by the OODS step's workgroup (device-resident transcript)
   uint32_t bad_mark = 0;                 // this proof's mark of the non-canonical-word verdict
+  // Unsharded proofs go on without the sampled values as well (round 6): k_quot_prepare mixes them, draws the quotient
+  // randomness and writes the quotient kernels' tables on the device; the host's first wait is the one for the FRI results,
+  // where it replays everything from root 1 on (finish_oods_on_host).  LMN_HOST_QUOT=1 keeps the wait in run_oods.
+  bool quot_dev = false;
+  const QM31* h_vals = nullptr;          // page-locked: the sampled values (eval_jobs order) + the device's quotient randomness
+  std::vector<QuotientArgs> qargs;       // the quotient launches, one per LDE size (descending), laid out by run_oods
   // OODS: point 0 = the OODS point, then per trace size the point one trace step before it (plan_sample_points)
   std::map<int, int> prev_point_of_log;
   std::vector<Pt> neg_step;

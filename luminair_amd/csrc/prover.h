@@ -251,6 +251,10 @@ class Context {
   void run_composition(ProofRun& r);
   void run_oods(ProofRun& r);
   void replay_device_transcript(ProofRun& r, const std::function<void(QM31)>& set_points);
+  void set_sample_points(ProofRun& r, QM31 t);          // phase_oods.cpp: the OODS point of the draw t and the mask points
+  void enqueue_quotient_tables(ProofRun& r, const QM31* d_vals);   // phase_oods.cpp: k_quot_prepare + the quotient launches' arguments
+  void finish_oods_on_host(ProofRun& r);                 // phase_oods.cpp: the host's replay of everything from root 1 to the quotient randomness
+  void check_composition_identity(ProofRun& r);          // phase_oods.cpp: stwo's OODS sanity check on the sampled values
   void run_quotients(ProofRun& r);
   void run_fri_commit(ProofRun& r);
   void run_queries(ProofRun& r);
@@ -322,7 +326,7 @@ class Context {
   // d_jobs (device copy of `jobs`, already in place) saves the upload
   std::vector<QM31> eval_at_points(const std::vector<EvalJob>& jobs, const std::vector<QPt>& points, int max_log,
                                    bool split = false, const QM31* d_maps = nullptr, int n_points = 0,
-                                   const EvalJob* d_jobs = nullptr);
+                                   const EvalJob* d_jobs = nullptr, const QM31** device_out = nullptr);
 
   // pinned host staging (bump allocator, reset per proof): async H2D sources / D2H targets
   void begin_op();

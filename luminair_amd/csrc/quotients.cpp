@@ -28,6 +28,7 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
     }
   if (batch_point.size() > (size_t)QUOT_MAX_BATCH) throw LmnError(LMN_ERR_INTERNAL, "too many sample batches");
   QuotientArgs a{};
+  QuotDev qd{};
   a.log_size = ls;
   a.nbatch = (int)batch_point.size();
   std::vector<int> col_idx;
@@ -49,19 +50,20 @@ QuotientArgs Context::make_quotient_args(int ls, const std::vector<const uint32_
       col_idx.push_back(cv.first);
       coeff_c.push_back(q_mul(alpha, lc));
     }
-    a.A[b] = A;
-    a.B[b] = B;
-    a.batch_coeff[b] = q_pow(quot_alpha, batch_cols[b].size());
-    a.prx[b] = {pt.x.a, pt.x.b};
-    a.pix[b] = {pt.x.c, pt.x.d};
-    a.pry[b] = {pt.y.a, pt.y.b};
-    a.piy[b] = {pt.y.c, pt.y.d};
+    qd.A[b] = A;
+    qd.B[b] = B;
+    qd.batch_coeff[b] = q_pow(quot_alpha, batch_cols[b].size());
+    qd.prx[b] = {pt.x.a, pt.x.b};
+    qd.pix[b] = {pt.x.c, pt.x.d};
+    qd.pry[b] = {pt.y.a, pt.y.b};
+    qd.piy[b] = {pt.y.c, pt.y.d};
   }
   a.batch_start[batch_point.size()] = (int)col_idx.size();
   if (col_idx.size() > (size_t)QUOT_MAX_ENTRIES) throw LmnError(LMN_ERR_INTERNAL, "too many column samples");
   std::vector<QuotEntry> entries(col_idx.size());
   for (size_t k = 0; k < col_idx.size(); ++k) entries[k] = {cols[col_idx[k]], coeff_c[k]};
   a.entries = upload_vec(entries);
+  a.dev = (const QuotDev*)stage_upload(&qd, sizeof qd);
   a.tw_y = twY_[ls];
   a.tw_x = ls >= 2 ? twX_[ls] : nullptr;
   a.row0 = 0;

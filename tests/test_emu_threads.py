@@ -11,7 +11,9 @@ import numpy as np
 from luminair_amd import backend, synthetic as syn
 
 
-def _pies():
+def _pies(small=False):
+    if small:   # the thread-sanitizer run: every emulated lane is a fiber switch the sanitizer tracks
+        return [syn.config2_add_only(40, 1), syn.chain_graph(60, 3), syn.config2_add_only(200, 5), syn.simple_example()]
     return [syn.config2_add_only(100, 1), syn.chain_graph(300, 3), syn.config2_add_only(1 << 11, 5), syn.chain_graph(40, 9),
             syn.chain_graph(1 << 12, 7), syn.simple_example()]
 
@@ -20,9 +22,9 @@ def test_emu_contexts_in_concurrent_threads(root):
     run_concurrent_contexts(os.path.join(root, "tests", "emu", "libluminair_emu.so"))
 
 
-def run_concurrent_contexts(so_path):
+def run_concurrent_contexts(so_path, small=False):
     lib = backend.Library(so_path)
-    pies = [[(k, r, len(r)) for k, r in tabs] for tabs in _pies()]
+    pies = [[(k, r, len(r)) for k, r in tabs] for tabs in _pies(small)]
     seq = backend.Context(0, None, lib)
     want = [seq.prove_tables(p) for p in pies]
     seq.close()
@@ -44,7 +46,7 @@ def run_concurrent_contexts(so_path):
     def submitter():
         try:
             ctx = backend.Context(0, None, lib)
-            for i in (1, 3):
+            for i in (1, len(pies) - 1):
                 ctx.prove_submit(pies[i])
                 assert ctx.prove_wait() == want[i]
             ctx.close()
@@ -65,7 +67,7 @@ if __name__ == "__main__":
     # `python tests/test_emu_threads.py <library>`: the same scenario without pytest (tests/test_sanitizers.py runs it in an
     # interpreter that has the thread sanitizer's runtime preloaded - and nothing else that brings threads of its own)
     import sys
-    run_concurrent_contexts(sys.argv[1])
+    run_concurrent_contexts(sys.argv[1], small=True)
     # error paths and reuse from a second thread
     lib_ = backend.Library(sys.argv[1])
     ctx_ = backend.Context(0, None, lib_)

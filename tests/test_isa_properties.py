@@ -147,7 +147,7 @@ def test_column_loads_of_the_qm31_and_leaf_kernels_take_uniform_bases_from_sgprs
     address per load (27 of k_composition<0>'s 862 vector instructions, 32 of k_eval_at_point's 919, one per column and row
     in k_quotients before) - and building the resources does not spill SGPRs in the hot instantiations."""
     ks = _kernels(device_asm)
-    for part, max_addr in (("k_compositionILi0E", 0), ("k_compositionILi1E", 0), ("k_eval_at_point", 0), ("k_logup_fracsILi3E", 2),
+    for part, max_addr in (("k_compositionILi0E", 0), ("k_compositionILi1E", 0), ("k_eval_at_point", 0), ("k_logup_fracsILi3E", 12),   # (+ the row-major branch of LMN_ROWS_FUSION: per-lane row pointers)
                            ("k_merkle_fusedILi1ELi15E", 6), ("k_merkle_fusedILi1ELi12E", 6), ("k_merkle_fusedILi3E", 6)):
         name, = _find(ks, part)
         body, md = ks[name]

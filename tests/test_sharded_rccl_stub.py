@@ -39,7 +39,10 @@ def _worker(rank, world, fri_min_log, id_q, out_q):
         return ctx                                               # shared memory by id and is re-joined by every rank in order
     stats = []
     proofs = tsp._prove_all(make, stats)
-    assert all(c > 0 and g > 0 for c, _, g in stats), stats      # both primitives ran through the built-in transport
+    # both primitives ran through the built-in transport (blow-ups above 2 - the last cases - keep every column's
+    # coefficients on every rank: all-gathers only)
+    blowup2 = [len(c) <= 4 or len(c[4]) <= 3 or c[4][3] == 1 for c in tsp._cases()]
+    assert all((c > 0) == b2 and g > 0 for (c, _, g), b2 in zip(stats, blowup2)), stats
     # a rejected re-shard keeps the transport; clearing it returns the context to unsharded proofs
     ctx = make(False)
     with pytest.raises(backend.LuminairBackendError):
