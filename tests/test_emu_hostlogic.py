@@ -515,12 +515,19 @@ def test_emu_device_and_host_transcript_give_the_same_bytes_and_errors(root, mon
         monkeypatch.setenv("LMN_CHAN_STEP_SEPARATE", "1")      # the steps as launches of their own (k_chan_step)
         assert ctx.prove_tables(t, luts) == dev
         monkeypatch.delenv("LMN_CHAN_STEP_SEPARATE")
+        # round 6: the step in front of the FRI quotient kernels (mix of the sampled values, quotient randomness, line
+        # coefficients and tables) is made by k_quot_prepare by default; LMN_HOST_QUOT=1 puts the host's wait back
+        monkeypatch.setenv("LMN_HOST_QUOT", "1")
+        assert ctx.prove_tables(t, luts) == dev
+        monkeypatch.delenv("LMN_HOST_QUOT")
     tabs = syn.chain_graph(300, 3)
-    for env in (None, "1"):
-        if env:
+    for env in (None, "1", "quot"):
+        monkeypatch.delenv("LMN_HOST_FS", raising=False)
+        monkeypatch.delenv("LMN_HOST_QUOT", raising=False)
+        if env == "1":
             monkeypatch.setenv("LMN_HOST_FS", env)
-        else:
-            monkeypatch.delenv("LMN_HOST_FS", raising=False)
+        elif env == "quot":
+            monkeypatch.setenv("LMN_HOST_QUOT", "1")
         bad = [(k, r.copy(), len(r)) for k, r in tabs]
         bad[0][1][5, 9] = 0x7fffffff
         with pytest.raises(backend.LuminairBackendError) as e:

@@ -551,6 +551,7 @@ def test_gpu_storage_and_fusion_switches_do_not_change_the_proof(gpu_prover, mon
     for env in ({"LMN_MERKLE_FULL": "1"}, {"LMN_MERKLE_BELOW_MIN_LOG": "99"}, {"LMN_NO_JOIN_FUSION": "1"},
                 {"LMN_NO_FOLD_FUSION": "1"},   # every FRI fold a launch of its own
                 {"LMN_HOST_FS": "1"},    # round 5: the transcript of the commitment phases back on the host
+                {"LMN_HOST_QUOT": "1"},  # round 6: the step in front of the quotient kernels back on the host (3 waits)
                 {"LMN_CHAN_STEP_SEPARATE": "1"}):   # ... or on the device in launches of their own
         for k, v in env.items():
             monkeypatch.setenv(k, v)
