@@ -16,6 +16,17 @@
 
 #include "capi_internal.h"
 
+// Sanitizer builds of the emulated batch library (tests/emu/build_emu.sh batch asan | tsan): every switch between a worker
+// thread's scheduler context and a member fiber is announced, as tests/emu/emu_runtime.cpp does for the kernel fibers.
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define LMN_BATCH_ASAN 1
+#endif
+#if defined(__SANITIZE_THREAD__)
+#include <sanitizer/tsan_interface.h>
+#define LMN_BATCH_TSAN 1
+#endif
+
 struct lmn_batch;
 namespace lmn {
 
@@ -194,16 +205,43 @@ struct BatchFiber {
   bool done = true;
   bool waiting = false;
   uint64_t waiting_gen = 0;
+#ifdef LMN_BATCH_ASAN
+  void* fake_stack = nullptr;
+#endif
+#ifdef LMN_BATCH_TSAN
+  void* tsan_fiber = nullptr;
+#endif
 };
 static thread_local ucontext_t tls_sched_ctx;
 static thread_local BatchFiber* tls_fiber = nullptr;
+#ifdef LMN_BATCH_ASAN
+static thread_local void* tls_sched_fake = nullptr;
+static thread_local const void* tls_sched_bottom = nullptr;
+static thread_local size_t tls_sched_size = 0;
+#endif
+#ifdef LMN_BATCH_TSAN
+static thread_local void* tls_sched_tsan = nullptr;
+#endif
+// member fiber -> its worker thread's scheduler (`last`: the fiber is finished) and back
+static void fiber_yield(BatchFiber* f) {
+#ifdef LMN_BATCH_ASAN
+  __sanitizer_start_switch_fiber(&f->fake_stack, tls_sched_bottom, tls_sched_size);
+#endif
+#ifdef LMN_BATCH_TSAN
+  __tsan_switch_to_fiber(tls_sched_tsan, 0);
+#endif
+  swapcontext(&f->ctx, &tls_sched_ctx);
+#ifdef LMN_BATCH_ASAN
+  __sanitizer_finish_switch_fiber(f->fake_stack, &tls_sched_bottom, &tls_sched_size);
+#endif
+}
 
 static void wait_generation(BatchGroup& g, uint64_t gen) {
   if (tls_fiber) {
     BatchFiber* f = tls_fiber;
     f->waiting = true;
     f->waiting_gen = gen;
-    while (g.generation.load(std::memory_order_acquire) == gen) swapcontext(&f->ctx, &tls_sched_ctx);
+    while (g.generation.load(std::memory_order_acquire) == gen) fiber_yield(f);
     f->waiting = false;
     return;
   }
@@ -535,9 +573,18 @@ static void run_member(lmn_batch* b, uint32_t me) {
 
 static void fiber_entry() {
   lmn::BatchFiber* f = lmn::tls_fiber;
+#ifdef LMN_BATCH_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &lmn::tls_sched_bottom, &lmn::tls_sched_size);
+#endif
   run_member(f->batch, (uint32_t)f->member);
   f->done = true;
   // returning resumes uc_link = the scheduler
+#ifdef LMN_BATCH_ASAN
+  __sanitizer_start_switch_fiber(nullptr, lmn::tls_sched_bottom, lmn::tls_sched_size);
+#endif
+#ifdef LMN_BATCH_TSAN
+  __tsan_switch_to_fiber(lmn::tls_sched_tsan, 0);
+#endif
 }
 
 constexpr size_t BATCH_FIBER_STACK = 1u << 20;
@@ -588,6 +635,11 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
       f.done = false;
       f.waiting = false;
       makecontext(&f.ctx, fiber_entry, 0);
+#ifdef LMN_BATCH_TSAN
+      lmn::tls_sched_tsan = __tsan_get_current_fiber();
+      if (f.tsan_fiber) __tsan_destroy_fiber(f.tsan_fiber);
+      f.tsan_fiber = __tsan_create_fiber(0);
+#endif
     }
     uint32_t left = mine;
     while (left) {
@@ -598,7 +650,16 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
         if (f.waiting && b->group.generation.load(std::memory_order_acquire) == f.waiting_gen) continue;
         lmn::tls_fiber = &f;
         lmn::tls_batch_member = f.member;
+#ifdef LMN_BATCH_ASAN
+        __sanitizer_start_switch_fiber(&lmn::tls_sched_fake, f.stack, BATCH_FIBER_STACK);
+#endif
+#ifdef LMN_BATCH_TSAN
+        __tsan_switch_to_fiber(f.tsan_fiber, 0);
+#endif
         swapcontext(&lmn::tls_sched_ctx, &f.ctx);
+#ifdef LMN_BATCH_ASAN
+        __sanitizer_finish_switch_fiber(lmn::tls_sched_fake, nullptr, nullptr);
+#endif
         lmn::tls_fiber = nullptr;
         progress = true;
         if (f.done) --left;

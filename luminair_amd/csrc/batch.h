@@ -12,7 +12,9 @@
 // rendezvous too: one stream wait per batch instead of one per proof.
 #pragma once
 #ifdef LMN_BATCH
+#ifndef LMN_EMU
 #include <hip/hip_runtime.h>
+#endif   // (the emulation build's stand-ins for the HIP calls used here: platform.h)
 
 #include <atomic>
 #include <cstdint>
@@ -97,7 +99,7 @@ struct alignas(128) BatchMember {
 struct BatchGroup {
   int slots = 1;                 // z extent of every launch (members that left keep an inactive slot)
   int n_alloc = 1;               // members allocated (slots of the largest batch)
-  hipStream_t stream = nullptr;
+  hipStream_t stream{};
   bool solo = false;
   // (members still taking part) << 32 | (members arrived at the rendezvous in progress): one wait-free fetch_add per
   // arrival - lock-step members arrive within a microsecond of each other, a lock here is a convoy

@@ -263,8 +263,48 @@ struct LmnError : std::runtime_error {
 };
 
 void lmn_emu_run(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem);
+#ifdef LMN_BATCH
+// ---- emulation of the lock-step batch build (tests/emu/build_emu.sh batch; round 6): batch.h / batch.cpp - rendezvous, member
+// fibers, argument tables, the batched copy list - compiled as they are, the dozen HIP calls they make served from host
+// memory, the trampoline run through lmn_emu_run with blockIdx.z = the member.  Lets the CPU suite and the sanitizers reach
+// the one part of the host code that otherwise exists only in the gfx950 build.
+typedef int hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0, hipErrorNotReady = 600;
+constexpr unsigned hipHostMallocDefault = 0u, hipStreamNonBlocking = 1u;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s_, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated HIP call failed"; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s_, unsigned) { *s_ = 0; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+template <class F> inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+#define LMN_HIP_CHECK(expr)                                                          \
+  do {                                                                               \
+    if ((expr) != hipSuccess) throw LmnError(-100, "emulated HIP call failed");      \
+  } while (0)
+#define __global__
+#define __device__
+#define __forceinline__ inline
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) lmn_emu_run([&]() { kernel(__VA_ARGS__); }, grid, block, smem)
+#include "batch.h"
+#define LMN_LAUNCH(kernel, grid, block, smem, stream, ...) ::lmn::batch_launch<&kernel>(grid, block, smem, stream, __VA_ARGS__)
+#define LMN_BATCH_COPY(dst, src, n, dir) if (::lmn::batch_copy((dst), (src), (n), (dir))) return
+#else
 #define LMN_LAUNCH(kernel, grid, block, smem, stream, ...) \
   lmn_emu_run([&]() { kernel(__VA_ARGS__); }, grid, block, smem)
+#define LMN_BATCH_COPY(dst, src, n, dir) do { } while (0)
+#endif
 
 inline void* lmn_dev_malloc(size_t bytes) {
   void* p = malloc(bytes ? bytes : 1);
@@ -272,15 +312,43 @@ inline void* lmn_dev_malloc(size_t bytes) {
   return p;
 }
 inline void lmn_dev_free(void* p) { free(p); }
-inline void lmn_h2d(void* d, const void* s, size_t n, lmn_stream_t) { memcpy(d, s, n); }
-inline void lmn_d2h(void* d, const void* s, size_t n, lmn_stream_t) { memcpy(d, s, n); }
-inline void lmn_d2d(void* d, const void* s, size_t n, lmn_stream_t) { memmove(d, s, n); }
-inline void lmn_memset(void* d, int v, size_t n, lmn_stream_t) { memset(d, v, n); }
+// (emulated batch build: the members' transfers go through batch_copy's list and their waits are rendezvous, as on the GPU)
+inline void lmn_h2d(void* d, const void* s, size_t n, lmn_stream_t) {
+  LMN_BATCH_COPY(d, s, n, 0);
+  memcpy(d, s, n);
+}
+inline void lmn_d2h(void* d, const void* s, size_t n, lmn_stream_t) {
+  LMN_BATCH_COPY(d, s, n, 1);
+  memcpy(d, s, n);
+}
+inline void lmn_d2d(void* d, const void* s, size_t n, lmn_stream_t) {
+  LMN_BATCH_COPY(d, s, n, 2);
+  memmove(d, s, n);
+}
+inline void lmn_memset(void* d, int v, size_t n, lmn_stream_t) {
+  LMN_BATCH_COPY(d, (const void*)(uintptr_t)(unsigned char)v, n, 3);
+  memset(d, v, n);
+}
+#ifdef LMN_BATCH
+inline void lmn_sync(lmn_stream_t s) { ::lmn::batch_sync(s); }
+inline void* lmn_host_alloc_pinned(size_t bytes) {
+  void* p = malloc(bytes ? bytes : 1);
+  ::lmn::batch_register_pinned(p, bytes);
+  return p;
+}
+inline void lmn_host_free_pinned(void* p) {
+  ::lmn::batch_unregister_pinned(p);
+  free(p);
+}
+inline void lmn_host_register_range(void* p, size_t bytes) { ::lmn::batch_register_pinned(p, bytes); }
+inline void lmn_host_unregister_range(void* p) { ::lmn::batch_unregister_pinned(p); }
+#else
 inline void lmn_sync(lmn_stream_t) {}
 inline void* lmn_host_alloc_pinned(size_t bytes) { return malloc(bytes ? bytes : 1); }
 inline void lmn_host_free_pinned(void* p) { free(p); }
 inline void lmn_host_register_range(void*, size_t) {}
 inline void lmn_host_unregister_range(void*) {}
+#endif
 #include <chrono>
 typedef double* lmn_event_t;
 inline lmn_event_t lmn_event_create() { return new double(0.0); }

@@ -8,8 +8,9 @@ LMN_EMU_SANITIZER set (tests/conftest.py redirects the library path).  Any repor
 
     python -m pytest tests -m sanitize -x -q          (about 10 minutes on 8 CPUs)
 
-Not covered: csrc/batch.cpp (the lock-step batch library's fibers and rendezvous exist only in the gfx950 -DLMN_BATCH
-build; its tests are tests/test_batch.py -m gpu)."""
+csrc/batch.cpp (the lock-step batch library: member fibers on hand-made stacks, wait-free rendezvous, argument tables, the
+batched copy list) is reached through the emulated batch build (build_emu.sh batch asan | tsan; tests/test_batch_emu.py's
+scenarios as a plain script)."""
 import os
 import subprocess
 import sys
@@ -102,3 +103,36 @@ def test_concurrent_contexts_under_thread_sanitizer():
     tail = (r.stdout[-6000:] + "\n---- stderr ----\n" + r.stderr[-6000:])
     assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, tail
     assert "concurrent contexts ok" in r.stdout, tail
+
+
+def _run_script(runtime, options, script, lib, marker, timeout=3600, no_aslr=False):
+    env = dict(os.environ, LD_PRELOAD=runtime, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env.update(options)
+    cmd = (["setarch", os.uname().machine, "-R"] if no_aslr else []) + [sys.executable, os.path.join(ROOT, "tests", script), lib]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    tail = (r.stdout[-6000:] + "\n---- stderr ----\n" + r.stderr[-6000:])
+    assert r.returncode == 0 and marker in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr and \
+        "WARNING: ThreadSanitizer" not in r.stderr, tail
+
+
+@pytest.mark.sanitize
+def test_lock_step_batches_under_address_and_undefined_behaviour_sanitizers():
+    """csrc/batch.cpp + batch.h on the emulation runtime: KAT batches with more members than worker threads, a pie that fails
+    alone (constraints, non-canonical word), refused shapes, growing batches, four operators"""
+    import test_batch_emu
+    rt = _runtime("libasan.so")
+    lib = test_batch_emu._build("asan")
+    _run_script(rt, {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1:halt_on_error=1:detect_stack_use_after_return=0:verify_asan_link_order=0",
+                     "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}, "test_batch_emu.py", lib, "emulated batches ok")
+
+
+@pytest.mark.sanitize
+def test_lock_step_batches_under_thread_sanitizer():
+    """the same scenarios: up to eight worker threads carry the member fibers, the last arriver of every rendezvous launches
+    for everybody"""
+    import test_batch_emu
+    rt = _runtime("libtsan.so")
+    lib = test_batch_emu._build("tsan")
+    _run_script(rt, {"TSAN_OPTIONS": "halt_on_error=1:second_deadlock_stack=1:report_signal_unsafe=0"}, "test_batch_emu.py", lib,
+                "emulated batches ok", no_aslr=True)
