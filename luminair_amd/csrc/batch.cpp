@@ -401,6 +401,7 @@ static void complete_rendezvous(BatchGroup& g, BatchMember& me) {
     if (!g.failed.load()) {
       flush_copies(g, me);
       if (me.kind == 1) {
+        g.region = me.region;
         g.grid = dim3(0, 0, 1);
         for (int i = 0; i < g.slots; ++i) {
           BatchMember& m = g.member[i];
@@ -470,7 +471,7 @@ unsigned char* batch_launch_begin(BatchGroup& g, const void* fn, void (*do_launc
     }
   }
   const size_t region = table_alloc(g, me.tbl_off, me.epoch, slot_bytes * (size_t)g.slots);
-  g.region = region;   // every member writes the same value
+  me.region = region;   // (every member computes the same value; the group's copy is set by the last arriver: TSan, round 6)
   me.kind = 1;
   me.fn = fn;
   me.do_launch = do_launch;

@@ -85,6 +85,7 @@ struct alignas(128) BatchMember {
   uint64_t epoch = 0;            // synchronisations the member has passed
   uint32_t gx = 0, gy = 0, bx = 0, by = 0;
   size_t smem = 0, slot_bytes = 0;
+  size_t region = 0;             // the member's own view of the launch's table region (identical on all members)
   int kind = 0;                  // 1 launch, 2 wait
   bool present = false;          // arrived at the rendezvous in progress
   uint64_t t_arrive = 0, t_resume = 0, ns_busy = 0;   // instrumentation: the member's own host time between rendezvous

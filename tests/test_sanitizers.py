@@ -105,10 +105,10 @@ def test_concurrent_contexts_under_thread_sanitizer():
     assert "concurrent contexts ok" in r.stdout, tail
 
 
-def _run_script(runtime, options, script, lib, marker, timeout=3600, no_aslr=False):
+def _run_script(runtime, options, script, lib, marker, timeout=3600, no_aslr=False, args=()):
     env = dict(os.environ, LD_PRELOAD=runtime, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     env.update(options)
-    cmd = (["setarch", os.uname().machine, "-R"] if no_aslr else []) + [sys.executable, os.path.join(ROOT, "tests", script), lib]
+    cmd = (["setarch", os.uname().machine, "-R"] if no_aslr else []) + [sys.executable, os.path.join(ROOT, "tests", script), lib] + list(args)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     tail = (r.stdout[-6000:] + "\n---- stderr ----\n" + r.stderr[-6000:])
     assert r.returncode == 0 and marker in r.stdout, tail
@@ -129,10 +129,11 @@ def test_lock_step_batches_under_address_and_undefined_behaviour_sanitizers():
 
 @pytest.mark.sanitize
 def test_lock_step_batches_under_thread_sanitizer():
-    """the same scenarios: up to eight worker threads carry the member fibers, the last arriver of every rendezvous launches
-    for everybody"""
+    """16-row pies (KAT batches on two worker threads, a pie that fails alone): up to eight worker threads carry the member
+    fibers, the last arriver of every rendezvous launches for everybody.  One finding (round 6), fixed: every member stored
+    the launch's table region into the group (`g.region`, the same value from all of them)"""
     import test_batch_emu
     rt = _runtime("libtsan.so")
     lib = test_batch_emu._build("tsan")
     _run_script(rt, {"TSAN_OPTIONS": "halt_on_error=1:second_deadlock_stack=1:report_signal_unsafe=0"}, "test_batch_emu.py", lib,
-                "emulated batches ok", no_aslr=True)
+                "emulated batches ok", no_aslr=True, args=("small",))
