@@ -16,9 +16,6 @@ template <int ROWS>
 LMN_KERNEL k_transpose_pad(const uint32_t* __restrict__ rows, uint64_t n_rows, int ncols, uint64_t size,
                            uint32_t* __restrict__ cols, PadRow pad, uint32_t* __restrict__ bad_flag, uint32_t magic,
                            uint64_t out_stride, uint64_t blk_row0, uint32_t bad_value) {
-#if defined(LMN_TRANSPOSE_PRIO) && defined(__HIP_DEVICE_COMPILE__) && !defined(LMN_EMU)
-  __builtin_amdgcn_s_setprio(LMN_TRANSPOSE_PRIO);   // experiment build: a latency-bound kernel with next to no VALU work ahead of the issue-bound ones
-#endif
   LMN_DYN_SMEM(uint32_t, tile);  // ROWS x stride
   // odd row stride: the column-major read below walks rows at that stride, and an even one (16 words for the 15 columns of
   // Add) maps the rows of a column onto 2 of the 32 LDS banks
