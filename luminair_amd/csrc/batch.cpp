@@ -584,7 +584,10 @@ static void fiber_entry() {
   __sanitizer_start_switch_fiber(nullptr, lmn::tls_sched_bottom, lmn::tls_sched_size);
 #endif
 #ifdef LMN_BATCH_TSAN
+  // not by returning: this frame's function-exit event would be recorded after the switch, i.e. popped from the SCHEDULER's
+  // shadow stack - one entry too many per finished member, until the worker thread's own frames underflow it
   __tsan_switch_to_fiber(lmn::tls_sched_tsan, 0);
+  setcontext(&lmn::tls_sched_ctx);
 #endif
 }
 
@@ -678,7 +681,12 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
       if (b->pending == 0) b->cv_done.notify_all();
     }
   }
-  for (auto& f : fibers) fiber_stack_free(f.stack);
+  for (auto& f : fibers) {
+#ifdef LMN_BATCH_TSAN
+    if (f.tsan_fiber) __tsan_destroy_fiber(f.tsan_fiber);
+#endif
+    fiber_stack_free(f.stack);
+  }
 }
 
 extern "C" {

@@ -84,21 +84,21 @@ def scenario_operators(batch_so):
         solo.close()
 
 
-def scenario_kat_and_fewer_threads_than_members(batch_so, kat_bytes):
+def scenario_kat_and_fewer_threads_than_members(batch_so, kat_bytes, members=5):
     os.environ["LMN_BATCH_THREADS"] = "2"          # five members on two worker threads: three fibers on one of them
     try:
-        bk = BatchProver(0, 5, library_path=batch_so)
+        bk = BatchProver(0, members, library_path=batch_so)
     finally:
         del os.environ["LMN_BATCH_THREADS"]
     try:
         kat = _pie(syn.simple_example())
-        assert bk.prove_batch([kat] * 5) == [kat_bytes] * 5
+        assert bk.prove_batch([kat] * members) == [kat_bytes] * members
         assert bk.prove_batch([kat] * 2) == [kat_bytes] * 2    # a batch smaller than the number of slots
     finally:
         bk.close()
 
 
-def scenario_failures(batch_so, rows=64):
+def scenario_failures(batch_so, rows=64, repeats=2):
     solo = _solo(backend.VARIANT_PINNED)
     bp = BatchProver(0, 4, protocol_variant=backend.VARIANT_PINNED, library_path=batch_so)
     try:
@@ -122,7 +122,7 @@ def scenario_failures(batch_so, rows=64):
         rc, rcs, out = _raw_batch(bp, [good[0], bad, good[2], good[3]])
         assert rc == backend.ERR_INVALID_ARGUMENT and rcs == [0, backend.ERR_INVALID_ARGUMENT, 0, 0], (rc, rcs)
         assert [out[i] for i in (0, 2, 3)] == [want[i] for i in (0, 2, 3)]
-        for _ in range(2):
+        for _ in range(repeats):
             assert bp.prove_batch(good) == want
     finally:
         bp.close()
@@ -150,10 +150,13 @@ def scenario_growth(batch_so):
 
 def run_all(batch_so, small=False):
     kat = open(os.path.join(ROOT, "tests", "golden", "kat_simple", "proof"), "rb").read()
-    scenario_kat_and_fewer_threads_than_members(batch_so, kat)
-    scenario_failures(batch_so, 12 if small else 64)
-    if small:     # the thread sanitizer tracks every fiber switch of every emulated lane: 16-row pies only
+    if small:     # the thread sanitizer tracks every fiber switch of every emulated lane (~30 s per 16-row proof): three
+        # members on two worker threads, a smaller batch, a refused mix, a bad pie failing alone, the slot proving again
+        scenario_kat_and_fewer_threads_than_members(batch_so, kat, members=3)
+        scenario_failures(batch_so, 12, repeats=1)
         return
+    scenario_kat_and_fewer_threads_than_members(batch_so, kat)
+    scenario_failures(batch_so)
     scenario_growth(batch_so)
     scenario_operators(batch_so)
 
