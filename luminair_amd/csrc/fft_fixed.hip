@@ -475,12 +475,18 @@ bool launch_fft_rows_fixed(uint32_t* coeffs, uint64_t col_stride, const uint32_t
   return true;
 }
 
+// experiment knob (docs/SWITCHES.md): bytes of unused dynamic LDS per transform workgroup - caps how many of them a CU holds
+static size_t fx_lds_pad() {
+  static const size_t pad = getenv("LMN_FFT_LDS_PAD") ? (size_t)atol(getenv("LMN_FFT_LDS_PAD")) : 0;
+  return pad;
+}
+
 template <bool INV, int RBITS, int CB, bool LO0, bool ZX = false>
 static void launch_fx(uint32_t* data, uint64_t col_stride, const uint32_t* src, uint64_t src_stride, int lo, int log_n,
                       const TwPtrs& tw, uint32_t scale_log, int ncols, int cpb, uint32_t h_off, int xcd, lmn_stream_t s) {
   using S = FxShape<RBITS, CB, LO0>;
   const unsigned tiles = 1u << (log_n - S::TB);
-  const size_t smem = (size_t)4 * S::LDS_WORDS;
+  const size_t smem = (size_t)4 * S::LDS_WORDS + fx_lds_pad();
 #if !defined(LMN_EMU) && !defined(LMN_BATCH)
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_fx<INV, RBITS, CB, LO0, ZX>, 160 * 1024);
 #endif
@@ -545,7 +551,7 @@ template <int RBITS>
 static void launch_ie(uint32_t* coeffs, uint64_t coeff_stride, uint32_t* lde, uint64_t lde_stride, const TwPtrs& itw,
                       const TwPtrs& tw_ext, uint32_t scale_log, int ncols, lmn_stream_t s) {
   using S = FxShape<RBITS, 4, false>;
-  const size_t smem = (size_t)8 * S::LDS_WORDS;
+  const size_t smem = (size_t)8 * S::LDS_WORDS + fx_lds_pad();
 #if !defined(LMN_EMU) && !defined(LMN_BATCH)
   if (smem > 64 * 1024) allow_big_lds((const void*)k_fft_interp_extend_fx<RBITS>, 160 * 1024);
 #endif

@@ -616,6 +616,9 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
       size % ((uint32_t)TPB << sub) != 0)
     throw LmnError(-100, "merkle_fused: bad arguments");
   const dim3 g(cdiv(size >> sub, TPB)), b(TPB);
+  // experiment knob (docs/SWITCHES.md): bytes of unused dynamic LDS per workgroup - caps the workgroups of these issue-bound
+  // launches per CU (24 KB static + pad; 5 fit by registers) so that HBM-bound launches of other proofs find room next to them
+  static const size_t lds_pad = getenv("LMN_MERKLE_LDS_PAD") ? (size_t)atol(getenv("LMN_MERKLE_LDS_PAD")) : 0;
   const MerkleFold none{};
   // a null p[l] (l < sub only: the levels a lane keeps in registers) is a level the caller does not want written
   for (int l = sub; l <= nfused; ++l)
@@ -623,29 +626,29 @@ void launch_merkle_fused(const uint32_t* prev, const MerkleSegs& sg, int ncols, 
   if (fold && fold->below) {
     if (prev || fold->src || ncols < 1 || fold->below_ncols < 1 || fold->below_ncols > 8)
       throw LmnError(-100, "merkle_fused: a start level over its own leaf level has columns, no stored children and <= 8 leaf columns");
-    LMN_LAUNCH(k_merkle_fused<4>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+    LMN_LAUNCH(k_merkle_fused<4>, g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
   } else if (fold) {
     if (prev || ncols != 4) throw LmnError(-100, "merkle_fused: a folded level is a leaf level of 4 coordinate columns");
-    LMN_LAUNCH(k_merkle_fused<3>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
+    LMN_LAUNCH(k_merkle_fused<3>, g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, *fold);
   } else if (!prev && ncols <= 16 && sg.n[0] == ncols) {
     // the leaf's zero message words are compile-time zeros of the instantiation (blake2s.h b2_compress_fresh_nz)
     if (ncols <= 4) {
       MerkleFold leaf4 = none;
       if (LMN_ABLATED(128u)) leaf4.below_ncols = -128;
-      LMN_LAUNCH((k_merkle_fused<1, 4>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, leaf4);
+      LMN_LAUNCH((k_merkle_fused<1, 4>), g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, leaf4);
     }
     else if (ncols <= 8)
-      LMN_LAUNCH((k_merkle_fused<1, 8>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+      LMN_LAUNCH((k_merkle_fused<1, 8>), g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
     else if (ncols <= 12)
-      LMN_LAUNCH((k_merkle_fused<1, 12>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+      LMN_LAUNCH((k_merkle_fused<1, 12>), g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
     else if (ncols <= 15)
-      LMN_LAUNCH((k_merkle_fused<1, 15>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+      LMN_LAUNCH((k_merkle_fused<1, 15>), g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
     else
-      LMN_LAUNCH((k_merkle_fused<1, 16>), g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+      LMN_LAUNCH((k_merkle_fused<1, 16>), g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
   } else if (prev && ncols == 0)
-    LMN_LAUNCH(k_merkle_fused<2>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    LMN_LAUNCH(k_merkle_fused<2>, g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
   else
-    LMN_LAUNCH(k_merkle_fused<0>, g, b, 0, s, prev, sg, ncols, size, outs, sub, nfused, none);
+    LMN_LAUNCH(k_merkle_fused<0>, g, b, lds_pad, s, prev, sg, ncols, size, outs, sub, nfused, none);
 }
 
 void launch_merkle_small(const uint32_t* prev, const MerkleSegs& sg, int ncols, uint32_t size,
