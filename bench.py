@@ -5,7 +5,7 @@
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one BATCH of synthetic input: `--inflight` (default 8) independent 2^20-row
+A "step" is one pass of the hot path over one BATCH of synthetic input: `--inflight` (default 24; 8 until round 6) independent 2^20-row
 traces per GPU, one per prover context, proved concurrently (AoS trace rows resident in HBM -> bincode proof bytes on
 the host).  `value` is proofs/s = steps x batch x ranks / time.  (Rounds 1-3 counted one proof per step; the driver's
 20-step command then timed 35 ms, a region that starts and ends drained and is dominated by ramp and tail - that
@@ -34,9 +34,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=24, help="timed steps; one step = one batch of --inflight proofs per GPU")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-rows", type=int, default=20, help="log2 rows of the Add trace (default 20 = BASELINE config 2)")
-    ap.add_argument("--inflight", type=int, default=8,
-                    help="independent proofs in flight per GPU (one prover context + HIP stream + ~1.8 GB arena each); "
-                         "8 measured best on MI355X for both 20-step and 192-step regions (DESIGN.md section 7)")
+    ap.add_argument("--inflight", type=int, default=24,
+                    help="independent proofs in flight per GPU (one prover context + HIP stream + ~1.9 GB arena each); "
+                         "measured on MI355X at equal numbers of proofs: 12 make +2 %, 24 +3 % more proofs/s than 8, 36 / 48 "
+                         "no more, and 9 / 10 / 15 / 20 less than their neighbours 12 / 24 (DESIGN.md section 8)")
     ap.add_argument("--host-rows", action="store_true",
                     help="hand the trace rows over as host buffers (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -510,7 +511,7 @@ def main(argv=None):
 
     def variant_throughput(tables, variant, steps, what, n_ctx=None):
         """proofs/s + solo latency of another workload on its own contexts (device-resident rows)"""
-        ps = [mk_prover(protocol_variant=variant) for _ in range(n_ctx or inflight)]
+        ps = [mk_prover(protocol_variant=variant) for _ in range(n_ctx or min(inflight, 8))]   # (sub-results: as in rounds 2 - 5)
         bs = [[(k, q.ctx.upload(r), len(r)) for k, r in tables] for q in ps]
         try:
             for q, bb in zip(ps, bs):

@@ -56,6 +56,25 @@ Context::Context(int device, const lmn_config& c) : cfg(c), device_(device) {
     static const bool cycle = !(getenv("LMN_STREAM_PRIO_CYCLE") && atoi(getenv("LMN_STREAM_PRIO_CYCLE")) == 0);
     static std::atomic<int> counter{0};
     int lo = 0, hi = 0;
+    // LMN_CU_SPLIT=P[:1] (experiment of round 6, docs/SWITCHES.md): context k's stream runs on partition k mod P of the CUs
+    // only (P = 2, 4, 8; contiguous mask bits, or ":1" = bit i belongs to partition (i mod 8) * P / 8) - do launches of
+    // different proofs overlap better side by side on parts of the chip than queued behind each other on all of it?
+    static const char* split_env = getenv("LMN_CU_SPLIT");
+    const int parts = split_env ? atoi(split_env) : 0;
+    if (parts == 2 || parts == 4 || parts == 8) {
+      static std::atomic<int> split_counter{0};
+      const int part = split_counter.fetch_add(1) % parts;
+      const bool by_xcd = strstr(split_env, ":1") != nullptr;
+      hipDeviceProp_t prop;
+      LMN_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+      const int n_cu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+      for (int i = 0; i < n_cu; ++i) {
+        const int owner = by_xcd ? (i % 8) * parts / 8 : (int)((int64_t)i * parts / n_cu);
+        if (owner == part) mask[(size_t)i / 32] |= 1u << (i % 32);
+      }
+      LMN_HIP_CHECK(hipExtStreamCreateWithCUMask(&stream_, (uint32_t)mask.size(), mask.data()));
+    } else
     if (cycle && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
       const int span = lo - hi + 1;                     // lo = least priority (numerically greatest)
       const int prio = hi + (counter.fetch_add(1) % span);
