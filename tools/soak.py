@@ -3,18 +3,20 @@ sys.path.insert(0, ".")
 import numpy as np, luminair_amd
 from luminair_amd import synthetic as syn, backend
 tabs = syn.config2_add_only(1 << 20, 42)
-provers = [luminair_amd.Prover(0) for _ in range(4)]
+N_CTX = int(sys.argv[1]) if len(sys.argv) > 1 else 4          # contexts = proofs in flight
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 2400 // N_CTX
+provers = [luminair_amd.Prover(0) for _ in range(N_CTX)]
 bufs = [[(k, p.ctx.upload(r), len(r)) for k, r in tabs] for p in provers]
 ref = hashlib.sha256(provers[0].ctx.prove_tables(bufs[0])).hexdigest()
 bad = []
 def work(i):
-    for it in range(600):
+    for it in range(ITERS):
         h = hashlib.sha256(provers[i].ctx.prove_tables(bufs[i])).hexdigest()
         if h != ref: bad.append((i, it, h))
 t0 = time.time()
-ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+ths = [threading.Thread(target=work, args=(i,)) for i in range(N_CTX)]
 [t.start() for t in ths]; [t.join() for t in ths]
-print("2400 concurrent proofs in %.1f s, mismatches: %d" % (time.time() - t0, len(bad)), ref[:16])
+print("%d concurrent proofs on %d contexts in %.1f s (%.0f proofs/s), mismatches: %d" % (N_CTX * ITERS, N_CTX, time.time() - t0, N_CTX * ITERS / (time.time() - t0), len(bad)), ref[:16])
 # mixed workloads concurrently: LUT graph (PINNED) + chain + linear layer, each checked against its own first result
 import itertools
 jobs = [("chain", syn.chain_graph(30000, 3), None, backend.VARIANT_KAT), ("linear", syn.linear_layer(200, 300, 4, True), None, backend.VARIANT_KAT)]
