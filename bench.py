@@ -658,8 +658,10 @@ def main(argv=None):
             from luminair_amd.batch import BatchProver
             res = {}
             tabs4, luts4 = syn.config4_black_scholes_shape()
-            for name, mk, luts, B in (("reference_shape_32x32_add", lambda i: syn.config2_graph_faithful(1024, 100 + i), None, 64),
-                                      ("config_4", lambda i: tabs4, luts4, 16)):
+            # (G = batch groups driven at once in `concurrent_groups`: 3 pay on the host-bound 32x32 shape - 30 against 21 k
+            # proofs/s; config 4's batches are GPU-bound: 1 / 2 / 3 groups = 1 525 / 1 580 / 1 340, tools/small_proof_groups.py)
+            for name, mk, luts, B, G in (("reference_shape_32x32_add", lambda i: syn.config2_graph_faithful(1024, 100 + i), None, 64, 3),
+                                         ("config_4", lambda i: tabs4, luts4, 16, 2)):
                 pies = [[(k, r, len(r)) for k, r in mk(i)] for i in range(B)]
                 sp = mk_prover(protocol_variant=_bk.VARIANT_PINNED)
                 want = sp.ctx.prove_tables(pies[0], luts)
@@ -681,8 +683,23 @@ def main(argv=None):
                     bp.close()
                 res[name] = {"value": B * reps / dt, "unit": "proofs/s", "proofs_per_batch": B, "ms_per_batch": 1e3 * dt / reps,
                              "solo_lmn_prove_latency_ms": solo_ms, "bytes_identical_to_lmn_prove": True}
+                # several groups at once (BatchPool): the host code of one group's members overlaps the launches of another's
+                from luminair_amd.batch import BatchPool
+                pool = BatchPool(dev, G, B, protocol_variant=_bk.VARIANT_PINNED)
+                try:
+                    many = pies * (G * 4)
+                    got = pool.prove_many(many, luts)
+                    if got[0] != want or got[-B] != want:
+                        raise RuntimeError("proof bytes from concurrent batch groups differ from lmn_prove")
+                    t0 = time.perf_counter()
+                    pool.prove_many(many, luts)
+                    dt = time.perf_counter() - t0
+                finally:
+                    pool.close()
+                res[name]["concurrent_groups"] = {"value": len(many) / dt, "unit": "proofs/s", "groups": G, "proofs_per_batch": B,
+                                                  "bytes_identical_to_lmn_prove": True}
             res["note"] = ("lmn_batch_prove: B pies of identical shape in lock-step, one launch per pipeline step for the whole "
-                           "batch (host rows, PINNED variant); config 4 = 2->64->64->1 tanh MLP shape with its 2^17-row exp2 LUT")
+                           "batch (host rows, PINNED variant); `concurrent_groups`: several such groups driven at once (BatchPool); config 4 = 2->64->64->1 tanh MLP shape with its 2^17-row exp2 LUT")
             return res
         line["small_proofs"] = sub_result("small_proofs", run_small)
     if anchor:

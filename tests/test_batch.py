@@ -201,3 +201,28 @@ def test_gpu_batch_pie_with_a_non_canonical_word_fails_alone(gpu_prover):
         assert solo.ctx.prove_tables(good[1]) == bp.prove_batch([good[1]])[0]
     finally:
         bp.close()
+
+
+@pytest.mark.gpu
+def test_gpu_concurrent_batch_groups_equal_lmn_prove(gpu_prover):
+    """Three batch groups driven at once (`BatchPool`: one thread per group; while one group's members run their host code
+    another group's launches use the GPU): every proof byte-identical to `lmn_prove`'s, in input order, for more pies than
+    the groups hold at once and a last batch that is not full."""
+    import luminair_amd
+    from luminair_amd.batch import BatchPool
+    solo = luminair_amd.Prover(0, protocol_variant=backend.VARIANT_PINNED)
+    pool = BatchPool(0, groups=3, slots=8, protocol_variant=backend.VARIANT_PINNED)
+    try:
+        pies = [[(k, r, len(r)) for k, r in syn.config2_graph_faithful(1024, 300 + i)] for i in range(45)]
+        want = [solo.ctx.prove_tables(p) for p in pies]
+        for _ in range(3):
+            assert pool.prove_many(pies) == want
+        # a pie that violates its constraints fails its own batch call; the pool raises and stays usable
+        bad = [(k, r.copy(), n) for k, r, n in pies[9]]
+        bad[0][1][5, 11] = (int(bad[0][1][5, 11]) + 1) % ((1 << 31) - 1)
+        with pytest.raises(backend.LuminairBackendError) as e:
+            pool.prove_many(pies[:9] + [bad] + pies[10:])
+        assert e.value.code == backend.ERR_CONSTRAINTS
+        assert pool.prove_many(pies) == want
+    finally:
+        pool.close()

@@ -148,17 +148,35 @@ def scenario_growth(batch_so):
         solo.close()
 
 
+def scenario_two_groups(batch_so, rows=64, slots=3, n_pies=8):
+    """two batch groups driven at once (`BatchPool`): the groups share the library's registries (page-locked ranges, twiddle
+    tables) and nothing else"""
+    from luminair_amd.batch import BatchPool
+    solo = _solo(backend.VARIANT_PINNED)
+    pool = BatchPool(0, groups=2, slots=slots, protocol_variant=backend.VARIANT_PINNED, library_path=batch_so)
+    try:
+        pies = [_pie(syn.config2_graph_faithful(rows, 70 + i)) for i in range(n_pies)]
+        want = [solo.prove_tables(p) for p in pies]
+        assert pool.prove_many(pies) == want
+        assert pool.prove_many(pies[:slots + 1]) == want[:slots + 1]
+    finally:
+        pool.close()
+        solo.close()
+
+
 def run_all(batch_so, small=False):
     kat = open(os.path.join(ROOT, "tests", "golden", "kat_simple", "proof"), "rb").read()
     if small:     # the thread sanitizer tracks every fiber switch of every emulated lane (~30 s per 16-row proof): three
         # members on two worker threads, a smaller batch, a refused mix, a bad pie failing alone, the slot proving again
         scenario_kat_and_fewer_threads_than_members(batch_so, kat, members=3)
         scenario_failures(batch_so, 12, repeats=1)
+        scenario_two_groups(batch_so, rows=12, slots=2, n_pies=4)
         return
     scenario_kat_and_fewer_threads_than_members(batch_so, kat)
     scenario_failures(batch_so)
     scenario_growth(batch_so)
     scenario_operators(batch_so)
+    scenario_two_groups(batch_so)
 
 
 def test_emu_batch_kat_and_more_members_than_worker_threads(kat_bytes):
@@ -167,6 +185,10 @@ def test_emu_batch_kat_and_more_members_than_worker_threads(kat_bytes):
 
 def test_emu_batch_bad_pies_fail_alone_and_mixed_shapes_are_refused():
     scenario_failures(_build())
+
+
+def test_emu_two_batch_groups_at_once():
+    scenario_two_groups(_build())
 
 
 def test_emu_batch_grows_across_calls():
