@@ -16,7 +16,10 @@ extern "C" {
  * one launch per pipeline step and one host wait per transcript step for the whole batch; every proof is byte-identical
  * to what lmn_prove returns for its pie.  tables[i] = the n_tables tables of pie i; proofs[i] / lens[i] receive
  * lmn_free-able bytes; rcs (may be NULL) the per-pie status.  Returns LMN_OK or the first failing pie's code; pies of
- * different shapes -> LMN_ERR_INVALID_ARGUMENT. */
+ * different shapes -> LMN_ERR_INVALID_ARGUMENT.
+ * Threads: calls on ONE batch object are serialised by the object; DIFFERENT batch objects are independent and may be
+ * driven from different threads at the same time - three objects of 64 slots make 30 k instead of 21 k proofs/s on the
+ * reference's benchmark shape, because one group's host code overlaps another group's launches. */
 typedef struct lmn_batch lmn_batch;
 int lmn_batch_create(int device, const lmn_config* cfg, uint32_t slots, lmn_batch** out);
 int lmn_batch_prove(lmn_batch* batch, uint32_t n, const lmn_table* const* tables, size_t n_tables,
