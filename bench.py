@@ -660,8 +660,9 @@ def main(argv=None):
             tabs4, luts4 = syn.config4_black_scholes_shape()
             # (G = batch groups driven at once in `concurrent_groups`: 3 pay on the host-bound 32x32 shape - 30 against 21 k
             # proofs/s; config 4's batches are GPU-bound: 1 / 2 / 3 groups = 1 525 / 1 580 / 1 340, tools/small_proof_groups.py)
-            for name, mk, luts, B, G in (("reference_shape_32x32_add", lambda i: syn.config2_graph_faithful(1024, 100 + i), None, 64, 3),
-                                         ("config_4", lambda i: tabs4, luts4, 16, 2)):
+            # PB = slots per group there: 3 x 64 = 30, 3 x 128 = 36, 3 x 192 or 256 = 40 k proofs/s on the 32x32 shape)
+            for name, mk, luts, B, G, PB in (("reference_shape_32x32_add", lambda i: syn.config2_graph_faithful(1024, 100 + i), None, 64, 3, 192),
+                                             ("config_4", lambda i: tabs4, luts4, 16, 2, 16)):
                 pies = [[(k, r, len(r)) for k, r in mk(i)] for i in range(B)]
                 sp = mk_prover(protocol_variant=_bk.VARIANT_PINNED)
                 want = sp.ctx.prove_tables(pies[0], luts)
@@ -685,18 +686,18 @@ def main(argv=None):
                              "solo_lmn_prove_latency_ms": solo_ms, "bytes_identical_to_lmn_prove": True}
                 # several groups at once (BatchPool): the host code of one group's members overlaps the launches of another's
                 from luminair_amd.batch import BatchPool
-                pool = BatchPool(dev, G, B, protocol_variant=_bk.VARIANT_PINNED)
+                pool = BatchPool(dev, G, PB, protocol_variant=_bk.VARIANT_PINNED)
                 try:
-                    many = pies * (G * 4)
+                    many = (pies + [[(k, r, len(r)) for k, r in mk(i)] for i in range(B, PB)]) * (G * 4)
                     got = pool.prove_many(many, luts)
-                    if got[0] != want or got[-B] != want:
+                    if got[0] != want or got[-PB] != want:
                         raise RuntimeError("proof bytes from concurrent batch groups differ from lmn_prove")
                     t0 = time.perf_counter()
                     pool.prove_many(many, luts)
                     dt = time.perf_counter() - t0
                 finally:
                     pool.close()
-                res[name]["concurrent_groups"] = {"value": len(many) / dt, "unit": "proofs/s", "groups": G, "proofs_per_batch": B,
+                res[name]["concurrent_groups"] = {"value": len(many) / dt, "unit": "proofs/s", "groups": G, "proofs_per_batch": PB,
                                                   "bytes_identical_to_lmn_prove": True}
             res["note"] = ("lmn_batch_prove: B pies of identical shape in lock-step, one launch per pipeline step for the whole "
                            "batch (host rows, PINNED variant); `concurrent_groups`: several such groups driven at once (BatchPool); config 4 = 2->64->64->1 tanh MLP shape with its 2^17-row exp2 LUT")

@@ -96,7 +96,7 @@ class BatchPool:
     """`groups` lock-step batch groups of `slots` pies each, driven concurrently (one thread per group inside `prove_many`):
     while the members of one group run their host code - a third of a 64-pie batch's 2.9 ms on the reference's benchmark
     shape - the launches of another group use the GPU.  Measured on MI355X, 32x32 Add pies: 1 / 2 / 3 groups of 64 =
-    21 / 24 / 30 k proofs/s (tools/small_proof_groups.py; 4 groups: lower and unsteady).  Every proof is byte-identical to
+    21 / 24 / 30 k proofs/s, 3 groups of 192: 40 k (tools/small_proof_groups.py; 4 groups: lower and unsteady).  Every proof is byte-identical to
     `Prover.prove`'s; `prove_many` returns the proofs in input order."""
 
     def __init__(self, device: int = 0, groups: int = 3, slots: int = 64, protocol_variant: int = backend.VARIANT_KAT,
