@@ -54,7 +54,7 @@ class ProverPool:
     single-threaded caller of the reference's `prove` keeps the chip busy (eight proofs in flight saturate an MI355X; 12 make
     2 %, 24 make 3 % more proofs/s at 1.9 GB of device memory per context and 2^20 rows).  `prove_many` returns the proofs in input order."""
 
-    def __init__(self, device: int = 0, n: int = 8, protocol_variant: int = backend.VARIANT_KAT, library=None, **pcs):
+    def __init__(self, device: int = 0, n: int = 12, protocol_variant: int = backend.VARIANT_KAT, library=None, **pcs):
         self.provers = [Prover(device, protocol_variant, library, **pcs) for _ in range(max(1, n))]
 
     def prove_many(self, pies, settings: Optional[CircuitSettings] = None):
