@@ -587,7 +587,7 @@ def main(argv=None):
                    "per_rank_proofs_per_s": {"min": min(r["proofs_per_s"] for r in per_rank), "max": max(r["proofs_per_s"] for r in per_rank),
                                              "all": [round(r["proofs_per_s"], 1) for r in per_rank]},
                    "cpu_affinity": [r["affinity"] for r in per_rank],
-                   "host_cpu_budget": round(budget, 1), "host_wait_spin_us": os.environ.get("LMN_SPIN_US", "3000 (default)"),
+                   "host_cpu_budget": round(budget, 1), "host_wait_spin_us": os.environ.get("LMN_SPIN_US", "3000 (default; 100 while several proofs are in flight)"),
                    "host_wait_policy_set_by_bench": spin_set_by_bench,   # True: fewer than 4 CPUs per rank, waits sleep between polls
                    "ms_per_step_is": "per batch of %d proofs (rounds 1-3: per proof; compare `ms_per_proof` / `short_region`)" % inflight,
                    "proof_bytes": len(out["proof"])},
