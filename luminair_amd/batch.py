@@ -96,12 +96,24 @@ class BatchPool:
     """`groups` lock-step batch groups of `slots` pies each, driven concurrently (one thread per group inside `prove_many`):
     while the members of one group run their host code - a third of a 64-pie batch's 2.9 ms on the reference's benchmark
     shape - the launches of another group use the GPU.  Measured on MI355X, 32x32 Add pies: 1 / 2 / 3 groups of 64 =
-    21 / 24 / 30 k proofs/s, 3 groups of 192: 40 k (tools/small_proof_groups.py; 4 groups: lower and unsteady).  Every proof is byte-identical to
+    21 / 24 / 30 k proofs/s, 3 groups of 192: 40 k, with 4 instead of 8 worker threads per group 44 - 47 k
+    (tools/small_proof_groups.py).  Every proof is byte-identical to
     `Prover.prove`'s; `prove_many` returns the proofs in input order."""
 
     def __init__(self, device: int = 0, groups: int = 3, slots: int = 64, protocol_variant: int = backend.VARIANT_KAT,
                  library_path: Optional[str] = None, **pcs):
-        self.groups = [BatchProver(device, slots, protocol_variant, library_path, **pcs) for _ in range(max(1, groups))]
+        # worker threads per group (LMN_BATCH_THREADS, read by lmn_batch_create; 8 when a group is alone): the groups' workers
+        # spin at their rendezvous, and about a dozen of them in the process is the plateau - 3 groups of 192 pies make 44 - 47 k
+        # proofs/s with 4 workers each, 38 - 40 k with 8, 14 - 16 k with 24 (tools/small_proof_groups.py)
+        groups = max(1, groups)
+        own_env = "LMN_BATCH_THREADS" not in os.environ
+        if own_env:
+            os.environ["LMN_BATCH_THREADS"] = str(max(2, min(8, 12 // groups)))
+        try:
+            self.groups = [BatchProver(device, slots, protocol_variant, library_path, **pcs) for _ in range(groups)]
+        finally:
+            if own_env:
+                del os.environ["LMN_BATCH_THREADS"]
         self.slots = slots
 
     def prove_many(self, pies: Sequence[Sequence[Tuple[int, object, int]]], luts=None) -> List[bytes]:
