@@ -104,10 +104,14 @@ struct BatchGroup {
   bool solo = false;
   // (members still taking part) << 32 | (members arrived at the rendezvous in progress): one wait-free fetch_add per
   // arrival - lock-step members arrive within a microsecond of each other, a lock here is a convoy
-  std::atomic<uint64_t> state{1ull << 32};
-  std::atomic_flag lock = ATOMIC_FLAG_INIT;   // counters only
-  std::atomic<uint64_t> generation{0};
+  // (own cache line: every arrival writes it - next to `generation`, which every waiting worker thread polls, each arrival
+  // took the line away from all of them: the more worker threads in the process, the slower the rendezvous; end of round 6)
+  alignas(128) std::atomic<uint64_t> state{1ull << 32};
+  alignas(128) std::atomic_flag lock = ATOMIC_FLAG_INIT;   // counters only
+  // written once per rendezvous by the last arriver, polled by everybody else
+  alignas(128) std::atomic<uint64_t> generation{0};
   std::atomic<int> failed{0};    // members diverged (different kernel / shape): every member throws at its next rendezvous
+  alignas(128)
   // Table memory, mirrored in page-locked host and device memory, in two halves used by alternating synchronisation
   // epochs.  Every member executes the same launch sequence, so each computes the table offsets itself (tbl_off):
   // no shared allocator on the launch path.
