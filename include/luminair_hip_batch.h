@@ -19,7 +19,7 @@ extern "C" {
  * different shapes -> LMN_ERR_INVALID_ARGUMENT.
  * Threads: calls on ONE batch object are serialised by the object; DIFFERENT batch objects are independent and may be
  * driven from different threads at the same time - three objects of 64 slots make 30 k instead of 21 k proofs/s on the
- * reference's benchmark shape (three of 192 slots with LMN_BATCH_THREADS=4 - about a dozen worker threads per process is the plateau -: 44 - 47 k), because one group's host code overlaps another group's launches. */
+ * reference's benchmark shape (three of 192 slots: 46 - 49 k; keep the worker threads of all batch objects of a process - LMN_BATCH_THREADS each, default 8 - at 24 or fewer), because one group's host code overlaps another group's launches. */
 typedef struct lmn_batch lmn_batch;
 int lmn_batch_create(int device, const lmn_config* cfg, uint32_t slots, lmn_batch** out);
 int lmn_batch_prove(lmn_batch* batch, uint32_t n, const lmn_table* const* tables, size_t n_tables,

@@ -96,19 +96,19 @@ class BatchPool:
     """`groups` lock-step batch groups of `slots` pies each, driven concurrently (one thread per group inside `prove_many`):
     while the members of one group run their host code - a third of a 64-pie batch's 2.9 ms on the reference's benchmark
     shape - the launches of another group use the GPU.  Measured on MI355X, 32x32 Add pies: 1 / 2 / 3 groups of 64 =
-    21 / 24 / 30 k proofs/s, 3 groups of 192: 40 k, with 4 instead of 8 worker threads per group 44 - 47 k
+    21 / 24 / 30 k proofs/s, 3 groups of 192: 40 k, 46 - 49 k since the workers back off while idle
     (tools/small_proof_groups.py).  Every proof is byte-identical to
     `Prover.prove`'s; `prove_many` returns the proofs in input order."""
 
     def __init__(self, device: int = 0, groups: int = 3, slots: int = 64, protocol_variant: int = backend.VARIANT_KAT,
                  library_path: Optional[str] = None, **pcs):
-        # worker threads per group (LMN_BATCH_THREADS, read by lmn_batch_create; 8 when a group is alone): the groups' workers
-        # spin at their rendezvous, and about a dozen of them in the process is the plateau - 3 groups of 192 pies make 44 - 47 k
-        # proofs/s with 4 workers each, 38 - 40 k with 8, 14 - 16 k with 24 (tools/small_proof_groups.py)
+        # worker threads per group (LMN_BATCH_THREADS, read by lmn_batch_create; 8 when a group is alone): the throughput collapses
+        # when the process has many of them - 3 groups of 192 pies make 46 - 49 k proofs/s with 8 workers each, 43 - 44 k with 4,
+        # 20 - 22 k with 16, 12 k with 24 (tools/small_proof_groups.py, profiles/r6_small_proof_groups_threads.txt): at most 24 in all
         groups = max(1, groups)
         own_env = "LMN_BATCH_THREADS" not in os.environ
         if own_env:
-            os.environ["LMN_BATCH_THREADS"] = str(max(2, min(8, 12 // groups)))
+            os.environ["LMN_BATCH_THREADS"] = str(max(2, min(8, 24 // groups)))
         try:
             self.groups = [BatchProver(device, slots, protocol_variant, library_path, **pcs) for _ in range(groups)]
         finally:

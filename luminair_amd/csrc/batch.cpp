@@ -646,6 +646,7 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
 #endif
     }
     uint32_t left = mine;
+    uint32_t idle_pauses = 1u;
     while (left) {
       bool progress = false;
       for (uint32_t i = 0; i < mine; ++i) {
@@ -668,10 +669,15 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
         progress = true;
         if (f.done) --left;
       }
+      // nothing runnable: back off (1 .. 64 pauses) - a worker that polls at full speed takes issue slots from the hardware
+      // thread next to it, which may be the one whose member everybody is waiting for
       if (!progress) {
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+        for (uint32_t k = 0; k < idle_pauses; ++k) __builtin_ia32_pause();
 #endif
+        if (idle_pauses < 64u) idle_pauses *= 2u;
+      } else {
+        idle_pauses = 1u;
       }
     }
     lmn::tls_batch_group = nullptr;
