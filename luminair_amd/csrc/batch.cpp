@@ -197,8 +197,65 @@ static void stream_wait(hipStream_t s) {
 // Members are FIBERS: a handful of OS threads each run several members, switching at every rendezvous.  (One spinning
 // thread per member was the first design: beyond ~32 members the waiting threads alone exhaust the CPU time a
 // container is entitled to and the batch time explodes - measured on the MI355X boxes, tools/small_proof_batch.py.)
+// Switching between a worker's scheduler and its member fibers: ucontext.  glibc's swapcontext saves and restores the signal mask -
+// one rt_sigprocmask system call per switch, on a lock (sighand->siglock) that all threads of the process share - and that was the
+// suspect for the collapse of several groups' throughput with the number of worker threads (end of round 6).  Measured with a switch
+// of our own (-DLMN_BATCH_FIBER_ASM, x86-64: callee-saved registers, the two floating-point control words, the stack pointer; byte-
+// identical proofs on the emulated and the GPU batch library): no difference - 3 groups of 192 with 8 / 16 / 24 workers each 42 / 24 /
+// 13 k proofs/s either way (gpurun_out/r11m).  Not the cause; the experiment build stays.
+#if defined(__x86_64__) && defined(LMN_BATCH_FIBER_ASM)
+#define LMN_FIBER_ASM 1
+struct FiberCtx {
+  void* sp = nullptr;
+};
+extern "C" void lmn_fiber_switch(FiberCtx* from, FiberCtx* to);
+#if !defined(__HIP_DEVICE_COMPILE__)
+asm(R"(
+  .text
+  .p2align 4
+  .globl lmn_fiber_switch
+  .type lmn_fiber_switch,@function
+lmn_fiber_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+  .size lmn_fiber_switch,.-lmn_fiber_switch
+)");
+#endif
+// a context that starts `entry` on the given stack at its first switch; `entry` must never return
+static void fiber_ctx_prepare(FiberCtx& c, void* stack, size_t bytes, void (*entry)()) {
+  uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+  uint64_t* sp = reinterpret_cast<uint64_t*>(top - 72);   // control words | r15 r14 r13 r12 rbx rbp | entry | (no caller)
+  sp[0] = 0x1f80ull | (0x037full << 32);                   // default MXCSR, default x87 control word
+  for (int k = 1; k <= 6; ++k) sp[k] = 0;
+  sp[7] = (uint64_t)(uintptr_t)entry;                      // popped by the switch's ret: rsp = top - 8, as right after a call
+  sp[8] = 0;                                               // where a caller's return address would be: the unwinder stops here
+  c.sp = sp;
+}
+#else
+typedef ucontext_t FiberCtx;
+#endif
+
 struct BatchFiber {
-  ucontext_t ctx;
+  FiberCtx ctx;
   void* stack = nullptr;
   lmn_batch* batch = nullptr;
   int member = 0;
@@ -212,7 +269,7 @@ struct BatchFiber {
   void* tsan_fiber = nullptr;
 #endif
 };
-static thread_local ucontext_t tls_sched_ctx;
+static thread_local FiberCtx tls_sched_ctx;
 static thread_local BatchFiber* tls_fiber = nullptr;
 #ifdef LMN_BATCH_ASAN
 static thread_local void* tls_sched_fake = nullptr;
@@ -230,7 +287,11 @@ static void fiber_yield(BatchFiber* f) {
 #ifdef LMN_BATCH_TSAN
   __tsan_switch_to_fiber(tls_sched_tsan, 0);
 #endif
+#ifdef LMN_FIBER_ASM
+  lmn_fiber_switch(&f->ctx, &tls_sched_ctx);
+#else
   swapcontext(&f->ctx, &tls_sched_ctx);
+#endif
 #ifdef LMN_BATCH_ASAN
   __sanitizer_finish_switch_fiber(f->fake_stack, &tls_sched_bottom, &tls_sched_size);
 #endif
@@ -587,6 +648,11 @@ static void fiber_entry() {
   // not by returning: this frame's function-exit event would be recorded after the switch, i.e. popped from the SCHEDULER's
   // shadow stack - one entry too many per finished member, until the worker thread's own frames underflow it
   __tsan_switch_to_fiber(lmn::tls_sched_tsan, 0);
+#endif
+#ifdef LMN_FIBER_ASM
+  lmn::lmn_fiber_switch(&f->ctx, &lmn::tls_sched_ctx);   // never resumed (the entry of a prepared context must not return)
+  __builtin_unreachable();
+#elif defined(LMN_BATCH_TSAN)
   setcontext(&lmn::tls_sched_ctx);
 #endif
 }
@@ -630,15 +696,21 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
     for (uint32_t m = w; m < n; m += b->n_threads, ++k) {
       lmn::BatchFiber& f = fibers[k];
       if (!f.stack) f.stack = fiber_stack_alloc();
+#ifdef LMN_FIBER_ASM
+      lmn::fiber_ctx_prepare(f.ctx, f.stack, BATCH_FIBER_STACK, fiber_entry);
+#else
       getcontext(&f.ctx);
       f.ctx.uc_stack.ss_sp = f.stack;
       f.ctx.uc_stack.ss_size = BATCH_FIBER_STACK;
       f.ctx.uc_link = &lmn::tls_sched_ctx;
+#endif
       f.batch = b;
       f.member = (int)m;
       f.done = false;
       f.waiting = false;
+#ifndef LMN_FIBER_ASM
       makecontext(&f.ctx, fiber_entry, 0);
+#endif
 #ifdef LMN_BATCH_TSAN
       lmn::tls_sched_tsan = __tsan_get_current_fiber();
       if (f.tsan_fiber) __tsan_destroy_fiber(f.tsan_fiber);
@@ -661,7 +733,11 @@ static void batch_worker(lmn_batch* b, uint32_t w) {
 #ifdef LMN_BATCH_TSAN
         __tsan_switch_to_fiber(f.tsan_fiber, 0);
 #endif
+#ifdef LMN_FIBER_ASM
+        lmn::lmn_fiber_switch(&lmn::tls_sched_ctx, &f.ctx);
+#else
         swapcontext(&lmn::tls_sched_ctx, &f.ctx);
+#endif
 #ifdef LMN_BATCH_ASAN
         __sanitizer_finish_switch_fiber(lmn::tls_sched_fake, nullptr, nullptr);
 #endif
